@@ -1,0 +1,148 @@
+"""Pins the numpy oracle (oracle/vae_oracle.py) against golden vectors produced by the
+reference itself (tests/golden/gen_fixtures.py).  CPU only."""
+import os
+
+import numpy as np
+import pytest
+
+import simulgen_vae_amd  # noqa: F401
+from simulgen_vae_amd.init import init_state, synthetic_eps, synthetic_samples
+from simulgen_vae_amd.spec import VAEConfig, param_spec
+from oracle import vae_oracle as vo
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+G0 = dict(latent_dim=32, hierarchical_dim=8, enc=[32, 16, 8, 8], num_node=72, num_time=10)
+G1 = dict(latent_dim=32, hierarchical_dim=8, enc=[64, 32, 16, 8], num_node=520, num_time=12)
+
+
+def make(cfgd, small, lossfun):
+    cfg = VAEConfig(cfgd["latent_dim"], cfgd["hierarchical_dim"], cfgd["enc"], cfgd["enc"][::-1],
+                    cfgd["num_node"], cfgd["num_time"], lossfun, small)
+    return cfg
+
+
+def relerr(a, b):
+    a = np.asarray(a, np.float64)
+    b = np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-30))
+
+
+def run_steps(cfg, g):
+    alpha, beta, lr, sseed, dseed, eseed, B = g["meta"]
+    B = int(B)
+    m = vo.OracleVAE(cfg, init_state(cfg, int(sseed)))
+    res = []
+    for step in range(3):
+        x = synthetic_samples(int(dseed), range(step * B, (step + 1) * B), cfg.num_node, cfg.num_time)
+        eps = synthetic_eps(int(eseed), step, cfg, B)
+        xhat, rl, kls, mse = m.forward(x, eps)
+        snap = None
+        if step == 0:
+            snap = dict(xhat=xhat, acts=dict(m.acts), uv={k: v.copy() for k, v in m.P.items()
+                                                         if k.endswith("_u") or k.endswith("_v")})
+        grads = m.backward(alpha, beta)
+        gn = m.grad_norm()
+        loss = alpha * float(rl) + beta * sum(float(k) for k in kls)
+        if step == 0:
+            snap["grads"] = {k: (None if v is None else v.copy()) for k, v in grads.items()}
+        res.append((np.array([float(rl)] + [float(k) for k in kls] + [float(mse), loss, gn]), snap))
+        m.adamw_step(lr)
+        if step == 0:
+            res[0][1]["p1"] = {k: v.copy() for k, v in m.P.items()}
+    return m, res
+
+
+@pytest.mark.parametrize("tag,small", [("g0_small_MSE", True), ("g0_large_MSE", False)])
+def test_full_fixture(tag, small):
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    cfg = make(G0, small, "MSE")
+    m, res = run_steps(cfg, g)
+    sc0, snap = res[0]
+    np.testing.assert_allclose(sc0, g["scalars0"], rtol=2e-5)
+    assert relerr(snap["xhat"], g["x_hat"]) < 1e-5
+    for k in g.files:
+        if k.startswith("act."):
+            assert relerr(snap["acts"][k[4:]], g[k]) < 1e-5, k
+        elif k.startswith("uv1."):
+            assert relerr(snap["uv"][k[4:]], g[k]) < 1e-5, k
+        elif k.startswith("grad."):
+            assert relerr(snap["grads"][k[5:]], g[k]) < 5e-5, k
+        elif k.startswith("p1."):
+            assert relerr(snap["p1"][k[3:]], g[k]) < 1e-5, k
+    nograd = set(g["nograd"].tolist())
+    assert nograd == {k for k, v in snap["grads"].items() if v is None}
+    np.testing.assert_allclose(res[1][0], g["scalars1"], rtol=5e-5)
+    np.testing.assert_allclose(res[2][0], g["scalars2"], rtol=1e-4)
+    for e in param_spec(cfg):
+        assert relerr(m.P[e.name], g["s3." + e.name]) < 2e-4, e.name
+    # eval-mode forward and the mode='fix' decoder path on the step-3 state
+    B = int(g["meta"][6])
+    m.training = False
+    x = synthetic_samples(int(g["meta"][4]), range(100, 100 + B), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(int(g["meta"][5]), 100, cfg, B)
+    xhat, rl, kls, mse = m.forward(x, eps)
+    assert relerr(xhat, g["eval.x_hat"]) < 2e-4
+    np.testing.assert_allclose([float(rl)] + [float(k) for k in kls] + [float(mse)], g["eval.scalars"], rtol=5e-4)
+    assert relerr(m.acts["mu"], g["eval.mu"]) < 2e-4
+    m._W, m._sigma, m.acts = {}, {}, {}
+    mu, lv, xs = m.encoder(x)
+    for i, v in enumerate(xs):
+        assert relerr(v, g[f"eval.xs{i}"]) < 2e-4
+    z = vo.reparam_fwd(mu, lv, eps[0])
+    assert relerr(z, g["fix.z"]) < 2e-4
+    xfix, _ = m.decoder(z, xs, eps[1:], mode="fix")
+    assert relerr(xfix, g["fix.x_hat"]) < 2e-4
+
+
+@pytest.mark.parametrize("tag,cfgd,lossfun", [("g0_small_MAE", G0, "MAE"), ("g0_small_smoothL1", G0, "smoothL1"),
+                                              ("g0_small_Huber", G0, "Huber"), ("g1_small_MSE", G1, "MSE")])
+def test_norm_fixture(tag, cfgd, lossfun):
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    cfg = make(cfgd, True, lossfun)
+    m, res = run_steps(cfg, g)
+    sc0, snap = res[0]
+    np.testing.assert_allclose(sc0, g["scalars0"], rtol=3e-5)
+    assert relerr(snap["xhat"], g["x_hat"]) < 1e-5
+    for k in g.files:
+        if k.startswith("gradnorm."):
+            gn = np.linalg.norm(snap["grads"][k[9:]].astype(np.float64))
+            assert abs(gn - g[k]) <= 1e-4 * abs(g[k]) + 1e-12, k
+        elif k.startswith("s3norm."):
+            assert abs(np.linalg.norm(m.P[k[7:]].astype(np.float64)) - g[k]) <= 1e-4 * abs(g[k]), k
+    np.testing.assert_allclose(res[2][0], g["scalars2"], rtol=1e-4)
+
+
+def test_schedules():
+    g = np.load(os.path.join(GOLD, "schedules.npz"))
+    for E in (4, 8, 20, 40):
+        got = [vo.cosine_warm_restarts_lr(1e-3, E, e) for e in range(E)]
+        np.testing.assert_allclose(got, g[f"lr_E{E}"], rtol=1e-9)
+    for E in (4, 10, 20):
+        got = [vo.beta_schedule(E, e) for e in range(E)]
+        np.testing.assert_allclose(got, g[f"beta_E{E}"], rtol=1e-12)
+    with pytest.raises(ValueError):
+        vo.cosine_warm_restarts_lr(1e-3, 2, 0)   # epochs < 4 raises in the reference
+
+
+def test_augmentation():
+    g = np.load(os.path.join(GOLD, "augment.npz"))
+    P, N, T = g["shape"]
+    data = synthetic_samples(20251003, range(P), N, T)
+    rand, randint, beta, noise = list(g["rand"]), list(g["randint"]), list(g["beta"]), list(g["noise"])
+    for i in range(P):
+        dec = {}
+        dec["noise"] = rand.pop(0) < 0.5
+        nz = noise.pop(0) if dec["noise"] else None
+        dec["scale"] = (0.9 + rand.pop(0) * (1.1 - 0.9)) if rand.pop(0) < 0.5 else None
+        rand.pop(0)  # shift draw (prob 0)
+        other = None
+        if rand.pop(0) < 0.5:
+            o = int(randint.pop(0))
+            while o == i:
+                o = int(randint.pop(0))
+            other = data[o]
+            dec["lam"] = beta.pop(0)
+        rand.pop(0)  # cutout draw (prob 0)
+        out = vo.augment_sample(data[i], other, nz, dec)
+        np.testing.assert_allclose(out, g["out"][i], rtol=1e-6, atol=1e-7)
+    assert not rand and not randint and not beta and not noise
