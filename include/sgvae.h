@@ -1,0 +1,170 @@
+/*
+ * sgvae.h -- C ABI of libsgvae.so: the MI355X-native (gfx950) engine for the SimulGen-VAE
+ * training step.
+ *
+ * The reference (leesihun/SimulGen-VAE) has no FFI/plugin boundary for this path: it sits behind
+ * Python classes.  Each entry point below names the reference interface it stands in for
+ * (paths relative to the reference root).  The build's own host-side mirror
+ * (simulgen-vae_amd/modules/, same names and argument meaning as the reference's
+ * modules/ package) binds these symbols through ctypes; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions: every function returns 0 on success or a negative sgv_status; the message of the
+ * last failure on the calling thread is sgv_last_error().  No C++ exception crosses the ABI.
+ * The caller owns every buffer it passes; the engine owns parameters, optimizer state and
+ * workspace.  All device work is enqueued on the hipStream_t given to sgv_create (pass the
+ * stream PyTorch-ROCm is using so that it composes with torch tensors); nothing here
+ * synchronises the stream except the explicitly host-returning calls (marked [sync]).
+ * One engine per process/thread; an engine is not thread-safe.
+ *
+ * Layouts: "reference layout" means exactly what the reference's tensors hold:
+ * activations [B, C, T] row-major fp32, parameters as in its state_dict.  Internally the engine
+ * keeps activations channels-last [B, T, C] and weights [tap][Cout][Cin]; conversion happens
+ * inside these calls.
+ */
+#ifndef SGVAE_H
+#define SGVAE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct sgv_engine sgv_engine;
+
+typedef enum {
+    SGV_OK = 0,
+    SGV_ERR_ARG = -1,      /* bad argument / unsupported configuration */
+    SGV_ERR_HIP = -2,      /* a HIP runtime call failed */
+    SGV_ERR_STATE = -3,    /* call order (e.g. backward before forward) */
+    SGV_ERR_NAME = -4,     /* unknown state_dict key */
+    SGV_ERR_NOGPU = -5     /* no gfx950 device visible: there is no CPU fallback */
+} sgv_status;
+
+enum { SGV_DTYPE_F32 = 0, SGV_DTYPE_BF16 = 1 };
+enum { SGV_LOSS_MSE = 0, SGV_LOSS_MAE = 1, SGV_LOSS_SMOOTHL1 = 2, SGV_LOSS_HUBER = 3 };
+enum { SGV_MAX_LEVELS = 8 };
+
+/* Mirrors the constructor arguments of modules.VAE_network.VAE (modules/VAE_network.py:60):
+ * VAE(latent_dim, hierarchical_dim, num_filter_enc, num_filter_dec, num_node, num_time,
+ *     lossfun, batch_size, small).  num_filter_dec is num_filter_enc reversed
+ * (SimulGen-VAE.py:219) and is not passed separately. */
+typedef struct {
+    int32_t latent_dim;
+    int32_t hierarchical_dim;
+    int32_t n_levels;
+    int32_t num_filter_enc[SGV_MAX_LEVELS];
+    int32_t num_node;
+    int32_t num_time;
+    int32_t max_batch;        /* per-GPU batch the workspace is sized for */
+    int32_t loss_type;        /* SGV_LOSS_* <- condition.txt Loss_type (SimulGen-VAE.py:208-215) */
+    int32_t small;            /* 1 <=> --size small */
+    int32_t compute_dtype;    /* SGV_DTYPE_*: storage/MFMA input type of activations and weight copies */
+    int32_t flags;            /* bit0: TN GEMM uses scalar LDS fragment reads instead of ds_read_tr */
+} sgv_config;
+
+/* Scalars written by forward, in the order VAE.forward returns them (VAE_network.py:117):
+ * [0] recon_loss (selected loss fn), [1] kl, [2] kl_2 stage 0, [3] kl_2 stage 1, ...,
+ * [1+n_kl] recon_loss_MSE; n_kl = n_levels - 1. */
+enum { SGV_MAX_SCALARS = 12 };
+
+const char* sgv_last_error(void);
+
+/* modules/VAE_network.py:60 VAE.__init__ (+ train.py:65,83 model creation / .to(device)). */
+int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out);
+int sgv_destroy(sgv_engine* e);
+
+/* nn.Module.state_dict() surface: key names/shapes of the reference (checkpoint row).
+ * kind: 0 bias, 1 weight_orig, 2 weight_u, 3 weight_v, 4 GroupNorm weight, 5 GroupNorm bias. */
+int sgv_param_count(const sgv_engine* e);
+int sgv_param_info(const sgv_engine* e, int index, const char** name, int* ndim, int64_t shape[4],
+                   int* kind, int* has_grad);
+/* load_state_dict / state_dict(): host fp32 buffers in reference layout.  [sync] */
+int sgv_load_state(sgv_engine* e, const char* name, const float* host, size_t count);
+int sgv_export_state(sgv_engine* e, const char* name, float* host, size_t count);
+/* p.grad of a parameter after sgv_backward (wrt weight_orig, i.e. with the spectral-norm chain
+ * rule applied), reference layout; *is_none = 1 for parameters that never get a gradient
+ * (train.py:157 `if p.grad is not None`).  [sync] */
+int sgv_export_grad(sgv_engine* e, const char* name, float* host, size_t count, int* is_none);
+/* Adam exp_avg / exp_avg_sq of a parameter (torch.optim.AdamW state), reference layout. [sync] */
+int sgv_export_adam(sgv_engine* e, const char* name, float* host_m, float* host_v, size_t count);
+
+/* Refresh the compute-dtype weight copies from the fp32 masters after sgv_load_state. */
+int sgv_prepare(sgv_engine* e);
+
+/* Batch input.  x_dev: device fp32 [batch, num_node, num_time] (the tensor train.py:142 hands to
+ * model(image)); converted to the internal layout/dtype. */
+int sgv_set_input(sgv_engine* e, const float* x_dev, int batch);
+/* Reparameterisation noise (decoder.py:221 torch.randn_like), device fp32, reference layouts
+ * [B,latent], [B,C,T]...; site 0 = top latent, 1.. = decoder stages.  If a site is never set the
+ * engine draws it from its Philox stream (sgv_seed). */
+int sgv_set_eps(sgv_engine* e, int site, const float* eps_dev, int batch);
+int sgv_seed(sgv_engine* e, uint64_t seed);
+/* Engine switches: "write_xhat" (materialise the reconstruction in training forwards; default 1),
+ * "use_tr" (weight-gradient GEMM reads LDS with ds_read_b64_tr_b16; default 1). */
+int sgv_set_option(sgv_engine* e, const char* key, int value);
+
+/* VAE.forward (VAE_network.py:79-121) on the current input.  train != 0: spectral-norm power
+ * iteration runs (model.train()); mode_fix != 0: Decoder.forward(mode="fix") (decoder.py:209-210).
+ * scalars_host (may be NULL): SGV_MAX_SCALARS floats, filled after a stream sync.  [sync if given] */
+int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host);
+/* Encoder.forward only (utils.py:492): mu, log_var [B,latent], xs [n_levels-1][B,hier] to host. [sync] */
+int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host);
+/* Reconstruction of the last forward, reference layout [B, num_node, num_time] fp32 on device. */
+int sgv_get_xhat(sgv_engine* e, float* xhat_dev);
+/* Named intermediate of the last forward as fp32 reference layout on host (parity tests):
+ * "enc_h<i>", "dec_out<i>", "zmap<i>", "mu", "log_var", "z", "xs<i>".  [sync] */
+int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t count);
+
+/* loss = alpha*recon + beta*sum(kl); loss.backward() (train.py:144-153). */
+int sgv_backward(sgv_engine* e, float alpha, float beta);
+/* Callback invoked from inside sgv_backward (host side, after the kernels producing a gradient
+ * bucket have been enqueued) so the caller can overlap its all-reduce of
+ * [sgv_grad_buffer + offset, +count) with the rest of backward.  Buckets arrive in
+ * reverse-autograd order. */
+typedef void (*sgv_bucket_cb)(void* user, int bucket, size_t offset_elems, size_t count_elems);
+int sgv_set_bucket_callback(sgv_engine* e, sgv_bucket_cb cb, void* user);
+/* The flat fp32 gradient arena (device) of all parameters that receive gradients; what the
+ * data-parallel all-reduce (RCCL via torch.distributed) operates on. */
+int sgv_grad_buffer(sgv_engine* e, float** dev_ptr, size_t* count_elems);
+int sgv_scale_grads(sgv_engine* e, float factor);
+
+/* Gradient 2-norm as train.py:156-161 computes it.  [sync] */
+int sgv_grad_norm(sgv_engine* e, double* out);
+/* torch.optim.AdamW(lr).step() with its defaults (train.py:92,168): betas (0.9, 0.999),
+ * eps 1e-8, weight_decay 0.01; skips parameters without gradient.  Also refreshes the
+ * compute-dtype weight copies. */
+int sgv_adamw_step(sgv_engine* e, float lr);
+
+/* AugmentedDataset.__getitem__ x batch + default collate (augmentation.py:43-124) on a dataset
+ * resident in HBM in the engine's internal layout: builds the input batch directly.
+ * dataset_dev: [P][num_time][num_node] in compute dtype (see sgv_dataset_convert).
+ * idx[b]: sample index; noise_seed[b]: 0 = no noise else Philox key; scale[b]: 1.0 = none;
+ * mix_idx[b]: -1 = none; lam[b]: mixup weight (already clipped to [0.1,0.9]). */
+int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const int32_t* idx,
+                        const uint64_t* noise_seed, const float* scale, const int32_t* mix_idx,
+                        const float* lam);
+/* utils.Dataset.__init__ with load_all (utils.py:41-43): device fp32 [count, num_node, num_time]
+ * -> internal [count][num_time][num_node] in compute dtype at dst_dev. */
+int sgv_dataset_convert(sgv_engine* e, const float* src_dev, void* dst_dev, int count);
+size_t sgv_dataset_sample_bytes(const sgv_engine* e);
+
+/* Profiling aid for bench.py: hipEvent-timed duration (total ms and number of launches since the
+ * last reset) of a kernel class ("gemm_nt", "gemm_tn"), measured on the engine's own stream. [sync] */
+int sgv_kernel_time(sgv_engine* e, const char* which, float* total_ms, int* calls);
+int sgv_kernel_time_reset(sgv_engine* e, int enable);
+
+/* Low-level kernel entry points, exported for the unit parity tests (tests/test_kernels_gpu.py).
+ * All pointers are device pointers; dtype is SGV_DTYPE_*.  [sync] */
+int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale,
+                     const void* addend, int M, int N, int K, int taps, int Tlen, int splitk, int out_f32,
+                     void* stream);
+int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,
+                     int Tlen, int splitk, int use_tr, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGVAE_H */

@@ -1,0 +1,1497 @@
+// libsgvae engine: parameter/optimizer arenas, layer graph of the hierarchical VAE, forward /
+// backward orchestration on one HIP stream, and the C ABI of include/sgvae.h.
+//
+// Graph restated from the reference (channels-last, weights [tap][Cout][Cin]):
+//   VAE.forward modules/VAE_network.py:79-121 ; Encoder modules/encoder.py:96-167 ;
+//   Decoder modules/decoder.py:84-223 ; blocks modules/common.py:78-162 ; losses modules/losses.py:8-48 ;
+//   training step modules/train.py:139-168.
+// The backward pass is written out by hand (the reference uses autograd).
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <functional>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/sgvae.h"
+#include "sgv_ew.h"
+
+static thread_local char g_err[1024] = "";
+static int fail(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+#define HIPCHK(x)                                                                                   \
+    do {                                                                                            \
+        hipError_t e_ = (x);                                                                        \
+        if (e_ != hipSuccess) return fail(SGV_ERR_HIP, "%s failed: %s (%s:%d)", #x, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+#define CHK(x)                                  \
+    do {                                        \
+        int r_ = (x);                           \
+        if (r_ != 0) return r_ < 0 ? r_ : -r_;  \
+    } while (0)
+
+static const size_t NPOS = (size_t)-1;
+
+struct Tensor {
+    void* p = nullptr;
+    int C = 0;
+    long ld = 0;
+    bool f32 = false;
+};
+
+enum { OP_CONV = 0, OP_CONVT = 1, OP_LINEAR = 2 };
+enum { LIN_NONE = 0, LIN_HEAD = 1, LIN_EXPAND = 2 };
+
+struct Layer {
+    std::string prefix;
+    int op = OP_CONV, cin = 0, cout = 0, k = 1;
+    bool used = true, has_grad = true, need_wct = true;
+    int lin_kind = LIN_NONE, lin_C = 0;      // head: K = lin_C*T; expand: O = lin_C*T
+    size_t w = NPOS, b = NPOS, u = NPOS, v = NPOS;  // param arena (floats)
+    size_t gw = NPOS, gb = NPOS;                    // grad arena (floats)
+    size_t wc = NPOS, wct = NPOS;                   // compute-copy arena (elements)
+    int sn = -1;
+    int splitk_tn = 1;
+    long nw() const { return (long)cout * cin * k; }
+};
+struct GNLayer {
+    std::string prefix;
+    int C = 0, G = 1;
+    bool used = true, has_grad = true;
+    size_t gamma = NPOS, beta = NPOS, ggamma = NPOS, gbeta = NPOS;
+};
+struct Stage {
+    int layer = -1, gn = -1, act = 0;
+    bool pre_gelu = false, out_f32 = false;
+    Tensor pre, y, a, dy, da, dpre;
+    size_t sums = NPOS, sums2 = NPOS;   // stats arena (doubles)
+};
+struct Block {
+    std::vector<Stage> st;
+    bool residual = false;
+};
+struct StateEntry {
+    std::string name;
+    int kind;  // 0 bias,1 weight_orig,2 u,3 v,4 gn w,5 gn b
+    int layer = -1, gn = -1;
+    std::vector<int64_t> shape;
+    bool has_grad;
+    long count() const { long n = 1; for (auto s : shape) n *= s; return n; }
+};
+
+struct TimerRec { hipEvent_t a, b; int tag; };
+
+struct sgv_engine {
+    sgv_config cfg;
+    hipStream_t stream = nullptr;
+    int dt = 0;         // compute dtype
+    size_t esz = 4;     // bytes per compute element
+    int n = 0, n_st = 0, T = 0, N = 0, Z = 0, H = 0, maxB = 0;
+    std::vector<int> enc, dec;
+    std::vector<Layer> layers;
+    std::vector<GNLayer> gns;
+    std::vector<StateEntry> entries;
+    std::map<std::string, int> entry_index;
+    // arenas
+    float* params = nullptr; size_t n_params = 0;
+    float* grads = nullptr; size_t n_grads = 0, n_grads_w = 0;   // weights zone first, small zone after
+    float* adam_m = nullptr; float* adam_v = nullptr;
+    char* copies = nullptr; size_t n_copies = 0;
+    char* act = nullptr; size_t act_bytes = 0, act_used = 0;
+    double* stats = nullptr; size_t n_stats = 0, n_stats_fwd = 0;  // [fwd sums | bwd sums2]
+    float* sn_tmp = nullptr; size_t n_sn_tmp = 0;
+    float* sn_sigma = nullptr;
+    double* sn_dot = nullptr;
+    double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
+    float* partial = nullptr; size_t partial_floats = 0;
+    float* xpose_tmp = nullptr; size_t xpose_floats = 0;
+    float* recon_unit = nullptr;   // [2][N] unit-scale dgamma/dbeta of the recon GroupNorm
+    SNDesc* sn_dev = nullptr; std::vector<SNDesc> sn_host;
+    AdamDesc* adam_dev = nullptr; std::vector<AdamDesc> adam_host;
+    WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr, *items_copy = nullptr;
+    int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0, n_items_copy = 0;
+    // graph
+    std::vector<Block> encA, encR, decU, decD, decP1, decP2, decX, decQ1, decQ2;
+    Block decS, recon;
+    std::vector<int> xs_lin, xs_exp;   // layer ids: encoder.xs_linear.i ; decoder.xs_sequence.i.0
+    int last_lin = -1, start_lin = -1;
+    // tensors
+    Tensor x_in, xhat, sbuf, d_sbuf, dy_recon;
+    std::vector<Tensor> enc_h, d_h, enc_a_dummy, zs, dzs, cat, dcat, dec_out, d_out, d_u, d_pres, d_qres, d_outp, gp, gq, xl, d_xl;
+    std::vector<float*> xs_raw, d_xs_raw, eps, zmap;
+    std::vector<int> eps_set;
+    float *last = nullptr, *d_last = nullptr, *zlat = nullptr, *d_z = nullptr;
+    int batch = 0;
+    bool have_fwd = false, fwd_train = false, write_xhat = true, copies_fresh = false;
+    uint64_t seed = 0x5347564145ull, draw = 0;
+    long step = 0;
+    float scalars_host[SGV_MAX_SCALARS];
+    sgv_bucket_cb cb = nullptr; void* cb_user = nullptr;
+    std::vector<std::pair<size_t, size_t>> buckets;   // (offset, count) in grad arena, backward order
+    bool timing = false;
+    std::vector<TimerRec> timers;
+    std::map<std::string, int> tag_ids;
+    std::vector<std::string> tag_names;
+    int use_tr = 1;
+};
+
+// ------------------------------------------------------------------------------------------
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+static int gn_groups(int c) { int g = c / 4; if (g < 1) g = 1; if (g > 8) g = 8; return g; }
+
+struct Builder {
+    sgv_engine* e;
+    size_t np = 0, ngw = 0, ngs = 0, ncp = 0;
+    std::vector<size_t*> small_grad_slots;   // gb / ggamma / gbeta offsets get rebased after the weight zone
+    int add_layer(const std::string& prefix, int op, int cin, int cout, int k, bool used, bool has_grad, bool need_wct,
+                  int lin_kind = LIN_NONE, int lin_C = 0) {
+        Layer l;
+        l.prefix = prefix; l.op = op; l.cin = cin; l.cout = cout; l.k = k;
+        l.used = used; l.has_grad = has_grad; l.need_wct = need_wct && used && op != OP_LINEAR;
+        l.lin_kind = lin_kind; l.lin_C = lin_C;
+        e->layers.push_back(l);
+        return (int)e->layers.size() - 1;
+    }
+    int add_gn(const std::string& prefix, int C, bool used, bool has_grad) {
+        GNLayer g;
+        g.prefix = prefix; g.C = C; g.G = gn_groups(C); g.used = used; g.has_grad = has_grad;
+        e->gns.push_back(g);
+        return (int)e->gns.size() - 1;
+    }
+};
+
+static Tensor alloc_act(sgv_engine* e, long rows, int C, bool f32 = false) {
+    Tensor t;
+    t.C = C; t.ld = C; t.f32 = f32;
+    size_t bytes = (size_t)rows * C * (f32 ? 4 : e->esz);
+    e->act_used = align_up(e->act_used, 256);
+    t.p = (void*)(e->act_used);   // offset for now; rebased after allocation
+    e->act_used += bytes;
+    return t;
+}
+static Tensor view_cols(const Tensor& t, int c0, int C, sgv_engine* e) {
+    Tensor v = t;
+    v.p = (char*)t.p + (size_t)c0 * (t.f32 ? 4 : e->esz);
+    v.C = C;
+    return v;
+}
+
+// ---- state-entry list in reference order (mirrors simulgen-vae_amd/spec.py) --------------------
+static void add_entries_for_layer(sgv_engine* e, int li) {
+    const Layer& l = e->layers[li];
+    auto push = [&](const char* suffix, int kind, std::vector<int64_t> shape, bool hg) {
+        StateEntry s;
+        s.name = l.prefix + suffix; s.kind = kind; s.layer = li; s.shape = shape; s.has_grad = hg;
+        e->entry_index[s.name] = (int)e->entries.size();
+        e->entries.push_back(s);
+    };
+    push(".bias", 0, {l.cout}, l.has_grad);
+    if (l.op == OP_CONV) push(".weight_orig", 1, {l.cout, l.cin, l.k}, l.has_grad);
+    else if (l.op == OP_CONVT) push(".weight_orig", 1, {l.cin, l.cout, l.k}, l.has_grad);
+    else push(".weight_orig", 1, {l.cout, l.cin}, l.has_grad);
+    push(".weight_u", 2, {l.cout}, false);
+    push(".weight_v", 3, {(int64_t)l.cin * l.k}, false);
+}
+static void add_entries_for_gn(sgv_engine* e, int gi) {
+    const GNLayer& g = e->gns[gi];
+    StateEntry s;
+    s.name = g.prefix + ".weight"; s.kind = 4; s.gn = gi; s.shape = {g.C}; s.has_grad = g.has_grad;
+    e->entry_index[s.name] = (int)e->entries.size(); e->entries.push_back(s);
+    s.name = g.prefix + ".bias"; s.kind = 5;
+    e->entry_index[s.name] = (int)e->entries.size(); e->entries.push_back(s);
+}
+
+static Stage mk_stage(int layer, int gn, int act, bool pre_gelu = false, bool out_f32 = false) {
+    Stage s;
+    s.layer = layer; s.gn = gn; s.act = act; s.pre_gelu = pre_gelu; s.out_f32 = out_f32;
+    return s;
+}
+
+// Build layers + blocks in the reference's module registration order so that `entries` comes out in
+// state_dict order (encoder: blocks, residual blocks, xs_linear, last; decoder: blocks, residual blocks,
+// recon, sequence_start, xs_sequence, condition_z, condition_xz).
+static int build_graph(sgv_engine* e) {
+    Builder B{e};
+    const bool small = e->cfg.small != 0;
+    const int n = e->n, T = e->T;
+    char buf[256];
+    auto P = [&](const char* fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(buf, sizeof(buf), fmt, ap); va_end(ap); return std::string(buf); };
+    std::vector<std::function<void()>> entry_order;
+
+    e->encA.resize(n); e->encR.resize(n);
+    for (int i = 0; i < n; ++i) {
+        const int cin = i == 0 ? e->N : e->enc[i - 1], C = e->enc[i];
+        std::string p = P("encoder.encoder_blocks.%d.module_list.0._seq", i);
+        int l0 = B.add_layer(p + ".0", OP_CONV, cin, C, 1, true, true, i > 0);
+        int g0 = B.add_gn(p + ".1", C, true, true);
+        add_entries_for_layer(e, l0); add_entries_for_gn(e, g0);
+        e->encA[i].st.push_back(mk_stage(l0, g0, 1));
+        if (!small) {
+            int l1 = B.add_layer(p + ".3", OP_CONV, C, C, 3, true, true, true);
+            int g1 = B.add_gn(p + ".4", C, true, true);
+            add_entries_for_layer(e, l1); add_entries_for_gn(e, g1);
+            e->encA[i].st.push_back(mk_stage(l1, g1, 1));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const int C = e->enc[i];
+        std::string p = P("encoder.encoder_residual_blocks.%d.seq", i);
+        e->encR[i].residual = true;
+        for (int r = 0; r < (small ? 1 : 2); ++r) {
+            int l = B.add_layer(p + P(".%d", r * 3), OP_CONV, C, C, 3, true, true, true);
+            int g = B.add_gn(p + P(".%d", r * 3 + 1), C, true, true);
+            add_entries_for_layer(e, l); add_entries_for_gn(e, g);
+            e->encR[i].st.push_back(mk_stage(l, g, 1));
+        }
+    }
+    for (int i = 0; i < n; ++i) {
+        const bool dead = (i == 0) || (i == n - 1);
+        int l = B.add_layer(P("encoder.xs_linear.%d", i), OP_LINEAR, e->enc[i] * T, e->H, 1, true, !dead, false, LIN_HEAD, e->enc[i]);
+        add_entries_for_layer(e, l);
+        e->xs_lin.push_back(l);
+    }
+    e->last_lin = B.add_layer("encoder.last_x_linear", OP_LINEAR, e->enc[n - 1] * T, 2 * e->Z, 1, true, true, false, LIN_HEAD, e->enc[n - 1]);
+    add_entries_for_layer(e, e->last_lin);
+
+    const int n_st = e->n_st;
+    e->decU.resize(n_st); e->decD.resize(n_st);
+    e->decP1.resize(n_st); e->decP2.resize(n_st); e->decX.resize(n_st); e->decQ1.resize(n_st); e->decQ2.resize(n_st);
+    for (int i = 0; i < n_st; ++i) {
+        int l = B.add_layer(P("decoder.decoder_blocks.%d.module_list.0._seq.0", i), OP_CONVT, e->dec[i], e->dec[i + 1], 3, true, true, true);
+        add_entries_for_layer(e, l);
+        e->decU[i].st.push_back(mk_stage(l, -1, 1));
+    }
+    for (int i = 0; i < n_st; ++i) {
+        const int C = e->dec[i + 1];
+        std::string p = P("decoder.decoder_residual_blocks.%d.seq", i);
+        e->decD[i].residual = true;
+        struct CS { int cin, cout, k; };
+        std::vector<CS> cs;
+        if (small) cs = {{C, 5 * C, 1}, {5 * C, 5 * C, 5}, {5 * C, C, 1}};
+        else cs = {{C, C, 1}, {C, 5 * C, 5}, {5 * C, 5 * C, 5}, {5 * C, C, 1}};
+        for (size_t r = 0; r < cs.size(); ++r) {
+            int l = B.add_layer(p + P(".%d", (int)r * 3), OP_CONV, cs[r].cin, cs[r].cout, cs[r].k, true, true, true);
+            int g = B.add_gn(p + P(".%d", (int)r * 3 + 1), cs[r].cout, true, true);
+            add_entries_for_layer(e, l); add_entries_for_gn(e, g);
+            e->decD[i].st.push_back(mk_stage(l, g, 1));
+        }
+    }
+    {
+        int l = B.add_layer("decoder.recon.0", OP_CONV, e->dec[n_st], e->N, 1, true, true, true);
+        int g = B.add_gn("decoder.recon.1", e->N, true, true);
+        add_entries_for_layer(e, l); add_entries_for_gn(e, g);
+        e->recon.st.push_back(mk_stage(l, g, 2));
+    }
+    {
+        e->start_lin = B.add_layer("decoder.sequence_start.0.0", OP_LINEAR, e->Z, e->Z * T, 1, true, true, false, LIN_EXPAND, e->Z);
+        int l = B.add_layer("decoder.sequence_start.0.2", OP_CONV, e->Z, e->dec[0], 5, true, true, true);
+        int g = B.add_gn("decoder.sequence_start.0.3", e->dec[0], true, true);
+        add_entries_for_layer(e, e->start_lin); add_entries_for_layer(e, l); add_entries_for_gn(e, g);
+        e->decS.st.push_back(mk_stage(l, g, 1));
+    }
+    for (int i = 0; i < n_st; ++i) {
+        const bool live = i < n_st - 1;
+        std::string p = P("decoder.xs_sequence.%d", i);
+        int ll = B.add_layer(p + ".0", OP_LINEAR, e->H, e->H * T, 1, live, live, false, LIN_EXPAND, e->H);
+        int l = B.add_layer(p + ".2", OP_CONV, e->H, e->dec[i + 1], 5, live, live, true);
+        int g = B.add_gn(p + ".3", e->dec[i + 1], live, live);
+        add_entries_for_layer(e, ll); add_entries_for_layer(e, l); add_entries_for_gn(e, g);
+        e->xs_exp.push_back(ll);
+        e->decX[i].st.push_back(mk_stage(l, g, 1));
+    }
+    for (int which = 0; which < 2; ++which) {
+        for (int i = 0; i < n_st; ++i) {
+            const bool live = i < n_st - 1;
+            const int C = (which + 1) * e->dec[i + 1];
+            std::string p = P("decoder.%s.%d", which ? "condition_xz" : "condition_z", i);
+            Block& b1 = which ? e->decQ1[i] : e->decP1[i];
+            Block& b2 = which ? e->decQ2[i] : e->decP2[i];
+            b1.residual = true;
+            for (int r = 0; r < (small ? 1 : 2); ++r) {
+                int l = B.add_layer(p + P(".0._seq.%d", r * 3), OP_CONV, C, C, 3, live, live, true);
+                int g = B.add_gn(p + P(".0._seq.%d", r * 3 + 1), C, live, live);
+                add_entries_for_layer(e, l); add_entries_for_gn(e, g);
+                b1.st.push_back(mk_stage(l, g, 1));
+            }
+            int l2 = B.add_layer(p + ".2", OP_CONV, C, 2 * e->dec[i + 1], 3, live, live, true);
+            add_entries_for_layer(e, l2);
+            b2.st.push_back(mk_stage(l2, -1, 0, true, true));
+        }
+    }
+    return 0;
+}
+
+// ---- arena layout ---------------------------------------------------------------------------
+static int layout_arenas(sgv_engine* e) {
+    size_t np = 0;
+    auto take = [&](size_t& cur, size_t n) { size_t o = cur; cur = align_up(cur + n, 4); return o; };
+    for (auto& l : e->layers) {
+        l.w = take(np, (size_t)l.nw());
+        l.b = take(np, l.cout);
+        l.u = take(np, l.cout);
+        l.v = take(np, (size_t)l.cin * l.k);
+    }
+    for (auto& g : e->gns) { g.gamma = take(np, g.C); g.beta = take(np, g.C); }
+    e->n_params = np;
+    return 0;
+}
+
+// order in which weight gradients become available during backward (for bucketed all-reduce)
+static void backward_layer_order(sgv_engine* e, std::vector<std::vector<int>>& sections) {
+    auto add_block = [&](std::vector<int>& v, const Block& b) {
+        for (int s = (int)b.st.size() - 1; s >= 0; --s) v.push_back(b.st[s].layer);
+    };
+    const int n = e->n, n_st = e->n_st;
+    std::vector<int> sec;
+    add_block(sec, e->recon);
+    sections.push_back(sec);
+    for (int i = n_st - 1; i >= 0; --i) {
+        sec.clear();
+        if (i < n_st - 1) {
+            add_block(sec, e->decQ2[i]); add_block(sec, e->decQ1[i]); add_block(sec, e->decX[i]);
+            sec.push_back(e->xs_exp[i]);
+            add_block(sec, e->decP2[i]); add_block(sec, e->decP1[i]);
+        }
+        add_block(sec, e->decD[i]); add_block(sec, e->decU[i]);
+        if (i == 0) { add_block(sec, e->decS); sec.push_back(e->start_lin); }
+        sections.push_back(sec);
+    }
+    sec.clear();
+    sec.push_back(e->last_lin);
+    for (int i = n - 1; i >= 1; --i) {
+        if (e->layers[e->xs_lin[i]].has_grad) sec.push_back(e->xs_lin[i]);
+        add_block(sec, e->encR[i]); add_block(sec, e->encA[i]);
+    }
+    add_block(sec, e->encR[0]);
+    sections.push_back(sec);
+    sec.clear();
+    add_block(sec, e->encA[0]);
+    sections.push_back(sec);
+}
+
+static int layout_grads(sgv_engine* e) {
+    std::vector<std::vector<int>> sections;
+    backward_layer_order(e, sections);
+    size_t ng = 0;
+    auto take = [&](size_t n) { size_t o = ng; ng = align_up(ng + n, 4); return o; };
+    e->buckets.clear();
+    for (auto& sec : sections) {
+        size_t start = ng;
+        for (int li : sec) {
+            Layer& l = e->layers[li];
+            if (!l.has_grad) continue;
+            l.gw = take((size_t)l.nw());
+        }
+        if (ng > start) e->buckets.push_back({start, ng - start});
+    }
+    e->n_grads_w = ng;
+    size_t small_start = ng;
+    for (auto& l : e->layers) if (l.has_grad) l.gb = take(l.cout);
+    for (auto& g : e->gns) if (g.has_grad) { g.ggamma = take(g.C); g.gbeta = take(g.C); }
+    e->buckets.push_back({small_start, ng - small_start});
+    e->n_grads = ng;
+    // every trainable layer must have been placed
+    for (auto& l : e->layers) if (l.has_grad && l.gw == NPOS) return fail(SGV_ERR_STATE, "layer %s missing from backward order", l.prefix.c_str());
+    return 0;
+}
+
+// ---- activations ------------------------------------------------------------------------------
+static void alloc_block(sgv_engine* e, Block& b, long M, int cin, bool need_din) {
+    int c_in = cin;
+    for (size_t s = 0; s < b.st.size(); ++s) {
+        Stage& S = b.st[s];
+        const Layer& L = e->layers[S.layer];
+        if (S.pre_gelu) { S.pre = alloc_act(e, M, c_in); S.dpre = alloc_act(e, M, c_in); }
+        S.y = alloc_act(e, M, L.cout, S.out_f32);
+        if (S.gn >= 0 || S.act) { if (!S.a.p) S.a = alloc_act(e, M, L.cout); }
+        else S.a = S.y;
+        S.dy = (S.gn >= 0 || S.act) ? alloc_act(e, M, L.cout) : Tensor();
+        if (s + 1 < b.st.size()) S.da = alloc_act(e, M, L.cout);
+        if (S.gn >= 0) {
+            const GNLayer& g = e->gns[S.gn];
+            S.sums = e->n_stats_fwd; e->n_stats_fwd += (size_t)e->maxB * g.G * 2;
+        }
+        c_in = L.cout;
+    }
+    (void)need_din;
+}
+// Tensor.p holds arena offsets until rebase; mark "preset" views via a flag value
+static void rebase(sgv_engine* e, Tensor& t) { if (t.p || t.C) t.p = e->act + (size_t)t.p; }
+
+static int alloc_activations(sgv_engine* e) {
+    const long M = (long)e->maxB * e->T;
+    const int n = e->n, n_st = e->n_st;
+    e->act_used = 256;   // offset 0 is reserved so that "p == 0" means unallocated
+    e->x_in = alloc_act(e, M, e->N);
+    e->xhat = alloc_act(e, M, e->N);
+    e->dy_recon = alloc_act(e, M, e->N);
+    e->enc_h.resize(n); e->d_h.resize(n);
+    for (int i = 0; i < n; ++i) {
+        alloc_block(e, e->encA[i], M, i == 0 ? e->N : e->enc[i - 1], i > 0);
+        alloc_block(e, e->encR[i], M, e->enc[i], true);
+        e->enc_h[i] = e->encR[i].st.back().a;
+        e->d_h[i] = alloc_act(e, M, e->enc[i]);
+    }
+    e->enc_a_dummy.resize(n);
+    for (int i = 0; i < n; ++i) e->enc_a_dummy[i] = alloc_act(e, M, e->enc[i]);   // d(a_i): grad wrt ConvBlock output
+    e->sbuf = alloc_act(e, M, e->Z);
+    e->d_sbuf = alloc_act(e, M, e->Z);
+    alloc_block(e, e->decS, M, e->Z, true);
+    e->zs.resize(n_st); e->dzs.resize(n_st); e->cat.resize(n_st); e->dcat.resize(n_st); e->dec_out.resize(n_st);
+    e->d_out.resize(n_st); e->d_u.resize(n_st); e->d_pres.resize(n_st); e->d_qres.resize(n_st); e->d_outp.resize(n_st);
+    e->gp.resize(n_st); e->gq.resize(n_st); e->xl.resize(n_st); e->d_xl.resize(n_st);
+    e->zs[0] = e->decS.st.back().a;
+    for (int i = 0; i < n_st; ++i) {
+        const int C = e->dec[i + 1];
+        const bool live = i < n_st - 1;
+        if (i > 0) e->zs[i] = alloc_act(e, M, e->dec[i]);
+        e->dzs[i] = alloc_act(e, M, e->dec[i]);
+        alloc_block(e, e->decU[i], M, e->dec[i], true);
+        if (live) {
+            e->cat[i] = alloc_act(e, M, 2 * C);
+            e->dcat[i] = alloc_act(e, M, 2 * C);
+            // DecoderResidualBlock output and xs_sequence output are written straight into the concat buffer
+            Tensor v = e->cat[i]; v.C = C; v.p = (void*)((size_t)v.p + (size_t)C * e->esz);
+            e->decD[i].st.back().a = v;
+            Tensor vx = e->cat[i]; vx.C = C;
+            e->decX[i].st.back().a = vx;
+        }
+        alloc_block(e, e->decD[i], M, C, true);
+        e->dec_out[i] = e->decD[i].st.back().a;
+        e->d_out[i] = alloc_act(e, M, C);
+        e->d_u[i] = alloc_act(e, M, C);
+        if (live) {
+            alloc_block(e, e->decP1[i], M, C, true);
+            alloc_block(e, e->decP2[i], M, C, true);
+            e->xl[i] = alloc_act(e, M, e->H);
+            e->d_xl[i] = alloc_act(e, M, e->H);
+            alloc_block(e, e->decX[i], M, e->H, true);
+            alloc_block(e, e->decQ1[i], M, 2 * C, true);
+            alloc_block(e, e->decQ2[i], M, 2 * C, true);
+            e->d_pres[i] = alloc_act(e, M, C);
+            e->d_qres[i] = alloc_act(e, M, 2 * C);
+            e->d_outp[i] = alloc_act(e, M, C);
+            e->gp[i] = alloc_act(e, M, 2 * C);
+            e->gq[i] = alloc_act(e, M, 2 * C);
+        }
+    }
+    alloc_block(e, e->recon, M, e->dec[n_st], true);
+    // fp32 side buffers
+    auto f32buf = [&](long count) { e->act_used = align_up(e->act_used, 256); size_t o = e->act_used; e->act_used += (size_t)count * 4; return (float*)o; };
+    e->xs_raw.resize(n); e->d_xs_raw.resize(n);
+    for (int i = 0; i < n; ++i) { e->xs_raw[i] = f32buf((long)e->maxB * e->H); e->d_xs_raw[i] = f32buf((long)e->maxB * e->H); }
+    e->last = f32buf((long)e->maxB * 2 * e->Z); e->d_last = f32buf((long)e->maxB * 2 * e->Z);
+    e->zlat = f32buf((long)e->maxB * e->Z); e->d_z = f32buf((long)e->maxB * e->Z);
+    e->eps.resize(n_st); e->zmap.resize(n_st); e->eps_set.assign(n_st, 0);
+    e->eps[0] = f32buf((long)e->maxB * e->Z);
+    e->zmap[0] = nullptr;
+    for (int i = 0; i + 1 < n_st; ++i) {
+        e->eps[i + 1] = f32buf(M * e->dec[i + 1]);
+        e->zmap[i] = f32buf(M * e->dec[i + 1]);
+    }
+    e->recon_unit = f32buf(2L * e->N);
+    // backward group sums mirror the forward slots
+    e->n_stats = e->n_stats_fwd * 2;
+    e->act_bytes = align_up(e->act_used, 256);
+    return 0;
+}
+
+static void rebase_block(sgv_engine* e, Block& b) {
+    for (auto& S : b.st) {
+        const bool alias = (S.gn < 0 && !S.act);
+        rebase(e, S.pre); rebase(e, S.dpre); rebase(e, S.y); rebase(e, S.dy); rebase(e, S.da);
+        if (alias) S.a = S.y; else rebase(e, S.a);
+        if (S.sums != NPOS) S.sums2 = S.sums + e->n_stats_fwd;
+    }
+}
+static void rebase_all(sgv_engine* e) {
+    auto R = [&](Tensor& t) { rebase(e, t); };
+    auto RF = [&](float*& p) { if (p) p = (float*)(e->act + (size_t)p); };
+    R(e->x_in); R(e->xhat); R(e->dy_recon); R(e->sbuf); R(e->d_sbuf);
+    for (auto& b : e->encA) rebase_block(e, b);
+    for (auto& b : e->encR) rebase_block(e, b);
+    for (auto& b : e->decU) rebase_block(e, b);
+    for (auto& b : e->decD) rebase_block(e, b);
+    for (int i = 0; i + 1 < e->n_st; ++i) { rebase_block(e, e->decP1[i]); rebase_block(e, e->decP2[i]); rebase_block(e, e->decX[i]); rebase_block(e, e->decQ1[i]); rebase_block(e, e->decQ2[i]); }
+    rebase_block(e, e->decS); rebase_block(e, e->recon);
+    for (auto& t : e->d_h) R(t);
+    for (auto& t : e->enc_a_dummy) R(t);
+    for (int i = 0; i < e->n; ++i) e->enc_h[i] = e->encR[i].st.back().a;
+    for (int i = 0; i < e->n_st; ++i) {
+        if (i > 0) R(e->zs[i]);
+        R(e->dzs[i]); R(e->d_out[i]); R(e->d_u[i]);
+        if (i + 1 < e->n_st) { R(e->cat[i]); R(e->dcat[i]); R(e->xl[i]); R(e->d_xl[i]); R(e->d_pres[i]); R(e->d_qres[i]); R(e->d_outp[i]); R(e->gp[i]); R(e->gq[i]); }
+        e->dec_out[i] = e->decD[i].st.back().a;
+    }
+    e->zs[0] = e->decS.st.back().a;
+    for (auto& p : e->xs_raw) RF(p);
+    for (auto& p : e->d_xs_raw) RF(p);
+    RF(e->last); RF(e->d_last); RF(e->zlat); RF(e->d_z);
+    for (auto& p : e->eps) RF(p);
+    for (auto& p : e->zmap) RF(p);
+    RF(e->recon_unit);
+}
+
+// ---- descriptor tables --------------------------------------------------------------------------
+static int build_tables(sgv_engine* e) {
+    // compute copies
+    size_t nc = 0;
+    for (auto& l : e->layers) {
+        if (!l.used || l.op == OP_LINEAR) continue;
+        if (e->dt == SGV_DTYPE_BF16) { l.wc = nc; nc = align_up(nc + (size_t)l.nw(), 8); }
+        if (l.need_wct) { l.wct = nc; nc = align_up(nc + (size_t)l.nw(), 8); }
+    }
+    e->n_copies = nc;
+    // SN scratch
+    size_t nt = 0;
+    int si = 0;
+    for (auto& l : e->layers) { l.sn = si++; nt += align_up((size_t)l.cin * l.k, 4) + align_up((size_t)l.cout, 4); }
+    e->n_sn_tmp = nt;
+    return 0;
+}
+
+static int upload_tables(sgv_engine* e) {
+    const int L = (int)e->layers.size();
+    e->sn_host.resize(L);
+    size_t to = 0;
+    std::vector<WorkItem> i_sn, i_dot, i_adam, i_copy;
+    for (int i = 0; i < L; ++i) {
+        Layer& l = e->layers[i];
+        SNDesc d;
+        d.W = e->params + l.w; d.u = e->params + l.u; d.v = e->params + l.v;
+        d.tmp_t = e->sn_tmp + to; to += align_up((size_t)l.cin * l.k, 4);
+        d.tmp_s = e->sn_tmp + to; to += align_up((size_t)l.cout, 4);
+        d.sigma = e->sn_sigma + 2 * i;
+        d.dot = e->sn_dot + i;
+        d.G = l.has_grad ? e->grads + l.gw : nullptr;
+        d.taps = l.k; d.rows = l.cout; d.cols = l.cin; d.active = l.used ? 1 : 0;
+        e->sn_host[i] = d;
+        if (l.used) {
+            const int rb = (l.cout + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (l.cin + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
+            for (int c = 0; c < l.k * rb * cb; ++c) i_sn.push_back({i, c});
+        }
+        if (l.has_grad) {
+            const long nch = (l.nw() + OPT_CHUNK - 1) / OPT_CHUNK;
+            for (long c = 0; c < nch; ++c) i_dot.push_back({i, (int)c});
+        }
+    }
+    e->adam_host.clear();
+    auto add_adam = [&](size_t p, size_t g, long n, int sn, int rows, int cols, int taps, void* wc, void* wct) {
+        AdamDesc a;
+        a.p = e->params + p; a.g = e->grads + g; a.m = e->adam_m + g; a.v = e->adam_v + g;
+        a.n = n; a.sn = sn; a.rows = rows; a.cols = cols; a.taps = taps; a.wc = wc; a.wct = wct;
+        const int id = (int)e->adam_host.size();
+        e->adam_host.push_back(a);
+        const long nch = (n + OPT_CHUNK - 1) / OPT_CHUNK;
+        for (long c = 0; c < nch; ++c) i_adam.push_back({id, (int)c});
+        return id;
+    };
+    for (int i = 0; i < L; ++i) {
+        Layer& l = e->layers[i];
+        void* wc = l.wc != NPOS ? (void*)(e->copies + l.wc * e->esz) : nullptr;
+        void* wct = l.wct != NPOS ? (void*)(e->copies + l.wct * e->esz) : nullptr;
+        int id = -1;
+        if (l.has_grad) {
+            id = add_adam(l.w, l.gw, l.nw(), i, l.cout, l.cin, l.k, wc, wct);
+            add_adam(l.b, l.gb, l.cout, -1, 1, l.cout, 1, nullptr, nullptr);
+        }
+        if (wc || wct) {
+            if (id < 0) {   // used-in-forward but frozen layers never occur for convs; keep general
+                AdamDesc a; memset(&a, 0, sizeof(a));
+                a.p = e->params + l.w; a.n = l.nw(); a.sn = -1; a.rows = l.cout; a.cols = l.cin; a.taps = l.k; a.wc = wc; a.wct = wct;
+                id = (int)e->adam_host.size();
+                e->adam_host.push_back(a);
+            }
+            const int rt = (l.cout + 31) / 32, ct = (l.cin + 31) / 32;
+            for (int c = 0; c < l.k * rt * ct; ++c) i_copy.push_back({id, c});
+        }
+    }
+    for (auto& g : e->gns) {
+        if (!g.has_grad) continue;
+        add_adam(g.gamma, g.ggamma, g.C, -1, 1, g.C, 1, nullptr, nullptr);
+        add_adam(g.beta, g.gbeta, g.C, -1, 1, g.C, 1, nullptr, nullptr);
+    }
+    auto up = [&](const void* src, size_t bytes, void** dst) -> int {
+        if (bytes == 0) { *dst = nullptr; return 0; }
+        if (hipMalloc(dst, bytes) != hipSuccess) return -1;
+        if (hipMemcpy(*dst, src, bytes, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        return 0;
+    };
+    if (up(e->sn_host.data(), sizeof(SNDesc) * L, (void**)&e->sn_dev)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(e->adam_host.data(), sizeof(AdamDesc) * e->adam_host.size(), (void**)&e->adam_dev)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_sn.data(), sizeof(WorkItem) * i_sn.size(), (void**)&e->items_sn)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_dot.data(), sizeof(WorkItem) * i_dot.size(), (void**)&e->items_dot)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_adam.data(), sizeof(WorkItem) * i_adam.size(), (void**)&e->items_adam)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_copy.data(), sizeof(WorkItem) * i_copy.size(), (void**)&e->items_copy)) return fail(SGV_ERR_HIP, "table upload failed");
+    e->n_items_sn = (int)i_sn.size(); e->n_items_dot = (int)i_dot.size();
+    e->n_items_adam = (int)i_adam.size(); e->n_items_copy = (int)i_copy.size();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// timing helpers
+// ------------------------------------------------------------------------------------------------
+static int tag_id(sgv_engine* e, const std::string& name) {
+    auto it = e->tag_ids.find(name);
+    if (it != e->tag_ids.end()) return it->second;
+    int id = (int)e->tag_names.size();
+    e->tag_ids[name] = id; e->tag_names.push_back(name);
+    return id;
+}
+struct ScopedTimer {
+    sgv_engine* e; TimerRec r; bool on;
+    ScopedTimer(sgv_engine* e_, const char* cls, const Layer* l) : e(e_), on(e_->timing) {
+        if (!on) return;
+        hipEventCreate(&r.a); hipEventCreate(&r.b);
+        r.tag = tag_id(e, std::string(cls));
+        (void)l;
+        hipEventRecord(r.a, e->stream);
+    }
+    ~ScopedTimer() { if (on) { hipEventRecord(r.b, e->stream); e->timers.push_back(r); } }
+};
+
+// ------------------------------------------------------------------------------------------------
+// op wrappers
+// ------------------------------------------------------------------------------------------------
+static const void* wc_ptr(sgv_engine* e, const Layer& l) {
+    if (e->dt == SGV_DTYPE_BF16) return e->copies + l.wc * e->esz;
+    return e->params + l.w;
+}
+static const void* wct_ptr(sgv_engine* e, const Layer& l) { return e->copies + l.wct * e->esz; }
+
+// Y = conv(X) * (1/sigma) + bias
+static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = x.p; p.lda = x.ld;
+    p.W = wc_ptr(e, l); p.ldw = l.cin; p.w_tap_stride = (long)l.cout * l.cin;
+    p.C = y.p; p.ldc = y.ld; p.out_f32 = y.f32 ? 1 : 0;
+    p.bias = e->params + l.b;
+    p.scale = e->sn_sigma + 2 * l.sn + 1;
+    p.M = (int)M; p.N = l.cout; p.K = l.cin; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
+    p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
+    if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
+    p.partial = e->partial;
+    ScopedTimer tm(e, "gemm_nt", &l);
+    int r = launch_gemm_nt(e->dt, p, e->stream);
+    if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d)", l.prefix.c_str(), p.M, p.N, p.K);
+    return 0;
+}
+// dX = conv^T(dY) * (1/sigma) (+ addend)
+static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Tensor& dx, const Tensor* addend, long M) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = dy.p; p.lda = dy.ld;
+    p.W = wct_ptr(e, l); p.ldw = l.cout; p.w_tap_stride = (long)l.cout * l.cin;
+    p.C = dx.p; p.ldc = dx.ld; p.out_f32 = 0;
+    if (addend) { p.addend = addend->p; p.ldadd = addend->ld; }
+    p.scale = e->sn_sigma + 2 * l.sn + 1;
+    p.M = (int)M; p.N = l.cin; p.K = l.cout; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
+    p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
+    if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
+    p.partial = e->partial;
+    ScopedTimer tm(e, "gemm_nt", &l);
+    int r = launch_gemm_nt(e->dt, p, e->stream);
+    if (r) return fail(SGV_ERR_ARG, "gemm_nt(dX) launch failed for %s", l.prefix.c_str());
+    return 0;
+}
+__global__ void sum_slabs_kernel(float* out, const float* partial, int splitk, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < splitk; ++z) v += partial[(long)z * n + i];
+        out[i] = v;
+    }
+}
+// dW[tap][co][ci] = sum_m dY[m][co] X[m+tap-pad][ci]
+static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Tensor& x, long M) {
+    GemmTN p; memset(&p, 0, sizeof(p));
+    p.A = dy.p; p.lda = dy.ld; p.B = x.p; p.ldb = x.ld;
+    p.M = (int)M; p.N1 = l.cout; p.N2 = l.cin; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
+    p.use_tr = e->use_tr;
+    p.ldo = l.cin; p.out_tap_stride = (long)l.cout * l.cin;
+    int sk = gemm_tn_pick_splitk(p.M, p.N1, p.N2, p.taps, e->dt);
+    const long nw = l.nw();
+    if ((size_t)sk * nw > e->partial_floats) sk = 1;
+    float* G = e->grads + l.gw;
+    ScopedTimer tm(e, "gemm_tn", &l);
+    if (sk == 1) {
+        p.splitk = 1; p.out = G;
+        if (launch_gemm_tn(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s", l.prefix.c_str());
+    } else {
+        // split-K over the batch*time rows: each slice writes its own fp32 slab (plain stores), then one sum pass
+        p.splitk = sk; p.out = e->partial; p.out_slab_stride = nw;
+        if (launch_gemm_tn(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s", l.prefix.c_str());
+        int blocks = (int)((nw + 255) / 256); if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, e->stream, G, e->partial, sk, nw);
+    }
+    return 0;
+}
+
+static GNParams gn_base(sgv_engine* e, const GNLayer& g, int B) {
+    GNParams p;
+    p.gamma = e->params + g.gamma; p.beta = e->params + g.beta;
+    p.B = B; p.T = e->T; p.C = g.C; p.G = g.G; p.Cg = g.C / g.G;
+    return p;
+}
+
+static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
+    const long M = (long)B * e->T;
+    Tensor x = in;
+    for (size_t s = 0; s < b.st.size(); ++s) {
+        Stage& S = b.st[s];
+        const Layer& L = e->layers[S.layer];
+        Tensor cin = x;
+        if (S.pre_gelu) {
+            GNParams p; p.y = x.p; p.ldy = x.ld; p.out = S.pre.p; p.ldout = S.pre.ld; p.B = B; p.T = e->T; p.C = x.C;
+            ew_act(e->dt, 0, p, e->stream);
+            cin = S.pre;
+        }
+        CHK(conv_fwd(e, L, cin, S.y, M));
+        if (S.gn >= 0) {
+            const GNLayer& g = e->gns[S.gn];
+            GNParams p = gn_base(e, g, B);
+            p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
+            ew_gn_stats(e->dt, p, e->stream);
+            p.out = S.a.p; p.ldout = S.a.ld;
+            if (b.residual && s + 1 == b.st.size()) { p.res = in.p; p.ldres = in.ld; p.rscale = 0.1f; }
+            ew_gn_apply(e->dt, S.act, p, e->stream);
+        } else if (S.act) {
+            GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.out = S.a.p; p.ldout = S.a.ld; p.B = B; p.T = e->T; p.C = L.cout;
+            ew_act(e->dt, 0, p, e->stream);
+        }
+        x = S.a;
+    }
+    return 0;
+}
+
+// dOut: gradient wrt the block output; dIn (nullable): gradient wrt the block input (overwritten).
+static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dOut, const Tensor* dIn, int B) {
+    const long M = (long)B * e->T;
+    Tensor dA = dOut;
+    float sc = b.residual ? 0.1f : 1.0f;
+    for (int s = (int)b.st.size() - 1; s >= 0; --s) {
+        Stage& S = b.st[s];
+        const Layer& L = e->layers[S.layer];
+        const Tensor x_raw = (s == 0) ? in : b.st[s - 1].a;
+        const Tensor x_conv = S.pre_gelu ? S.pre : x_raw;
+        Tensor dY;
+        if (S.gn >= 0) {
+            const GNLayer& g = e->gns[S.gn];
+            GNParams p = gn_base(e, g, B);
+            p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
+            p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
+            p.dgamma = e->grads + g.ggamma; p.dbeta = e->grads + g.gbeta;
+            ew_gn_bwd_reduce(e->dt, p, e->stream);
+            p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb;
+            ew_gn_bwd_apply(e->dt, p, e->stream);
+            dY = S.dy;
+        } else if (S.act) {
+            GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
+            p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb; p.B = B; p.T = e->T; p.C = L.cout;
+            ew_act(e->dt, 1, p, e->stream);
+            dY = S.dy;
+        } else {
+            GNParams p; p.y = dA.p; p.ldy = dA.ld; p.dbias = e->grads + L.gb; p.B = B; p.T = e->T; p.C = L.cout;
+            ew_act(e->dt, 2, p, e->stream);
+            dY = dA;
+        }
+        sc = 1.0f;
+        CHK(conv_bwd_dw(e, L, dY, x_conv, M));
+        const bool need = (s > 0) || (dIn != nullptr);
+        if (need) {
+            const Tensor target = (s > 0) ? b.st[s - 1].da : *dIn;
+            if (S.pre_gelu) {
+                CHK(conv_bwd_dx(e, L, dY, S.dpre, nullptr, M));
+                GNParams p; p.y = x_raw.p; p.ldy = x_raw.ld; p.dout = S.dpre.p; p.lddout = S.dpre.ld; p.rscale = 1.f;
+                p.out = target.p; p.ldout = target.ld; p.B = B; p.T = e->T; p.C = x_raw.C;
+                ew_act(e->dt, 1, p, e->stream);
+            } else {
+                const Tensor* add = (s == 0 && b.residual) ? &dOut : nullptr;
+                CHK(conv_bwd_dx(e, L, dY, target, add, M));
+            }
+            dA = target;
+        }
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------
+extern "C" {
+
+const char* sgv_last_error(void) { return g_err; }
+
+int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
+    if (!cfg || !out) return fail(SGV_ERR_ARG, "null argument");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(SGV_ERR_NOGPU, "no HIP device visible: libsgvae has no CPU fallback");
+    if (cfg->n_levels < 2 || cfg->n_levels > SGV_MAX_LEVELS) return fail(SGV_ERR_ARG, "n_levels must be in [2,%d]", SGV_MAX_LEVELS);
+    if (cfg->n_levels - 1 + 2 > SGV_MAX_SCALARS) return fail(SGV_ERR_ARG, "too many levels");
+    if (cfg->compute_dtype != SGV_DTYPE_F32 && cfg->compute_dtype != SGV_DTYPE_BF16) return fail(SGV_ERR_ARG, "bad compute_dtype");
+    if (cfg->num_node % 8 || cfg->latent_dim % 8 || cfg->hierarchical_dim % 8)
+        return fail(SGV_ERR_ARG, "num_node, latent_dim and hierarchical_dim must be multiples of 8 (16-byte channel vectors)");
+    for (int i = 0; i < cfg->n_levels; ++i)
+        if (cfg->num_filter_enc[i] % 8 || cfg->num_filter_enc[i] <= 0) return fail(SGV_ERR_ARG, "num_filter_enc[%d]=%d must be a positive multiple of 8", i, cfg->num_filter_enc[i]);
+    if (cfg->max_batch < 1 || cfg->num_time < 1) return fail(SGV_ERR_ARG, "bad batch/time");
+    if (cfg->loss_type < 0 || cfg->loss_type > 3) return fail(SGV_ERR_ARG, "bad loss_type");
+    sgv_engine* e = new sgv_engine();
+    e->cfg = *cfg;
+    e->stream = (hipStream_t)hip_stream;
+    e->dt = cfg->compute_dtype; e->esz = e->dt == SGV_DTYPE_BF16 ? 2 : 4;
+    e->n = cfg->n_levels; e->n_st = e->n - 1; e->T = cfg->num_time; e->N = cfg->num_node;
+    e->Z = cfg->latent_dim; e->H = cfg->hierarchical_dim; e->maxB = cfg->max_batch;
+    e->use_tr = (cfg->flags & 1) ? 0 : 1;
+    for (int i = 0; i < e->n; ++i) e->enc.push_back(cfg->num_filter_enc[i]);
+    e->dec.assign(e->enc.rbegin(), e->enc.rend());
+    int r;
+    if ((r = build_graph(e)) || (r = layout_arenas(e)) || (r = layout_grads(e)) || (r = alloc_activations(e)) || (r = build_tables(e))) { delete e; return r; }
+    // workspace for split-K slabs: enough for the largest split GEMM
+    const long M = (long)e->maxB * e->T;
+    size_t pf = 0;
+    for (auto& l : e->layers) {
+        if (!l.used || l.op == OP_LINEAR) continue;
+        int sk = gemm_nt_pick_splitk((int)M, l.cout, l.cin, l.k, e->dt);
+        if (sk > 1) pf = std::max(pf, (size_t)sk * M * l.cout);
+        sk = gemm_nt_pick_splitk((int)M, l.cin, l.cout, l.k, e->dt);
+        if (sk > 1 && l.need_wct) pf = std::max(pf, (size_t)sk * M * l.cin);
+        sk = gemm_tn_pick_splitk((int)M, l.cout, l.cin, l.k, e->dt);
+        if (sk > 1) pf = std::max(pf, (size_t)sk * l.nw());
+    }
+    if (pf < ((size_t)32 << 20)) pf = (size_t)32 << 20;   // batch < max_batch can pick deeper splits
+    e->partial_floats = pf;
+    e->xpose_floats = (size_t)M * std::max(e->N, 8);
+    for (int i = 0; i < e->n; ++i) e->xpose_floats = std::max(e->xpose_floats, (size_t)M * e->enc[i] * 2);
+#define ALLOC(ptr, bytes)                                                                                      \
+    do {                                                                                                       \
+        size_t b_ = (bytes);                                                                                   \
+        if (b_ == 0) b_ = 256;                                                                                 \
+        if (hipMalloc((void**)&(ptr), b_) != hipSuccess) { int rc = fail(SGV_ERR_HIP, "hipMalloc(%zu bytes) failed for " #ptr, b_); sgv_destroy(e); return rc; } \
+        hipMemsetAsync((ptr), 0, b_, e->stream);                                                               \
+    } while (0)
+    ALLOC(e->params, e->n_params * 4);
+    ALLOC(e->grads, e->n_grads * 4);
+    ALLOC(e->adam_m, e->n_grads * 4);
+    ALLOC(e->adam_v, e->n_grads * 4);
+    ALLOC(e->copies, e->n_copies * e->esz);
+    ALLOC(e->act, e->act_bytes);
+    ALLOC(e->stats, e->n_stats * 8);
+    ALLOC(e->sn_tmp, e->n_sn_tmp * 4);
+    ALLOC(e->sn_sigma, e->layers.size() * 2 * 4);
+    ALLOC(e->sn_dot, e->layers.size() * 8);
+    ALLOC(e->scal, 32 * 8);
+    ALLOC(e->partial, e->partial_floats * 4);
+    ALLOC(e->xpose_tmp, e->xpose_floats * 4);
+#undef ALLOC
+    rebase_all(e);
+    if ((r = upload_tables(e))) { sgv_destroy(e); return r; }
+    if (hipStreamSynchronize(e->stream) != hipSuccess) { sgv_destroy(e); return fail(SGV_ERR_HIP, "stream sync failed in create"); }
+    *out = e;
+    return SGV_OK;
+}
+
+int sgv_destroy(sgv_engine* e) {
+    if (!e) return SGV_OK;
+    hipStreamSynchronize(e->stream);
+    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot,
+                    e->scal, e->partial, e->xpose_tmp, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy};
+    for (void* p : ptrs) if (p) hipFree(p);
+    for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    delete e;
+    return SGV_OK;
+}
+
+int sgv_param_count(const sgv_engine* e) { return e ? (int)e->entries.size() : 0; }
+
+int sgv_param_info(const sgv_engine* e, int index, const char** name, int* ndim, int64_t shape[4], int* kind, int* has_grad) {
+    if (!e || index < 0 || index >= (int)e->entries.size()) return fail(SGV_ERR_ARG, "bad index");
+    const StateEntry& s = e->entries[index];
+    if (name) *name = s.name.c_str();
+    if (ndim) *ndim = (int)s.shape.size();
+    if (shape) for (size_t i = 0; i < s.shape.size() && i < 4; ++i) shape[i] = s.shape[i];
+    if (kind) *kind = s.kind;
+    if (has_grad) *has_grad = s.has_grad ? 1 : 0;
+    return SGV_OK;
+}
+
+}  // extern "C"
+
+// ---- reference layout <-> internal layout (host) ---------------------------------------------
+// dir = +1: ref -> internal; -1: internal -> ref
+static void permute_entry(const sgv_engine* e, const StateEntry& s, const float* src, float* dst, int dir) {
+    const long cnt = s.count();
+    if (s.gn >= 0) { memcpy(dst, src, cnt * 4); return; }
+    const Layer& l = e->layers[s.layer];
+    const int T = e->T;
+    auto mov = [&](long iref, long iint) { if (dir > 0) dst[iint] = src[iref]; else dst[iref] = src[iint]; };
+    if (s.kind == 1) {
+        if (l.op == OP_CONV) {
+            for (int co = 0; co < l.cout; ++co) for (int ci = 0; ci < l.cin; ++ci) for (int j = 0; j < l.k; ++j)
+                mov(((long)co * l.cin + ci) * l.k + j, ((long)j * l.cout + co) * l.cin + ci);
+        } else if (l.op == OP_CONVT) {
+            for (int ci = 0; ci < l.cin; ++ci) for (int co = 0; co < l.cout; ++co) for (int j = 0; j < l.k; ++j)
+                mov(((long)ci * l.cout + co) * l.k + j, ((long)(l.k - 1 - j) * l.cout + co) * l.cin + ci);
+        } else if (l.lin_kind == LIN_HEAD) {
+            const int C = l.lin_C;
+            for (int o = 0; o < l.cout; ++o) for (int c = 0; c < C; ++c) for (int t = 0; t < T; ++t)
+                mov((long)o * l.cin + (long)c * T + t, (long)o * l.cin + (long)t * C + c);
+        } else {  // LIN_EXPAND: rows permuted
+            const int C = l.lin_C;
+            for (int c = 0; c < C; ++c) for (int t = 0; t < T; ++t) for (int k = 0; k < l.cin; ++k)
+                mov(((long)c * T + t) * l.cin + k, ((long)t * C + c) * l.cin + k);
+        }
+    } else if (s.kind == 3) {  // v over matrix columns
+        if (l.op == OP_CONV) { for (int ci = 0; ci < l.cin; ++ci) for (int j = 0; j < l.k; ++j) mov((long)ci * l.k + j, (long)j * l.cin + ci); }
+        else if (l.op == OP_CONVT) { for (int ci = 0; ci < l.cin; ++ci) for (int j = 0; j < l.k; ++j) mov((long)ci * l.k + j, (long)(l.k - 1 - j) * l.cin + ci); }
+        else if (l.lin_kind == LIN_HEAD) { const int C = l.lin_C; for (int c = 0; c < C; ++c) for (int t = 0; t < T; ++t) mov((long)c * T + t, (long)t * C + c); }
+        else memcpy(dst, src, cnt * 4);
+    } else {  // bias (0) or u (2): per output row
+        if (l.op == OP_LINEAR && l.lin_kind == LIN_EXPAND) { const int C = l.lin_C; for (int c = 0; c < C; ++c) for (int t = 0; t < T; ++t) mov((long)c * T + t, (long)t * C + c); }
+        else memcpy(dst, src, cnt * 4);
+    }
+}
+static size_t entry_param_offset(const sgv_engine* e, const StateEntry& s) {
+    if (s.gn >= 0) return s.kind == 4 ? e->gns[s.gn].gamma : e->gns[s.gn].beta;
+    const Layer& l = e->layers[s.layer];
+    switch (s.kind) { case 0: return l.b; case 1: return l.w; case 2: return l.u; default: return l.v; }
+}
+static size_t entry_grad_offset(const sgv_engine* e, const StateEntry& s) {
+    if (!s.has_grad) return NPOS;
+    if (s.gn >= 0) return s.kind == 4 ? e->gns[s.gn].ggamma : e->gns[s.gn].gbeta;
+    const Layer& l = e->layers[s.layer];
+    return s.kind == 0 ? l.gb : (s.kind == 1 ? l.gw : NPOS);
+}
+static const StateEntry* find_entry(sgv_engine* e, const char* name) {
+    auto it = e->entry_index.find(name);
+    if (it == e->entry_index.end()) return nullptr;
+    return &e->entries[it->second];
+}
+
+static int refresh_copies(sgv_engine* e) {
+    int r = opt_make_copies(e->adam_dev, e->items_copy, e->n_items_copy, e->dt, e->stream);
+    if (r) return fail(SGV_ERR_HIP, "make_copies launch failed");
+    e->copies_fresh = true;
+    return 0;
+}
+
+static int run_sn(sgv_engine* e, int train) {
+    HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp * 4, e->stream));
+    if (opt_sn_power_iteration(e->sn_dev, e->items_sn, e->n_items_sn, e->items_sn, e->n_items_sn, (int)e->layers.size(), train, e->stream))
+        return fail(SGV_ERR_HIP, "spectral-norm launch failed");
+    return 0;
+}
+
+static int export_act(sgv_engine* e, const Tensor& t, int B, float* host) {
+    // [B][T][C] compute dtype -> [B][C][T] fp32
+    const long cnt = (long)B * e->T * t.C;
+    if ((size_t)cnt > e->xpose_floats) return fail(SGV_ERR_ARG, "activation too large for the export buffer");
+    ew_transpose(t.f32 ? 0 : e->dt, 0, t.p, e->xpose_tmp, B, e->T, t.C, t.ld, e->T, (long)e->T * t.ld, (long)t.C * e->T, e->stream);
+    HIPCHK(hipMemcpyAsync(host, e->xpose_tmp, cnt * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return 0;
+}
+
+extern "C" {
+
+int sgv_load_state(sgv_engine* e, const char* name, const float* host, size_t count) {
+    if (!e || !name || !host) return fail(SGV_ERR_ARG, "null argument");
+    const StateEntry* s = find_entry(e, name);
+    if (!s) return fail(SGV_ERR_NAME, "unknown state key '%s'", name);
+    if ((long)count != s->count()) return fail(SGV_ERR_ARG, "size mismatch for '%s': got %zu expected %ld", name, count, s->count());
+    std::vector<float> tmp(count);
+    permute_entry(e, *s, host, tmp.data(), +1);
+    HIPCHK(hipMemcpy(e->params + entry_param_offset(e, *s), tmp.data(), count * 4, hipMemcpyHostToDevice));
+    e->copies_fresh = false;
+    return SGV_OK;
+}
+
+int sgv_export_state(sgv_engine* e, const char* name, float* host, size_t count) {
+    if (!e || !name || !host) return fail(SGV_ERR_ARG, "null argument");
+    const StateEntry* s = find_entry(e, name);
+    if (!s) return fail(SGV_ERR_NAME, "unknown state key '%s'", name);
+    if ((long)count != s->count()) return fail(SGV_ERR_ARG, "size mismatch for '%s'", name);
+    std::vector<float> tmp(count);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(tmp.data(), e->params + entry_param_offset(e, *s), count * 4, hipMemcpyDeviceToHost));
+    permute_entry(e, *s, tmp.data(), host, -1);
+    return SGV_OK;
+}
+
+int sgv_export_grad(sgv_engine* e, const char* name, float* host, size_t count, int* is_none) {
+    if (!e || !name || !host) return fail(SGV_ERR_ARG, "null argument");
+    const StateEntry* s = find_entry(e, name);
+    if (!s) return fail(SGV_ERR_NAME, "unknown state key '%s'", name);
+    if ((long)count != s->count()) return fail(SGV_ERR_ARG, "size mismatch for '%s'", name);
+    const size_t go = entry_grad_offset(e, *s);
+    if (is_none) *is_none = (go == NPOS);
+    if (go == NPOS) { memset(host, 0, count * 4); return SGV_OK; }
+    std::vector<float> g(count);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    HIPCHK(hipMemcpy(g.data(), e->grads + go, count * 4, hipMemcpyDeviceToHost));
+    if (s->kind == 1) {
+        // spectral-norm chain rule on the host (fp64): g_orig = (G - <G,W>/sigma * u v^T) / sigma
+        const Layer& l = e->layers[s->layer];
+        std::vector<float> w(count), u(l.cout), v((size_t)l.cin * l.k);
+        float sig[2];
+        HIPCHK(hipMemcpy(w.data(), e->params + l.w, count * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(u.data(), e->params + l.u, u.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(v.data(), e->params + l.v, v.size() * 4, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(sig, e->sn_sigma + 2 * l.sn, 8, hipMemcpyDeviceToHost));
+        double dot = 0.0;
+        for (size_t i = 0; i < count; ++i) dot += (double)g[i] * (double)w[i];
+        const double c = dot / sig[0];
+        for (int j = 0; j < l.k; ++j) for (int r = 0; r < l.cout; ++r) for (int cc = 0; cc < l.cin; ++cc) {
+            const size_t i = ((size_t)j * l.cout + r) * l.cin + cc;
+            g[i] = (float)(((double)g[i] - c * (double)u[r] * (double)v[(size_t)j * l.cin + cc]) / sig[0]);
+        }
+    }
+    permute_entry(e, *s, g.data(), host, -1);
+    return SGV_OK;
+}
+
+int sgv_export_adam(sgv_engine* e, const char* name, float* host_m, float* host_v, size_t count) {
+    if (!e || !name) return fail(SGV_ERR_ARG, "null argument");
+    const StateEntry* s = find_entry(e, name);
+    if (!s) return fail(SGV_ERR_NAME, "unknown state key '%s'", name);
+    const size_t go = entry_grad_offset(e, *s);
+    if (go == NPOS) return fail(SGV_ERR_ARG, "'%s' has no optimizer state", name);
+    if ((long)count != s->count()) return fail(SGV_ERR_ARG, "size mismatch for '%s'", name);
+    std::vector<float> t(count);
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (host_m) { HIPCHK(hipMemcpy(t.data(), e->adam_m + go, count * 4, hipMemcpyDeviceToHost)); permute_entry(e, *s, t.data(), host_m, -1); }
+    if (host_v) { HIPCHK(hipMemcpy(t.data(), e->adam_v + go, count * 4, hipMemcpyDeviceToHost)); permute_entry(e, *s, t.data(), host_v, -1); }
+    return SGV_OK;
+}
+
+int sgv_prepare(sgv_engine* e) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    return refresh_copies(e);
+}
+
+int sgv_set_input(sgv_engine* e, const float* x_dev, int batch) {
+    if (!e || !x_dev) return fail(SGV_ERR_ARG, "null argument");
+    if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "batch %d outside [1,%d]", batch, e->maxB);
+    // [B][N][T] fp32 -> [B][T][N] compute dtype
+    ew_transpose(0, e->dt, x_dev, e->x_in.p, batch, e->N, e->T, e->T, e->x_in.ld, (long)e->N * e->T, (long)e->T * e->x_in.ld, e->stream);
+    e->batch = batch;
+    e->have_fwd = false;
+    return SGV_OK;
+}
+
+int sgv_set_eps(sgv_engine* e, int site, const float* eps_dev, int batch) {
+    if (!e || !eps_dev) return fail(SGV_ERR_ARG, "null argument");
+    if (site < 0 || site >= e->n_st) return fail(SGV_ERR_ARG, "eps site %d outside [0,%d)", site, e->n_st);
+    if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "bad batch");
+    if (site == 0) {
+        HIPCHK(hipMemcpyAsync(e->eps[0], eps_dev, (size_t)batch * e->Z * 4, hipMemcpyDeviceToDevice, e->stream));
+    } else {
+        const int C = e->dec[site];
+        ew_transpose(0, 0, eps_dev, e->eps[site], batch, C, e->T, e->T, C, (long)C * e->T, (long)e->T * C, e->stream);
+    }
+    e->eps_set[site] = 1;
+    return SGV_OK;
+}
+
+int sgv_seed(sgv_engine* e, uint64_t seed) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    e->seed = seed; e->draw = 0;
+    return SGV_OK;
+}
+
+int sgv_set_option(sgv_engine* e, const char* key, int value) {
+    if (!e || !key) return fail(SGV_ERR_ARG, "null argument");
+    if (!strcmp(key, "write_xhat")) e->write_xhat = value != 0;
+    else if (!strcmp(key, "use_tr")) e->use_tr = value != 0;
+    else return fail(SGV_ERR_ARG, "unknown option '%s'", key);
+    return SGV_OK;
+}
+
+static int encoder_fwd(sgv_engine* e, int B) {
+    const int n = e->n;
+    Tensor x = e->x_in;
+    for (int i = 0; i < n; ++i) {
+        CHK(block_fwd(e, e->encA[i], x, B));
+        CHK(block_fwd(e, e->encR[i], e->encA[i].st.back().a, B));
+        x = e->enc_h[i];
+        if (i < n - 1) {
+            const Layer& l = e->layers[e->xs_lin[i]];
+            ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xs_raw[i], B, l.cin, l.cout, e->stream);
+        }
+    }
+    const Layer& l = e->layers[e->last_lin];
+    ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->last, B, l.cin, l.cout, e->stream);
+    return 0;
+}
+
+int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (e->batch < 1) return fail(SGV_ERR_STATE, "no input set");
+    if (train && mode_fix) return fail(SGV_ERR_ARG, "mode_fix is an inference path");
+    if (!e->copies_fresh) CHK(refresh_copies(e));
+    const int B = e->batch, n = e->n, n_st = e->n_st;
+    const long M = (long)B * e->T;
+    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
+    CHK(run_sn(e, train));
+    CHK(encoder_fwd(e, B));
+    // noise
+    for (int s = 0; s < n_st; ++s) {
+        if (!e->eps_set[s]) {
+            const long cnt = s == 0 ? (long)B * e->Z : M * e->dec[s];
+            ew_randn(e->eps[s], cnt, e->seed, (e->draw++) * 8 + s, e->stream);
+        }
+    }
+    ew_latent_fwd(e->last, e->eps[0], e->zlat, B, e->Z, e->scal + 2, e->stream);
+    {
+        const Layer& l = e->layers[e->start_lin];
+        ew_linear_expand_fwd(e->dt, e->zlat, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->sbuf.p, B, l.cin, l.cout, e->stream);
+    }
+    CHK(block_fwd(e, e->decS, e->sbuf, B));
+    for (int i = 0; i < n_st; ++i) {
+        CHK(block_fwd(e, e->decU[i], e->zs[i], B));
+        CHK(block_fwd(e, e->decD[i], e->decU[i].st.back().a, B));
+        if (i == n_st - 1) break;
+        const int C = e->dec[i + 1];
+        CHK(block_fwd(e, e->decP1[i], e->dec_out[i], B));
+        CHK(block_fwd(e, e->decP2[i], e->decP1[i].st.back().a, B));
+        {
+            const Layer& l = e->layers[e->xs_exp[i]];
+            const int lvl = n - 2 - i;
+            ew_linear_expand_fwd(e->dt, e->xs_raw[lvl], e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xl[i].p, B, l.cin, l.cout, e->stream);
+        }
+        CHK(block_fwd(e, e->decX[i], e->xl[i], B));
+        CHK(block_fwd(e, e->decQ1[i], e->cat[i], B));
+        CHK(block_fwd(e, e->decQ2[i], e->decQ1[i].st.back().a, B));
+        ew_stage_fwd(e->dt, (const float*)e->decP2[i].st[0].y.p, (const float*)e->decQ2[i].st[0].y.p, e->eps[i + 1], e->dec_out[i].p, e->dec_out[i].ld,
+                     e->zs[i + 1].p, e->zs[i + 1].ld, e->zmap[i], (int)M, C, mode_fix ? 1e-10f : 1.0f, e->scal + 3 + i, 1.0f / B, e->stream);
+    }
+    // recon head: conv -> GroupNorm stats -> tanh + loss (+ backward reductions in training)
+    {
+        Stage& S = e->recon.st[0];
+        const Layer& L = e->layers[S.layer];
+        const GNLayer& g = e->gns[S.gn];
+        CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M));
+        GNParams p = gn_base(e, g, B);
+        p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
+        ew_gn_stats(e->dt, p, e->stream);
+        p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type;
+        p.loss_sums = e->scal;
+        if (e->write_xhat || !train) { p.out = e->xhat.p; p.ldout = e->xhat.ld; }
+        if (train) {
+            HIPCHK(hipMemsetAsync(e->recon_unit, 0, 2L * e->N * 4, e->stream));
+            HIPCHK(hipMemsetAsync(e->stats + S.sums2, 0, (size_t)B * g.G * 2 * 8, e->stream));
+            p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
+        }
+        ew_recon_loss(e->dt, train, p, e->stream);
+    }
+    e->have_fwd = true;
+    e->fwd_train = train != 0;
+    for (int s = 0; s < n_st; ++s) e->eps_set[s] = 0;
+    if (scalars_host) {
+        double h[16];
+        HIPCHK(hipMemcpyAsync(h, e->scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+        HIPCHK(hipStreamSynchronize(e->stream));
+        const double numel = (double)M * e->N;
+        for (int i = 0; i < SGV_MAX_SCALARS; ++i) scalars_host[i] = 0.f;
+        scalars_host[0] = (float)(h[0] / numel);
+        scalars_host[1] = (float)h[2];
+        for (int i = 0; i + 1 < n_st; ++i) scalars_host[2 + i] = (float)h[3 + i];
+        scalars_host[1 + n_st] = (float)(h[1] / numel);
+    }
+    return SGV_OK;
+}
+
+int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (e->batch < 1) return fail(SGV_ERR_STATE, "no input set");
+    if (!e->copies_fresh) CHK(refresh_copies(e));
+    const int B = e->batch;
+    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    CHK(run_sn(e, 0));
+    CHK(encoder_fwd(e, B));
+    std::vector<float> last((size_t)B * 2 * e->Z);
+    HIPCHK(hipMemcpyAsync(last.data(), e->last, last.size() * 4, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    for (int b = 0; b < B; ++b) {
+        if (mu_host) memcpy(mu_host + (size_t)b * e->Z, &last[(size_t)b * 2 * e->Z], e->Z * 4);
+        if (logvar_host) memcpy(logvar_host + (size_t)b * e->Z, &last[(size_t)b * 2 * e->Z + e->Z], e->Z * 4);
+    }
+    if (xs_host) {
+        // list order of Encoder.forward's return: [xs_{n-2}, ..., xs_0]
+        for (int j = 0; j < e->n - 1; ++j)
+            HIPCHK(hipMemcpy(xs_host + (size_t)j * B * e->H, e->xs_raw[e->n - 2 - j], (size_t)B * e->H * 4, hipMemcpyDeviceToHost));
+    }
+    return SGV_OK;
+}
+
+int sgv_get_xhat(sgv_engine* e, float* xhat_dev) {
+    if (!e || !xhat_dev) return fail(SGV_ERR_ARG, "null argument");
+    if (!e->have_fwd) return fail(SGV_ERR_STATE, "no forward pass to read from");
+    ew_transpose(e->dt, 0, e->xhat.p, xhat_dev, e->batch, e->T, e->N, e->xhat.ld, e->T, (long)e->T * e->xhat.ld, (long)e->N * e->T, e->stream);
+    return SGV_OK;
+}
+
+int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t count) {
+    if (!e || !name || !host) return fail(SGV_ERR_ARG, "null argument");
+    if (!e->have_fwd) return fail(SGV_ERR_STATE, "no forward pass to read from");
+    const int B = e->batch;
+    std::string s(name);
+    auto chk = [&](long want) { return (long)count == want ? 0 : fail(SGV_ERR_ARG, "size mismatch for activation '%s': got %zu expected %ld", name, count, want); };
+    auto idx = [&](const char* pre) { return atoi(s.c_str() + strlen(pre)); };
+    HIPCHK(hipStreamSynchronize(e->stream));
+    if (s.rfind("enc_h", 0) == 0) { int i = idx("enc_h"); if (i < 0 || i >= e->n) return fail(SGV_ERR_NAME, "bad index"); CHK(chk((long)B * e->T * e->enc[i])); return export_act(e, e->enc_h[i], B, host); }
+    if (s.rfind("dec_out", 0) == 0) { int i = idx("dec_out"); if (i < 0 || i >= e->n_st) return fail(SGV_ERR_NAME, "bad index"); CHK(chk((long)B * e->T * e->dec[i + 1])); return export_act(e, e->dec_out[i], B, host); }
+    if (s.rfind("zmap", 0) == 0) {
+        int i = idx("zmap"); if (i < 0 || i + 1 >= e->n_st) return fail(SGV_ERR_NAME, "bad index");
+        Tensor t; t.p = e->zmap[i]; t.C = e->dec[i + 1]; t.ld = t.C; t.f32 = true;
+        CHK(chk((long)B * e->T * t.C)); return export_act(e, t, B, host);
+    }
+    if (s == "x_hat") { CHK(chk((long)B * e->T * e->N)); return export_act(e, e->xhat, B, host); }
+    if (s == "mu" || s == "log_var") {
+        CHK(chk((long)B * e->Z));
+        std::vector<float> last((size_t)B * 2 * e->Z);
+        HIPCHK(hipMemcpy(last.data(), e->last, last.size() * 4, hipMemcpyDeviceToHost));
+        for (int b = 0; b < B; ++b) memcpy(host + (size_t)b * e->Z, &last[(size_t)b * 2 * e->Z + (s == "mu" ? 0 : e->Z)], e->Z * 4);
+        return SGV_OK;
+    }
+    if (s == "z") { CHK(chk((long)B * e->Z)); HIPCHK(hipMemcpy(host, e->zlat, count * 4, hipMemcpyDeviceToHost)); return SGV_OK; }
+    if (s.rfind("xs", 0) == 0) {
+        int j = idx("xs"); if (j < 0 || j >= e->n - 1) return fail(SGV_ERR_NAME, "bad index");
+        CHK(chk((long)B * e->H)); HIPCHK(hipMemcpy(host, e->xs_raw[e->n - 2 - j], count * 4, hipMemcpyDeviceToHost)); return SGV_OK;
+    }
+    return fail(SGV_ERR_NAME, "unknown activation '%s'", name);
+}
+
+int sgv_set_bucket_callback(sgv_engine* e, sgv_bucket_cb cb, void* user) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    e->cb = cb; e->cb_user = user;
+    return SGV_OK;
+}
+int sgv_grad_buffer(sgv_engine* e, float** dev_ptr, size_t* count_elems) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (dev_ptr) *dev_ptr = e->grads;
+    if (count_elems) *count_elems = e->n_grads;
+    return SGV_OK;
+}
+int sgv_scale_grads(sgv_engine* e, float factor) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    ew_scale(e->grads, factor, (long)e->n_grads, e->stream);
+    return SGV_OK;
+}
+
+int sgv_backward(sgv_engine* e, float alpha, float beta) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (!e->have_fwd || !e->fwd_train) return fail(SGV_ERR_STATE, "sgv_backward needs a preceding sgv_forward(train=1)");
+    const int B = e->batch, n = e->n, n_st = e->n_st;
+    const long M = (long)B * e->T;
+    const float coefB = beta / (float)B;
+    int bucket = 0;
+    auto fire = [&]() { if (e->cb && bucket < (int)e->buckets.size()) e->cb(e->cb_user, bucket, e->buckets[bucket].first, e->buckets[bucket].second); ++bucket; };
+    // zero the small-gradient zone (biases / GroupNorm affine use atomics) and the backward group sums
+    HIPCHK(hipMemsetAsync(e->grads + e->n_grads_w, 0, (e->n_grads - e->n_grads_w) * 4, e->stream));
+    {
+        // keep the recon head's sums2 (filled by the forward loss pass): it is the last forward slot
+        Stage& S = e->recon.st[0];
+        const size_t lo = e->n_stats_fwd, hi = e->n_stats_fwd + S.sums;   // all slots before the recon slot
+        HIPCHK(hipMemsetAsync(e->stats + lo, 0, (hi - lo) * 8, e->stream));
+    }
+    // ---- recon head ----
+    {
+        Stage& S = e->recon.st[0];
+        const Layer& L = e->layers[S.layer];
+        const GNLayer& g = e->gns[S.gn];
+        const float gs = alpha / (float)((double)M * e->N);
+        GNParams p = gn_base(e, g, B);
+        p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
+        p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type; p.gscale = gs;
+        p.out = e->dy_recon.p; p.ldout = e->dy_recon.ld; p.dbias = e->grads + L.gb;
+        ew_recon_bwd_apply(e->dt, p, e->stream);
+        ew_axpy(e->grads + g.ggamma, e->recon_unit, gs, e->N, e->stream);
+        ew_axpy(e->grads + g.gbeta, e->recon_unit + e->N, gs, e->N, e->stream);
+        CHK(conv_bwd_dw(e, L, e->dy_recon, e->dec_out[n_st - 1], M));
+        CHK(conv_bwd_dx(e, L, e->dy_recon, e->d_out[n_st - 1], nullptr, M));
+        fire();
+    }
+    // ---- decoder stages ----
+    for (int i = n_st - 1; i >= 0; --i) {
+        const int C = e->dec[i + 1];
+        if (i < n_st - 1) {
+            ew_stage_bwd(e->dt, (const float*)e->decP2[i].st[0].y.p, (const float*)e->decQ2[i].st[0].y.p, e->eps[i + 1], e->dzs[i + 1].p, e->dzs[i + 1].ld,
+                         e->gp[i].p, e->gq[i].p, (int)M, C, coefB, e->stream);
+            CHK(block_bwd(e, e->decQ2[i], e->decQ1[i].st.back().a, e->gq[i], &e->d_qres[i], B));
+            CHK(block_bwd(e, e->decQ1[i], e->cat[i], e->d_qres[i], &e->dcat[i], B));
+            Tensor d_xs = e->dcat[i]; d_xs.C = C;
+            Tensor d_oq = e->dcat[i]; d_oq.C = C; d_oq.p = (char*)d_oq.p + (size_t)C * e->esz;
+            CHK(block_bwd(e, e->decX[i], e->xl[i], d_xs, &e->d_xl[i], B));
+            {
+                const Layer& l = e->layers[e->xs_exp[i]];
+                const int lvl = n - 2 - i;
+                ew_linear_expand_bwd(e->dt, e->d_xl[i].p, e->xs_raw[lvl], e->params + l.w, e->sn_sigma + 2 * l.sn + 1, e->d_xs_raw[lvl],
+                                     e->grads + l.gw, e->grads + l.gb, B, l.cin, l.cout, e->stream);
+            }
+            CHK(block_bwd(e, e->decP2[i], e->decP1[i].st.back().a, e->gp[i], &e->d_pres[i], B));
+            CHK(block_bwd(e, e->decP1[i], e->dec_out[i], e->d_pres[i], &e->d_outp[i], B));
+            ew_add3(e->dt, e->d_outp[i].p, e->d_outp[i].ld, e->dzs[i + 1].p, e->dzs[i + 1].ld, d_oq.p, d_oq.ld, e->d_out[i].p, e->d_out[i].ld, (int)M, C, e->stream);
+        }
+        CHK(block_bwd(e, e->decD[i], e->decU[i].st.back().a, e->d_out[i], &e->d_u[i], B));
+        CHK(block_bwd(e, e->decU[i], e->zs[i], e->d_u[i], &e->dzs[i], B));
+        if (i == 0) {
+            CHK(block_bwd(e, e->decS, e->sbuf, e->dzs[0], &e->d_sbuf, B));
+            const Layer& l = e->layers[e->start_lin];
+            ew_linear_expand_bwd(e->dt, e->d_sbuf.p, e->zlat, e->params + l.w, e->sn_sigma + 2 * l.sn + 1, e->d_z, e->grads + l.gw, e->grads + l.gb,
+                                 B, l.cin, l.cout, e->stream);
+        }
+        fire();
+    }
+    // ---- latent + encoder ----
+    ew_latent_bwd(e->last, e->eps[0], e->d_z, e->d_last, B, e->Z, coefB, e->stream);
+    {
+        const Layer& l = e->layers[e->last_lin];
+        ew_linear_head_bwd(e->dt, e->d_last, e->enc_h[n - 1].p, e->params + l.w, e->sn_sigma + 2 * l.sn + 1, nullptr, e->d_h[n - 1].p,
+                           e->grads + l.gw, e->grads + l.gb, B, l.cin, l.cout, e->stream);
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        const Layer& xl = e->layers[e->xs_lin[i]];
+        if (xl.has_grad) {
+            ew_linear_head_bwd(e->dt, e->d_xs_raw[i], e->enc_h[i].p, e->params + xl.w, e->sn_sigma + 2 * xl.sn + 1, e->d_h[i].p, e->d_h[i].p,
+                               e->grads + xl.gw, e->grads + xl.gb, B, xl.cin, xl.cout, e->stream);
+        }
+        CHK(block_bwd(e, e->encR[i], e->encA[i].st.back().a, e->d_h[i], &e->enc_a_dummy[i], B));
+        if (i == 0) fire();   // everything but the first-layer weight gradient is now enqueued
+        const Tensor x_prev = i == 0 ? e->x_in : e->enc_h[i - 1];
+        CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], i > 0 ? &e->d_h[i - 1] : nullptr, B));
+    }
+    fire();
+    fire();   // small zone
+    return SGV_OK;
+}
+
+static int compute_dots(sgv_engine* e) {
+    HIPCHK(hipMemsetAsync(e->sn_dot, 0, e->layers.size() * 8, e->stream));
+    if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
+    return 0;
+}
+
+int sgv_grad_norm(sgv_engine* e, double* out) {
+    if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
+    CHK(compute_dots(e));
+    HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
+    if (opt_grad_norm(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, e->scal + 15, e->stream)) return fail(SGV_ERR_HIP, "grad-norm launch failed");
+    double h = 0.0;
+    HIPCHK(hipMemcpyAsync(&h, e->scal + 15, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = sqrt(h);
+    return SGV_OK;
+}
+
+int sgv_adamw_step(sgv_engine* e, float lr) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    CHK(compute_dots(e));
+    e->step += 1;
+    const double b1 = 0.9, b2 = 0.999;
+    const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
+    const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
+    HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
+    if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+        return fail(SGV_ERR_HIP, "adamw launch failed");
+    CHK(refresh_copies(e));
+    return SGV_OK;
+}
+
+size_t sgv_dataset_sample_bytes(const sgv_engine* e) { return e ? (size_t)e->N * e->T * e->esz : 0; }
+
+int sgv_dataset_convert(sgv_engine* e, const float* src_dev, void* dst_dev, int count) {
+    if (!e || !src_dev || !dst_dev) return fail(SGV_ERR_ARG, "null argument");
+    ew_transpose(0, e->dt, src_dev, dst_dev, count, e->N, e->T, e->T, e->N, (long)e->N * e->T, (long)e->T * e->N, e->stream);
+    return SGV_OK;
+}
+
+int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const int32_t* idx, const uint64_t* noise_seed,
+                        const float* scale, const int32_t* mix_idx, const float* lam) {
+    if (!e || !dataset_dev || !idx || !noise_seed || !scale || !mix_idx || !lam) return fail(SGV_ERR_ARG, "null argument");
+    if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "batch %d outside [1,%d]", batch, e->maxB);
+    // small per-sample control arrays go through a device scratch at the head of xpose_tmp
+    char* scratch = (char*)e->xpose_tmp;
+    int* d_idx = (int*)scratch; int* d_mix = d_idx + batch;
+    float* d_scale = (float*)(d_mix + batch); float* d_lam = d_scale + batch;
+    unsigned long long* d_seed = (unsigned long long*)(scratch + align_up((size_t)batch * 16, 8));
+    HIPCHK(hipMemcpyAsync(d_idx, idx, batch * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_mix, mix_idx, batch * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_scale, scale, batch * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_lam, lam, batch * 4, hipMemcpyHostToDevice, e->stream));
+    HIPCHK(hipMemcpyAsync(d_seed, noise_seed, batch * 8, hipMemcpyHostToDevice, e->stream));
+    ew_augment(e->dt, dataset_dev, e->x_in.p, (long)e->N * e->T, batch, d_idx, d_seed, d_scale, d_mix, d_lam, e->stream);
+    e->batch = batch;
+    e->have_fwd = false;
+    return SGV_OK;
+}
+
+int sgv_kernel_time_reset(sgv_engine* e, int enable) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    hipStreamSynchronize(e->stream);
+    for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    e->timers.clear();
+    e->timing = enable != 0;
+    return SGV_OK;
+}
+int sgv_kernel_time(sgv_engine* e, const char* which, float* total_ms, int* calls) {
+    if (!e || !which) return fail(SGV_ERR_ARG, "null argument");
+    HIPCHK(hipStreamSynchronize(e->stream));
+    auto it = e->tag_ids.find(which);
+    float tot = 0.f; int n = 0;
+    if (it != e->tag_ids.end()) {
+        for (auto& t : e->timers) if (t.tag == it->second) { float ms = 0.f; hipEventElapsedTime(&ms, t.a, t.b); tot += ms; ++n; }
+    }
+    if (total_ms) *total_ms = tot;
+    if (calls) *calls = n;
+    return SGV_OK;
+}
+
+int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend,
+                     int M, int N, int K, int taps, int Tlen, int splitk, int out_f32, void* stream) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N;
+    p.addend = addend; p.ldadd = N; p.bias = bias; p.scale = scale;
+    p.M = M; p.N = N; p.K = K; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.out_f32 = out_f32;
+    float* partial = nullptr;
+    if (p.splitk > 1) HIPCHK(hipMalloc((void**)&partial, sizeof(float) * (size_t)p.splitk * M * N));
+    p.partial = partial;
+    int r = launch_gemm_nt(dtype, p, (hipStream_t)stream);
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    if (partial) hipFree(partial);
+    if (r) return fail(SGV_ERR_ARG, "launch_gemm_nt rejected the arguments (%d)", r);
+    if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt failed: %s", hipGetErrorString(se));
+    return SGV_OK;
+}
+
+int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps, int Tlen, int splitk,
+                     int use_tr, void* stream) {
+    GemmTN p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr;
+    float* partial = nullptr;
+    const long nw = (long)taps * N1 * N2;
+    if (p.splitk > 1) {
+        HIPCHK(hipMalloc((void**)&partial, sizeof(float) * (size_t)p.splitk * nw));
+        p.out = partial; p.out_slab_stride = nw;
+    }
+    int r = launch_gemm_tn(dtype, p, (hipStream_t)stream);
+    if (!r && p.splitk > 1) {
+        int blocks = (int)((nw + 255) / 256); if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dW, partial, p.splitk, nw);
+    }
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    if (partial) hipFree(partial);
+    if (r) return fail(SGV_ERR_ARG, "launch_gemm_tn rejected the arguments (%d)", r);
+    if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_tn failed: %s", hipGetErrorString(se));
+    return SGV_OK;
+}
+
+}  // extern "C"

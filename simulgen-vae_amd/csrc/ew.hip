@@ -1,0 +1,917 @@
+// HBM-bound kernels of the SimulGen-VAE step on channels-last [B*T][C] maps (gfx950):
+// GroupNorm(+GELU/tanh) forward/backward (reference nn.GroupNorm/nn.GELU call sites
+// modules/encoder.py:35-36, modules/common.py:85-87,111-112,136-143, modules/decoder.py:119-120,
+// 136-137,146-147), the reconstruction loss fused into the recon-head GroupNorm pass
+// (modules/VAE_network.py:110-111), reparameterisation + KL terms (modules/decoder.py:199-223,
+// modules/losses.py:8-48), the small Linear heads (modules/encoder.py:140-142,156-162,
+// modules/decoder.py:133,143), layout conversion and augmentation (modules/augmentation.py:86-124).
+// All arithmetic in fp32 (group sums in fp64); every thread owns 8 consecutive channels (16/32-byte
+// vector accesses) and walks rows, so per-channel constants stay in registers.
+#include "sgv_ew.h"
+
+static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ------------------------------------------------------------------------------------------
+// geometry shared by the GroupNorm-family kernels
+// ------------------------------------------------------------------------------------------
+struct GNGeom {
+    int CV, RL, rowsplit;
+    dim3 grid;
+};
+static GNGeom gn_geom(int B, int T, int C) {
+    GNGeom g;
+    const int nv = C / 8;
+    int cv = 1;
+    while (cv < nv && cv < 256) cv <<= 1;
+    g.CV = cv;
+    g.RL = 256 / cv;
+    const int colblocks = cdiv_i(nv, cv);
+    // aim for >= ~2048 blocks, at least RL rows per block
+    int rs = cdiv_i(2048, (long)colblocks * B);
+    int maxrs = cdiv_i(T, g.RL);
+    if (rs > maxrs) rs = maxrs;
+    if (rs < 1) rs = 1;
+    g.rowsplit = rs;
+    g.grid = dim3(colblocks, rs, B);
+    return g;
+}
+
+struct GNCtx {
+    int tx, ty, c0, b, t_lo, t_hi, RL;
+    bool col_ok;
+};
+__device__ __forceinline__ GNCtx gn_ctx(const GNParams& p) {
+    GNCtx c;
+    const int tid = threadIdx.x;
+    c.tx = tid % p.CV;
+    c.ty = tid / p.CV;
+    c.RL = 256 / p.CV;
+    c.c0 = (blockIdx.x * p.CV + c.tx) * 8;
+    c.col_ok = c.c0 < p.C;
+    c.b = blockIdx.z;
+    const int rps = (p.T + gridDim.y - 1) / gridDim.y;
+    c.t_lo = blockIdx.y * rps;
+    c.t_hi = min(p.T, c.t_lo + rps);
+    return c;
+}
+
+// per-element mean / rstd of the element's group from the fp64 group sums
+__device__ __forceinline__ void gn_consts(const GNParams& p, const GNCtx& c, float mean[8], float rstd[8]) {
+    const double n = (double)p.Cg * (double)p.T;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = (c.c0 + e) / p.Cg;
+        const double s = p.sums[((long)c.b * p.G + g) * 2 + 0];
+        const double ss = p.sums[((long)c.b * p.G + g) * 2 + 1];
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0.0) var = 0.0;
+        mean[e] = (float)m;
+        rstd[e] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+}
+
+// Block-level reduction: column sums over the block's rows (optionally accumulated to per-channel
+// outputs) and weighted group sums accumulated into global fp64 (2 values per (b, group)).
+__device__ __forceinline__ void gn_block_reduce(const GNParams& p, const GNCtx& c, float colA[8], float colB[8],
+                                                const float w[8], float* chanA, float* chanB, double* gsums) {
+    __shared__ float smA[2048];
+    __shared__ float smB[2048];
+    __shared__ float smG[16];
+    const int tid = threadIdx.x;
+    if (tid < 16) smG[tid] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        smA[(c.ty * p.CV + c.tx) * 8 + e] = colA[e];
+        smB[(c.ty * p.CV + c.tx) * 8 + e] = colB[e];
+    }
+    __syncthreads();
+    if (c.ty == 0 && c.col_ok) {
+        for (int r = 1; r < c.RL; ++r) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                colA[e] += smA[(r * p.CV + c.tx) * 8 + e];
+                colB[e] += smB[(r * p.CV + c.tx) * 8 + e];
+            }
+        }
+        if (chanA) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                atomicAdd(chanA + c.c0 + e, colA[e]);
+                atomicAdd(chanB + c.c0 + e, colB[e]);
+            }
+        }
+        int gprev = c.c0 / p.Cg;
+        float ga = 0.f, gb = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int g = (c.c0 + e) / p.Cg;
+            if (g != gprev) {
+                atomicAdd(&smG[gprev * 2], ga);
+                atomicAdd(&smG[gprev * 2 + 1], gb);
+                ga = 0.f; gb = 0.f; gprev = g;
+            }
+            ga += w[e] * colA[e];
+            gb += w[e] * colB[e];
+        }
+        atomicAdd(&smG[gprev * 2], ga);
+        atomicAdd(&smG[gprev * 2 + 1], gb);
+    }
+    __syncthreads();
+    if (tid < p.G * 2) {
+        // only groups that intersect this block's columns carry non-zero sums
+        const float v = smG[tid];
+        if (v != 0.f) atomicAdd(&gsums[(long)c.b * p.G * 2 + tid], (double)v);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
+    const GNCtx c = gn_ctx(p);
+    float a[8], s[8], w[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; s[e] = 0.f; w[e] = 1.f; }
+    if (c.col_ok) {
+        const T* y = reinterpret_cast<const T*>(p.y);
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+            float v[8];
+            load8(y + ((long)c.b * p.T + t) * p.ldy + c.c0, v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a[e] += v[e]; s[e] += v[e] * v[e]; }
+        }
+    }
+    gn_block_reduce(p, c, a, s, w, nullptr, nullptr, p.sums);
+}
+
+__device__ __forceinline__ float act_apply(int act, float z) {
+    return act == 1 ? gelu_f(z) : (act == 2 ? tanhf(z) : z);
+}
+
+// out = [res + rscale *] act(gn(y))
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
+    const GNCtx c = gn_ctx(p);
+    if (!c.col_ok) return;
+    float mean[8], rstd[8], ka[8], kb[8];
+    gn_consts(p, c, mean, rstd);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float g = p.gamma[c.c0 + e];
+        ka[e] = rstd[e] * g;
+        kb[e] = p.beta[c.c0 + e] - mean[e] * rstd[e] * g;
+    }
+    const T* y = reinterpret_cast<const T*>(p.y);
+    const T* res = reinterpret_cast<const T*>(p.res);
+    T* out = reinterpret_cast<T*>(p.out);
+    for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+        const long m = (long)c.b * p.T + t;
+        float v[8], r[8];
+        load8(y + m * p.ldy + c.c0, v);
+        if (res) load8(res + m * p.ldres + c.c0, r);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float f = act_apply(ACT, v[e] * ka[e] + kb[e]);
+            v[e] = res ? r[e] + p.rscale * f : f;
+        }
+        store8(out + m * p.ldout + c.c0, v);
+    }
+}
+
+// d(loss)/d(xhat) for the selected reconstruction loss, unit weight (mean reduction folded by caller)
+__device__ __forceinline__ float loss_grad(int lt, float d) {
+    if (lt == 0) return 2.f * d;
+    if (lt == 1) return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    return fabsf(d) < 1.f ? d : (d > 0.f ? 1.f : -1.f);
+}
+__device__ __forceinline__ float loss_val(int lt, float d) {
+    if (lt == 0) return d * d;
+    if (lt == 1) return fabsf(d);
+    const float a = fabsf(d);
+    return a < 1.f ? 0.5f * d * d : a - 0.5f;
+}
+
+// Backward reduction pass.  dz = dOut * act'(z) with dOut either a stored gradient (times p.rscale)
+// or, FROM_LOSS, the unit-weight loss gradient of tanh(z) vs the target p.dout (= input x).
+//   column sums  A_c = sum dz, B_c = sum dz*xhat  -> dbeta, dgamma (per channel)
+//   group sums   s1 = sum gamma*dz, s2 = sum gamma*dz*xhat -> p.sums2
+// FROM_LOSS also accumulates the loss sums (p.loss_sums[0] selected, [1] squared error) and can
+// write xhat.
+template <typename T, int ACT, bool FROM_LOSS, bool TRAIN>
+__global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
+    const GNCtx c = gn_ctx(p);
+    float A[8], Bc[8], gam[8];
+    float lsel = 0.f, lsq = 0.f;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { A[e] = 0.f; Bc[e] = 0.f; gam[e] = 0.f; }
+    if (c.col_ok) {
+        float mean[8], rstd[8], bet[8];
+        gn_consts(p, c, mean, rstd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c.c0 + e]; bet[e] = p.beta[c.c0 + e]; }
+        const T* y = reinterpret_cast<const T*>(p.y);
+        const T* dout = reinterpret_cast<const T*>(p.dout);
+        T* xo = reinterpret_cast<T*>(p.out);
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+            const long m = (long)c.b * p.T + t;
+            float v[8], d[8];
+            load8(y + m * p.ldy + c.c0, v);
+            load8(dout + m * p.lddout + c.c0, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (v[e] - mean[e]) * rstd[e];
+                const float z = xh * gam[e] + bet[e];
+                float dz;
+                if constexpr (FROM_LOSS) {
+                    const float o = tanhf(z);
+                    const float df = o - d[e];
+                    lsel += loss_val(p.loss_type, df);
+                    lsq += df * df;
+                    dz = loss_grad(p.loss_type, df) * (1.f - o * o);
+                    v[e] = o;
+                } else {
+                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
+                }
+                A[e] += dz;
+                Bc[e] += dz * xh;
+            }
+            if constexpr (FROM_LOSS) {
+                if (xo) store8(xo + m * p.ldout + c.c0, v);
+            }
+        }
+    }
+    if constexpr (FROM_LOSS) {
+        __shared__ float sml[8];
+        const float a = wave_sum(lsel), b2 = wave_sum(lsq);
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) { sml[wv * 2] = a; sml[wv * 2 + 1] = b2; }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            atomicAdd(&p.loss_sums[0], (double)(sml[0] + sml[2] + sml[4] + sml[6]));
+            atomicAdd(&p.loss_sums[1], (double)(sml[1] + sml[3] + sml[5] + sml[7]));
+        }
+    }
+    if constexpr (TRAIN) gn_block_reduce(p, c, A, Bc, gam, p.dbeta, p.dgamma, p.sums2);
+}
+
+// dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]; optional bias-grad column sums of dY.
+template <typename T, int ACT, bool FROM_LOSS>
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
+    const GNCtx c = gn_ctx(p);
+    float colD[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) colD[e] = 0.f;
+    if (c.col_ok) {
+        float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8];
+        gn_consts(p, c, mean, rstd);
+        const double n = (double)p.Cg * (double)p.T;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            gam[e] = p.gamma[c.c0 + e];
+            bet[e] = p.beta[c.c0 + e];
+            const int g = (c.c0 + e) / p.Cg;
+            m1[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
+            m2[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
+        }
+        const T* y = reinterpret_cast<const T*>(p.y);
+        const T* dout = reinterpret_cast<const T*>(p.dout);
+        T* dy = reinterpret_cast<T*>(p.out);
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+            const long m = (long)c.b * p.T + t;
+            float v[8], d[8];
+            load8(y + m * p.ldy + c.c0, v);
+            load8(dout + m * p.lddout + c.c0, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (v[e] - mean[e]) * rstd[e];
+                const float z = xh * gam[e] + bet[e];
+                float dz;
+                if constexpr (FROM_LOSS) {
+                    const float o = tanhf(z);
+                    dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
+                } else {
+                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
+                }
+                const float r = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
+                v[e] = r;
+                colD[e] += r;
+            }
+            store8(dy + m * p.ldout + c.c0, v);
+        }
+    }
+    if (p.dbias) {
+        __shared__ float smA[2048];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) smA[(c.ty * p.CV + c.tx) * 8 + e] = colD[e];
+        __syncthreads();
+        if (c.ty == 0 && c.col_ok) {
+            for (int r = 1; r < c.RL; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) colD[e] += smA[(r * p.CV + c.tx) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(p.dbias + c.c0 + e, colD[e]);
+        }
+    }
+}
+
+// activation without GroupNorm: MODE 0: out = gelu(y); MODE 1: out = dout*rscale*gelu'(y) (+ colsum -> dbias)
+//                               MODE 2: column sums of y only (-> dbias)
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void act_kernel(const GNParams p) {
+    const GNCtx c = gn_ctx(p);
+    float colD[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) colD[e] = 0.f;
+    if (c.col_ok) {
+        const T* y = reinterpret_cast<const T*>(p.y);
+        const T* dout = reinterpret_cast<const T*>(p.dout);
+        T* out = reinterpret_cast<T*>(p.out);
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+            const long m = (long)c.b * p.T + t;
+            float v[8], d[8];
+            load8(y + m * p.ldy + c.c0, v);
+            if constexpr (MODE == 1) load8(dout + m * p.lddout + c.c0, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                if constexpr (MODE == 0) v[e] = gelu_f(v[e]);
+                else if constexpr (MODE == 1) { v[e] = d[e] * p.rscale * gelu_grad_f(v[e]); }
+                colD[e] += v[e];
+            }
+            if constexpr (MODE != 2) store8(out + m * p.ldout + c.c0, v);
+        }
+    }
+    if (MODE != 0 && p.dbias) {
+        __shared__ float smA[2048];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) smA[(c.ty * p.CV + c.tx) * 8 + e] = colD[e];
+        __syncthreads();
+        if (c.ty == 0 && c.col_ok) {
+            for (int r = 1; r < c.RL; ++r)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) colD[e] += smA[(r * p.CV + c.tx) * 8 + e];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) atomicAdd(p.dbias + c.c0 + e, colD[e]);
+        }
+    }
+}
+
+template <typename T>
+static void gn_dispatch_fill(GNParams& p, int B, int T_, int C) {
+    GNGeom g = gn_geom(B, T_, C);
+    p.CV = g.CV;
+}
+
+#define GN_LAUNCH(KERN, P, S)                                              \
+    do {                                                                   \
+        GNGeom g_ = gn_geom((P).B, (P).T, (P).C);                          \
+        (P).CV = g_.CV;                                                    \
+        hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P);             \
+    } while (0)
+
+int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
+    if (dtype == 1) GN_LAUNCH((gn_stats_kernel<bf16_t>), p, s);
+    else GN_LAUNCH((gn_stats_kernel<float>), p, s);
+    return 0;
+}
+int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s) {
+    if (dtype == 1) {
+        if (act == 1) GN_LAUNCH((gn_apply_kernel<bf16_t, 1>), p, s);
+        else if (act == 2) GN_LAUNCH((gn_apply_kernel<bf16_t, 2>), p, s);
+        else GN_LAUNCH((gn_apply_kernel<bf16_t, 0>), p, s);
+    } else {
+        if (act == 1) GN_LAUNCH((gn_apply_kernel<float, 1>), p, s);
+        else if (act == 2) GN_LAUNCH((gn_apply_kernel<float, 2>), p, s);
+        else GN_LAUNCH((gn_apply_kernel<float, 0>), p, s);
+    }
+    return 0;
+}
+int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s) {   // gelu, stored gradient
+    if (dtype == 1) GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);
+    else GN_LAUNCH((gn_bwd_reduce_kernel<float, 1, false, true>), p, s);
+    return 0;
+}
+int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s) {
+    if (dtype == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 1, false>), p, s);
+    else GN_LAUNCH((gn_bwd_apply_kernel<float, 1, false>), p, s);
+    return 0;
+}
+int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + loss (+ bwd reduce)
+    if (dtype == 1) {
+        if (train) GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, true>), p, s);
+        else GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, false>), p, s);
+    } else {
+        if (train) GN_LAUNCH((gn_bwd_reduce_kernel<float, 2, true, true>), p, s);
+        else GN_LAUNCH((gn_bwd_reduce_kernel<float, 2, true, false>), p, s);
+    }
+    return 0;
+}
+int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s) {
+    if (dtype == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true>), p, s);
+    else GN_LAUNCH((gn_bwd_apply_kernel<float, 2, true>), p, s);
+    return 0;
+}
+int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
+    if (dtype == 1) {
+        if (mode == 0) GN_LAUNCH((act_kernel<bf16_t, 0>), p, s);
+        else if (mode == 1) GN_LAUNCH((act_kernel<bf16_t, 1>), p, s);
+        else GN_LAUNCH((act_kernel<bf16_t, 2>), p, s);
+    } else {
+        if (mode == 0) GN_LAUNCH((act_kernel<float, 0>), p, s);
+        else if (mode == 1) GN_LAUNCH((act_kernel<float, 1>), p, s);
+        else GN_LAUNCH((act_kernel<float, 2>), p, s);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// strided elementwise helpers on [rows][C] maps (C % 8 == 0)
+// ------------------------------------------------------------------------------------------
+// out = a (+ b) (+ c): any of b, c may be null; all same dtype T
+template <typename T>
+__global__ __launch_bounds__(256) void add3_kernel(const T* a, long lda, const T* b, long ldb, const T* c, long ldc,
+                                                  T* out, long ldo, int rows, int C) {
+    const int nv = C / 8;
+    const long total = (long)rows * nv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / nv), cv = (int)(i - (long)r * nv);
+        float v[8], w[8];
+        load8(a + (long)r * lda + cv * 8, v);
+        if (b) { load8(b + (long)r * ldb + cv * 8, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += w[e]; }
+        if (c) { load8(c + (long)r * ldc + cv * 8, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) v[e] += w[e]; }
+        store8(out + (long)r * ldo + cv * 8, v);
+    }
+}
+int ew_add3(int dtype, const void* a, long lda, const void* b, long ldb, const void* c, long ldc, void* out, long ldo,
+            int rows, int C, hipStream_t s) {
+    long total = (long)rows * (C / 8);
+    int blocks = cdiv_i(total, 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    if (dtype == 1)
+        hipLaunchKernelGGL((add3_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)a, lda, (const bf16_t*)b, ldb,
+                           (const bf16_t*)c, ldc, (bf16_t*)out, ldo, rows, C);
+    else
+        hipLaunchKernelGGL((add3_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)a, lda, (const float*)b, ldb,
+                           (const float*)c, ldc, (float*)out, ldo, rows, C);
+    return 0;
+}
+
+// batched transpose with cast: dst[b][j][i] = src[b][i][j]   (src rows I, cols J contiguous)
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void transpose_kernel(const TI* src, TO* dst, int I, int J, long lds_, long ldd,
+                                                        long sbatch, long dbatch) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int r = ty; r < 32; r += 8) {
+        const int i = i0 + r, j = j0 + tx;
+        tile[r][tx] = (i < I && j < J) ? to_f32(src[(long)b * sbatch + (long)i * lds_ + j]) : 0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 32; r += 8) {
+        const int j = j0 + r, i = i0 + tx;
+        if (i < I && j < J) dst[(long)b * dbatch + (long)j * ldd + i] = from_f32<TO>(tile[tx][r]);
+    }
+}
+int ew_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, long lds_, long ldd,
+                 long sbatch, long dbatch, hipStream_t s) {
+    dim3 grid(cdiv_i(J, 32), cdiv_i(I, 32), Bn);
+    if (src_dtype == 0 && dst_dtype == 0)
+        hipLaunchKernelGGL((transpose_kernel<float, float>), grid, dim3(256), 0, s, (const float*)src, (float*)dst, I, J, lds_, ldd, sbatch, dbatch);
+    else if (src_dtype == 0 && dst_dtype == 1)
+        hipLaunchKernelGGL((transpose_kernel<float, bf16_t>), grid, dim3(256), 0, s, (const float*)src, (bf16_t*)dst, I, J, lds_, ldd, sbatch, dbatch);
+    else if (src_dtype == 1 && dst_dtype == 0)
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, float>), grid, dim3(256), 0, s, (const bf16_t*)src, (float*)dst, I, J, lds_, ldd, sbatch, dbatch);
+    else
+        hipLaunchKernelGGL((transpose_kernel<bf16_t, bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)src, (bf16_t*)dst, I, J, lds_, ldd, sbatch, dbatch);
+    return 0;
+}
+
+// standard normals into an fp32 buffer (Philox keyed by seed/stream; element i <- block i/4)
+__global__ __launch_bounds__(256) void randn_kernel(float* out, long n, uint64_t seed, uint64_t stream) {
+    const long n4 = (n + 3) / 4;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        float r[4];
+        philox_normal4(seed, stream, (uint64_t)i, r);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (i * 4 + e < n) out[i * 4 + e] = r[e];
+    }
+}
+int ew_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t s) {
+    int blocks = cdiv_i((n + 3) / 4, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(randn_kernel, dim3(blocks), dim3(256), 0, s, out, n, seed, stream);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// latent reparameterisation + KL (tiny, fp32): last = [mu | logvar] per row
+// ------------------------------------------------------------------------------------------
+__global__ void latent_fwd_kernel(const float* last, const float* eps, float* z, int B, int Z, double* kl_sum) {
+    float acc = 0.f;
+    for (int i = threadIdx.x; i < B * Z; i += blockDim.x) {
+        const int b = i / Z, d = i - b * Z;
+        const float mu = last[b * 2 * Z + d], lv = last[b * 2 * Z + Z + d];
+        const float lvc = fminf(fmaxf(lv, -30.f), 30.f);
+        const float sd = fminf(fmaxf(expf(0.5f * lvc), 1e-8f), 10.f);
+        z[i] = mu + eps[i] * sd;
+        acc += 0.5f * (mu * mu + expf(lvc) - lvc - 1.f);
+    }
+    __shared__ float sm[16];
+    const float w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f;
+        for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm[i];
+        kl_sum[0] = (double)t / B;   // mean over batch (losses.py:32)
+    }
+}
+// dlast = [dz + coef*mu | dz*eps*0.5*std*[in range] + coef*0.5*(e^lv - 1)*[in range]], coef = beta/B
+__global__ void latent_bwd_kernel(const float* last, const float* eps, const float* dz, float* dlast, int B, int Z,
+                                  float coef) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < B * Z; i += gridDim.x * blockDim.x) {
+        const int b = i / Z, d = i - b * Z;
+        const float mu = last[b * 2 * Z + d], lv = last[b * 2 * Z + Z + d];
+        const bool inr = (lv >= -30.f) && (lv <= 30.f);
+        const float lvc = fminf(fmaxf(lv, -30.f), 30.f);
+        const float sd = expf(0.5f * lvc);
+        const bool ins = (sd >= 1e-8f) && (sd <= 10.f);
+        const float g = dz[i];
+        dlast[b * 2 * Z + d] = g + coef * mu;
+        float glv = 0.f;
+        if (inr) glv = (ins ? g * eps[i] * 0.5f * sd : 0.f) + coef * 0.5f * (expf(lvc) - 1.f);
+        dlast[b * 2 * Z + Z + d] = glv;
+    }
+}
+int ew_latent_fwd(const float* last, const float* eps, float* z, int B, int Z, double* kl_sum, hipStream_t s) {
+    hipLaunchKernelGGL(latent_fwd_kernel, dim3(1), dim3(256), 0, s, last, eps, z, B, Z, kl_sum);
+    return 0;
+}
+int ew_latent_bwd(const float* last, const float* eps, const float* dz, float* dlast, int B, int Z, float coef,
+                  hipStream_t s) {
+    hipLaunchKernelGGL(latent_bwd_kernel, dim3(cdiv_i((long)B * Z, 256)), dim3(256), 0, s, last, eps, dz, dlast, B, Z, coef);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// decoder stage: posterior/prior combination, kl_2, reparameterisation  (decoder.py:187-212)
+//   pz = [mu | lv], qz = [dmu | dlv] fp32 [M][2C]; eps fp32 [M][C]
+//   zs_next = dec_out + (mu+dmu) + eps*clamp(exp(.5*clamp(lv+dlv))*std_scale)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void stage_fwd_kernel(const float* pz, const float* qz, const float* eps,
+                                                       const T* dec_out, long ldd, T* zs_next, long ldz, float* zmap,
+                                                       int M, int C, float std_scale, double* kl_sum, float inv_b) {
+    const long total = (long)M * C;
+    float acc = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        const float mu = pz[(long)m * 2 * C + c], lv = pz[(long)m * 2 * C + C + c];
+        const float dmu = qz[(long)m * 2 * C + c], dlv = qz[(long)m * 2 * C + C + c];
+        const float lvc = fminf(fmaxf(lv, -30.f), 30.f), dlvc = fminf(fmaxf(dlv, -30.f), 30.f);
+        const float var = expf(lvc) + 1e-8f, dvar = expf(dlvc);
+        const float df = mu - dmu;
+        acc += 0.5f * (dvar / var + df * df / var - dlvc + lvc - 1.f);
+        const float lv2 = fminf(fmaxf(lv + dlv, -30.f), 30.f);
+        const float sd = fminf(fmaxf(expf(0.5f * lv2) * std_scale, 1e-8f), 10.f);
+        const float z = (mu + dmu) + eps[i] * sd;
+        if (zmap) zmap[i] = z;
+        zs_next[(long)m * ldz + c] = from_f32<T>(to_f32(dec_out[(long)m * ldd + c]) + z);
+    }
+    __shared__ float sm[4];
+    const float w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(kl_sum, (double)(sm[0] + sm[1] + sm[2] + sm[3]) * (double)inv_b);
+}
+// gradients wrt the prior output pz (g_p) and posterior output qz (g_q); coef = beta/B
+template <typename T>
+__global__ __launch_bounds__(256) void stage_bwd_kernel(const float* pz, const float* qz, const float* eps, const T* dzs,
+                                                       long ldd, T* g_p, T* g_q, int M, int C, float coef) {
+    const long total = (long)M * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int m = (int)(i / C), c = (int)(i - (long)m * C);
+        const float mu = pz[(long)m * 2 * C + c], lv = pz[(long)m * 2 * C + C + c];
+        const float dmu = qz[(long)m * 2 * C + c], dlv = qz[(long)m * 2 * C + C + c];
+        const bool in1 = (lv >= -30.f) && (lv <= 30.f), in2 = (dlv >= -30.f) && (dlv <= 30.f);
+        const float lvc = fminf(fmaxf(lv, -30.f), 30.f), dlvc = fminf(fmaxf(dlv, -30.f), 30.f);
+        const float ev = expf(lvc), var = ev + 1e-8f, dvar = expf(dlvc);
+        const float df = mu - dmu;
+        const float sc = 0.5f * coef;
+        const float k_dmu = sc * (-2.f * df / var);
+        const float k_mu = -k_dmu;
+        const float k_dlv = in2 ? sc * (dvar / var - 1.f) : 0.f;
+        const float k_lv = in1 ? sc * (-(dvar + df * df) / (var * var) * ev + 1.f) : 0.f;
+        // reparameterisation (training mode: std_scale = 1)
+        const float s2 = lv + dlv;
+        const bool in3 = (s2 >= -30.f) && (s2 <= 30.f);
+        const float sd = expf(0.5f * fminf(fmaxf(s2, -30.f), 30.f));
+        const bool ins = (sd >= 1e-8f) && (sd <= 10.f);
+        const float g = to_f32(dzs[(long)m * ldd + c]);
+        const float g_lv2 = (in3 && ins) ? g * eps[i] * 0.5f * sd : 0.f;
+        g_p[(long)m * 2 * C + c] = from_f32<T>(g + k_mu);
+        g_p[(long)m * 2 * C + C + c] = from_f32<T>(g_lv2 + k_lv);
+        g_q[(long)m * 2 * C + c] = from_f32<T>(g + k_dmu);
+        g_q[(long)m * 2 * C + C + c] = from_f32<T>(g_lv2 + k_dlv);
+    }
+}
+int ew_stage_fwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dec_out, long ldd,
+                 void* zs_next, long ldz, float* zmap, int M, int C, float std_scale, double* kl_sum, float inv_b,
+                 hipStream_t s) {
+    int blocks = cdiv_i((long)M * C, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (dtype == 1)
+        hipLaunchKernelGGL((stage_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, pz, qz, eps, (const bf16_t*)dec_out, ldd,
+                           (bf16_t*)zs_next, ldz, zmap, M, C, std_scale, kl_sum, inv_b);
+    else
+        hipLaunchKernelGGL((stage_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, pz, qz, eps, (const float*)dec_out, ldd,
+                           (float*)zs_next, ldz, zmap, M, C, std_scale, kl_sum, inv_b);
+    return 0;
+}
+int ew_stage_bwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dzs, long ldd, void* g_p,
+                 void* g_q, int M, int C, float coef, hipStream_t s) {
+    int blocks = cdiv_i((long)M * C, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (dtype == 1)
+        hipLaunchKernelGGL((stage_bwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, pz, qz, eps, (const bf16_t*)dzs, ldd,
+                           (bf16_t*)g_p, (bf16_t*)g_q, M, C, coef);
+    else
+        hipLaunchKernelGGL((stage_bwd_kernel<float>), dim3(blocks), dim3(256), 0, s, pz, qz, eps, (const float*)dzs, ldd,
+                           (float*)g_p, (float*)g_q, M, C, coef);
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// small Linear layers (fp32 master weights, scale = 1/sigma from the spectral-norm pass)
+// ------------------------------------------------------------------------------------------
+// "head": Y[b][o] (fp32, pre-zeroed) += scale * sum_k X[b][k] W[o][k]  (+ bias once); K large, O small
+template <typename TX>
+__global__ __launch_bounds__(256) void linear_head_fwd_kernel(const TX* X, const float* W, const float* bias,
+                                                             const float* scale, float* Y, int B, int K, int O) {
+    const int o = blockIdx.x;
+    const int ks = gridDim.y, kz = blockIdx.y;
+    const int nv = K / 8;
+    const int v_lo = (int)((long)nv * kz / ks), v_hi = (int)((long)nv * (kz + 1) / ks);
+    const float sc = scale ? *scale : 1.f;
+    __shared__ float sm[4];
+    for (int b0 = 0; b0 < B; b0 += 4) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (int v = v_lo + threadIdx.x; v < v_hi; v += 256) {
+            float w[8];
+            load8(W + (long)o * K + v * 8, w);
+#pragma unroll
+            for (int bb = 0; bb < 4; ++bb) {
+                if (b0 + bb < B) {
+                    float x[8];
+                    load8(X + (long)(b0 + bb) * K + v * 8, x);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[bb] += w[e] * x[e];
+                }
+            }
+        }
+#pragma unroll
+        for (int bb = 0; bb < 4; ++bb) {
+            const float wsum = wave_sum(acc[bb]);
+            __syncthreads();
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = wsum;
+            __syncthreads();
+            if (threadIdx.x == 0 && b0 + bb < B) {
+                float t = (sm[0] + sm[1] + sm[2] + sm[3]) * sc;
+                if (kz == 0 && bias) t += bias[o];
+                atomicAdd(&Y[(long)(b0 + bb) * O + o], t);
+            }
+        }
+    }
+}
+// dX[b][k] = scale * sum_o dY[b][o] W[o][k] (+ addend[b][k]); output TX
+template <typename TX>
+__global__ __launch_bounds__(256) void linear_head_bwd_dx_kernel(const float* dY, const float* W, const float* scale,
+                                                                const TX* addend, TX* dX, int B, int K, int O) {
+    const int nv = K / 8;
+    const float sc = scale ? *scale : 1.f;
+    const long total = (long)B * nv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / nv), v = (int)(i - (long)b * nv);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int o = 0; o < O; ++o) {
+            const float g = dY[(long)b * O + o];
+            float w[8];
+            load8(W + (long)o * K + v * 8, w);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += g * w[e];
+        }
+        float a[8];
+        if (addend) load8(addend + (long)b * K + v * 8, a);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = acc[e] * sc + (addend ? a[e] : 0.f);
+        store8(dX + (long)b * K + v * 8, acc);
+    }
+}
+// dW[o][k] = sum_b dY[b][o] X[b][k]  (plain store); db[o] = sum_b dY[b][o]
+template <typename TX>
+__global__ __launch_bounds__(256) void linear_head_bwd_dw_kernel(const float* dY, const TX* X, float* dW, float* db, int B,
+                                                                int K, int O) {
+    const int nv = K / 8;
+    const long total = (long)O * nv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int o = (int)(i / nv), v = (int)(i - (long)o * nv);
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int b = 0; b < B; ++b) {
+            const float g = dY[(long)b * O + o];
+            float x[8];
+            load8(X + (long)b * K + v * 8, x);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[e] += g * x[e];
+        }
+        store8(dW + (long)o * K + v * 8, acc);
+    }
+    if (db && blockIdx.x == 0) {
+        for (int o = threadIdx.x; o < O; o += 256) {
+            float t = 0.f;
+            for (int b = 0; b < B; ++b) t += dY[(long)b * O + o];
+            db[o] = t;
+        }
+    }
+}
+int ew_linear_head_fwd(int xdtype, const void* X, const float* W, const float* bias, const float* scale, float* Y, int B,
+                       int K, int O, hipStream_t s) {
+    hipMemsetAsync(Y, 0, sizeof(float) * (size_t)B * O, s);
+    int ks = cdiv_i(K / 8, 2048);
+    if (ks < 1) ks = 1;
+    if (ks > 64) ks = 64;
+    dim3 grid(O, ks);
+    if (xdtype == 1) hipLaunchKernelGGL((linear_head_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, W, bias, scale, Y, B, K, O);
+    else hipLaunchKernelGGL((linear_head_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)X, W, bias, scale, Y, B, K, O);
+    return 0;
+}
+int ew_linear_head_bwd(int xdtype, const float* dY, const void* X, const float* W, const float* scale, const void* addend,
+                       void* dX, float* dW, float* db, int B, int K, int O, hipStream_t s) {
+    int blocks = cdiv_i((long)B * (K / 8), 256);
+    if (blocks > 4096) blocks = 4096;
+    int blocks2 = cdiv_i((long)O * (K / 8), 256);
+    if (blocks2 > 4096) blocks2 = 4096;
+    if (xdtype == 1) {
+        if (dX) hipLaunchKernelGGL((linear_head_bwd_dx_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, dY, W, scale, (const bf16_t*)addend, (bf16_t*)dX, B, K, O);
+        if (dW) hipLaunchKernelGGL((linear_head_bwd_dw_kernel<bf16_t>), dim3(blocks2), dim3(256), 0, s, dY, (const bf16_t*)X, dW, db, B, K, O);
+    } else {
+        if (dX) hipLaunchKernelGGL((linear_head_bwd_dx_kernel<float>), dim3(blocks), dim3(256), 0, s, dY, W, scale, (const float*)addend, (float*)dX, B, K, O);
+        if (dW) hipLaunchKernelGGL((linear_head_bwd_dw_kernel<float>), dim3(blocks2), dim3(256), 0, s, dY, (const float*)X, dW, db, B, K, O);
+    }
+    return 0;
+}
+
+// "expand": Y[b][o] = scale * sum_k X[b][k] W[o][k] + bias[o]; K tiny (<= 64), O = T*C large; Y in T
+template <typename T>
+__global__ __launch_bounds__(256) void linear_expand_fwd_kernel(const float* X, const float* W, const float* bias,
+                                                               const float* scale, T* Y, int B, int K, int O) {
+    const float sc = scale ? *scale : 1.f;
+    const long total = (long)B * O;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / O), o = (int)(i - (long)b * O);
+        float acc = 0.f;
+        for (int k = 0; k < K; ++k) acc += X[b * K + k] * W[(long)o * K + k];
+        Y[i] = from_f32<T>(acc * sc + bias[o]);
+    }
+}
+// dW[o][k] = sum_b dY[b][o] X[b][k]; db[o] = sum_b dY[b][o]
+template <typename T>
+__global__ __launch_bounds__(256) void linear_expand_bwd_dw_kernel(const T* dY, const float* X, float* dW, float* db, int B,
+                                                                  int K, int O) {
+    const long total = (long)O * K;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int o = (int)(i / K), k = (int)(i - (long)o * K);
+        float acc = 0.f, accb = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float g = to_f32(dY[(long)b * O + o]);
+            acc += g * X[b * K + k];
+            accb += g;
+        }
+        dW[i] = acc;
+        if (k == 0) db[o] = accb;
+    }
+}
+// dX[b][k] = scale * sum_o dY[b][o] W[o][k]   (one block per (b,k))
+template <typename T>
+__global__ __launch_bounds__(256) void linear_expand_bwd_dx_kernel(const T* dY, const float* W, const float* scale,
+                                                                  float* dX, int B, int K, int O) {
+    const int b = blockIdx.x / K, k = blockIdx.x - b * K;
+    float acc = 0.f;
+    for (int o = threadIdx.x; o < O; o += 256) acc += to_f32(dY[(long)b * O + o]) * W[(long)o * K + k];
+    __shared__ float sm[4];
+    const float w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) dX[b * K + k] = (sm[0] + sm[1] + sm[2] + sm[3]) * (scale ? *scale : 1.f);
+}
+int ew_linear_expand_fwd(int dtype, const float* X, const float* W, const float* bias, const float* scale, void* Y, int B,
+                         int K, int O, hipStream_t s) {
+    int blocks = cdiv_i((long)B * O, 256);
+    if (dtype == 1) hipLaunchKernelGGL((linear_expand_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, X, W, bias, scale, (bf16_t*)Y, B, K, O);
+    else hipLaunchKernelGGL((linear_expand_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, X, W, bias, scale, (float*)Y, B, K, O);
+    return 0;
+}
+int ew_linear_expand_bwd(int dtype, const void* dY, const float* X, const float* W, const float* scale, float* dX, float* dW,
+                         float* db, int B, int K, int O, hipStream_t s) {
+    int blocks = cdiv_i((long)O * K, 256);
+    if (dtype == 1) {
+        hipLaunchKernelGGL((linear_expand_bwd_dw_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, (const bf16_t*)dY, X, dW, db, B, K, O);
+        if (dX) hipLaunchKernelGGL((linear_expand_bwd_dx_kernel<bf16_t>), dim3(B * K), dim3(256), 0, s, (const bf16_t*)dY, W, scale, dX, B, K, O);
+    } else {
+        hipLaunchKernelGGL((linear_expand_bwd_dw_kernel<float>), dim3(blocks), dim3(256), 0, s, (const float*)dY, X, dW, db, B, K, O);
+        if (dX) hipLaunchKernelGGL((linear_expand_bwd_dx_kernel<float>), dim3(B * K), dim3(256), 0, s, (const float*)dY, W, scale, dX, B, K, O);
+    }
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// augmentation + collate on the HBM-resident dataset (internal layout [P][T][N], dtype T)
+//   out[b] = lam*(scale*(x[idx] + 0.05*noise)) + (1-lam)*x[mix]     (augmentation.py:58-124 order)
+// ------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void augment_kernel(const T* data, T* out, long sample_elems, const int* idx,
+                                                     const unsigned long long* noise_seed, const float* scale,
+                                                     const int* mix_idx, const float* lam) {
+    const int b = blockIdx.y;
+    const T* src = data + (long)idx[b] * sample_elems;
+    const int mi = mix_idx[b];
+    const T* oth = mi >= 0 ? data + (long)mi * sample_elems : nullptr;
+    const unsigned long long ns = noise_seed[b];
+    const float sc = scale[b], lm = lam[b];
+    T* dst = out + (long)b * sample_elems;
+    const long nv = sample_elems / 8;
+    for (long v = (long)blockIdx.x * 256 + threadIdx.x; v < nv; v += (long)gridDim.x * 256) {
+        float x[8];
+        load8(src + v * 8, x);
+        if (ns) {
+            float n0[4], n1[4];
+            philox_normal4(ns, 0x41554721ull, (uint64_t)(v * 2), n0);
+            philox_normal4(ns, 0x41554721ull, (uint64_t)(v * 2 + 1), n1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { x[e] += 0.05f * n0[e]; x[e + 4] += 0.05f * n1[e]; }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] *= sc;
+        if (oth) {
+            float o[8];
+            load8(oth + v * 8, o);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) x[e] = lm * x[e] + (1.f - lm) * o[e];
+        }
+        store8(dst + v * 8, x);
+    }
+}
+int ew_augment(int dtype, const void* data, void* out, long sample_elems, int batch, const int* idx,
+               const unsigned long long* noise_seed, const float* scale, const int* mix_idx, const float* lam, hipStream_t s) {
+    int bx = cdiv_i(sample_elems / 8, 256);
+    if (bx > 512) bx = 512;
+    dim3 grid(bx, batch);
+    if (dtype == 1) hipLaunchKernelGGL((augment_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)data, (bf16_t*)out, sample_elems, idx, noise_seed, scale, mix_idx, lam);
+    else hipLaunchKernelGGL((augment_kernel<float>), grid, dim3(256), 0, s, (const float*)data, (float*)out, sample_elems, idx, noise_seed, scale, mix_idx, lam);
+    return 0;
+}
+
+// y[i] += a * x[i]  (fp32, small arrays)
+__global__ void axpy_kernel(float* y, const float* x, float a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s) {
+    int blocks = cdiv_i(n, 256);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(axpy_kernel, dim3(blocks), dim3(256), 0, s, y, x, a, n);
+    return 0;
+}
+__global__ void scale_kernel(float* y, float a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] *= a;
+}
+int ew_scale(float* y, float a, long n, hipStream_t s) {
+    int blocks = cdiv_i(n, 256);
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(scale_kernel, dim3(blocks), dim3(256), 0, s, y, a, n);
+    return 0;
+}
+// cast fp32 [rows][C] -> T [rows][ld]
+template <typename T>
+__global__ void cast_rows_kernel(const float* src, long lds_, T* dst, long ldd, int rows, int C) {
+    const long total = (long)rows * C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / C), c = (int)(i - (long)r * C);
+        dst[(long)r * ldd + c] = from_f32<T>(src[(long)r * lds_ + c]);
+    }
+}
+int ew_cast_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int C, hipStream_t s) {
+    int blocks = cdiv_i((long)rows * C, 256);
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    if (dtype == 1) hipLaunchKernelGGL((cast_rows_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, src, lds_, (bf16_t*)dst, ldd, rows, C);
+    else hipLaunchKernelGGL((cast_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, src, lds_, (float*)dst, ldd, rows, C);
+    return 0;
+}

@@ -1,0 +1,246 @@
+// Multi-tensor HBM-bound passes over the fp32 master weights (gfx950):
+//  * legacy spectral-norm power iteration (torch nn/utils/spectral_norm.py compute_weight, applied by
+//    reference modules/common.py:15-37): v <- norm(W^T u), u <- norm(W v), sigma = u.(W v)
+//  * <G, W> per weight for the spectral-norm chain rule, fused AdamW (torch.optim.AdamW defaults,
+//    reference modules/train.py:92,168) + gradient 2-norm (modules/train.py:156-161)
+//  * compute-dtype weight copies in both GEMM layouts.
+// Every pass is ONE launch over a work-item table (desc, chunk) covering all tensors.
+// Weights are [taps][rows][cols] fp32 (cols contiguous); u is [rows], v is [taps*cols].
+#include "sgv_ew.h"
+
+// ---- pass 1: tmp_t[tap][c] += sum_r W[tap][r][c] * u[r] over a 64-row x 1024-col block ----------
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const SNDesc* descs, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const SNDesc d = descs[it.desc];
+    const int cb = (d.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
+    const int rb = (d.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM;
+    const int tap = it.chunk / (rb * cb);
+    const int rem = it.chunk - tap * rb * cb;
+    const int r_lo = (rem / cb) * SN_ROWS_PER_ITEM, c = (rem % cb) * SN_COLS_PER_ITEM + threadIdx.x * 4;
+    if (c >= d.cols) return;
+    const int r_hi = min(d.rows, r_lo + SN_ROWS_PER_ITEM);
+    const float* W = d.W + ((long)tap * d.rows) * d.cols + c;
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int r = r_lo; r < r_hi; ++r) {
+        const float4 w = *reinterpret_cast<const float4*>(W + (long)r * d.cols);
+        const float ur = d.u[r];
+        a0 += w.x * ur; a1 += w.y * ur; a2 += w.z * ur; a3 += w.w * ur;
+    }
+    float* t = d.tmp_t + (long)tap * d.cols + c;
+    atomicAdd(t + 0, a0); atomicAdd(t + 1, a1); atomicAdd(t + 2, a2); atomicAdd(t + 3, a3);
+}
+
+// ---- pass 2: v = t / max(||t||, 1e-12) ------------------------------------------------------------
+__global__ __launch_bounds__(1024) void sn_norm_v_kernel(const SNDesc* descs, int ndesc) {
+    const SNDesc d = descs[blockIdx.x];
+    if (!d.active) return;
+    const long n = (long)d.taps * d.cols;
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 1024) { const double t = d.tmp_t[i]; acc += t * t; }
+    __shared__ double sm[16];
+    const double w = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < 16; ++i) tot += sm[i];
+    const float inv = 1.0f / fmaxf((float)sqrt(tot), 1e-12f);
+    for (long i = threadIdx.x; i < n; i += 1024) d.v[i] = d.tmp_t[i] * inv;
+}
+
+// ---- pass 3: tmp_s[r] += sum_c W[tap][r][c] * v[tap][c]; one wave per row ---------------------------
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const SNDesc d = descs[it.desc];
+    const int cb = (d.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
+    const int rb = (d.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM;
+    const int tap = it.chunk / (rb * cb);
+    const int rem = it.chunk - tap * rb * cb;
+    const int r_lo = (rem / cb) * SN_ROWS_PER_ITEM;
+    const int c_lo = (rem % cb) * SN_COLS_PER_ITEM;
+    const int c_hi = min(d.cols, c_lo + SN_COLS_PER_ITEM);
+    const int r_hi = min(d.rows, r_lo + SN_ROWS_PER_ITEM);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const float* vv = d.v + (long)tap * d.cols;
+    for (int r = r_lo + wave; r < r_hi; r += 4) {
+        const float* W = d.W + ((long)tap * d.rows + r) * d.cols;
+        float acc = 0.f;
+        for (int c = c_lo + lane * 4; c < c_hi; c += 256) {
+            const float4 w = *reinterpret_cast<const float4*>(W + c);
+            const float4 x = *reinterpret_cast<const float4*>(vv + c);
+            acc += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) atomicAdd(d.tmp_s + r, acc);
+    }
+}
+
+// ---- pass 4: u = s / max(||s||, 1e-12) (train), sigma = u . s ----------------------------------------
+__global__ __launch_bounds__(1024) void sn_norm_u_kernel(const SNDesc* descs, int train) {
+    const SNDesc d = descs[blockIdx.x];
+    if (!d.active) return;
+    __shared__ double sm[16];
+    double acc = 0.0;
+    if (train) {
+        for (int i = threadIdx.x; i < d.rows; i += 1024) { const double t = d.tmp_s[i]; acc += t * t; }
+    } else {
+        for (int i = threadIdx.x; i < d.rows; i += 1024) acc += (double)d.u[i] * (double)d.tmp_s[i];
+    }
+    const double w = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < 16; ++i) tot += sm[i];
+    float sigma;
+    if (train) {
+        const float nrm = fmaxf((float)sqrt(tot), 1e-12f);
+        const float inv = 1.0f / nrm;
+        for (int i = threadIdx.x; i < d.rows; i += 1024) d.u[i] = d.tmp_s[i] * inv;
+        sigma = (float)(tot / (double)nrm);   // u . s with u = s/nrm
+    } else {
+        sigma = (float)tot;
+    }
+    if (threadIdx.x == 0) { d.sigma[0] = sigma; d.sigma[1] = 1.0f / sigma; }
+}
+
+int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,
+                           int ndesc, int train, hipStream_t s) {
+    if (train) {
+        if (n1 > 0) hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n1), dim3(256), 0, s, descs_dev, items1);
+        hipLaunchKernelGGL(sn_norm_v_kernel, dim3(ndesc), dim3(1024), 0, s, descs_dev, ndesc);
+    }
+    if (n3 > 0) hipLaunchKernelGGL(sn_w_v_kernel, dim3(n3), dim3(256), 0, s, descs_dev, items3);
+    hipLaunchKernelGGL(sn_norm_u_kernel, dim3(ndesc), dim3(1024), 0, s, descs_dev, train);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- <G, W> per spectrally-normalised weight ---------------------------------------------------------
+__global__ __launch_bounds__(256) void sn_grad_dot_kernel(const SNDesc* descs, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const SNDesc d = descs[it.desc];
+    const long n = (long)d.taps * d.rows * d.cols;
+    const long lo = (long)it.chunk * OPT_CHUNK;
+    const long hi = min(n, lo + OPT_CHUNK);
+    float acc = 0.f;
+    for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+        const float4 g = *reinterpret_cast<const float4*>(d.G + i);
+        const float4 w = *reinterpret_cast<const float4*>(d.W + i);
+        acc += g.x * w.x + g.y * w.y + g.z * w.z + g.w * w.w;
+    }
+    __shared__ float sm[4];
+    const float w = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(d.dot, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+}
+int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(sn_grad_dot_kernel, dim3(n), dim3(256), 0, s, descs_dev, items);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- fused AdamW (+ spectral-norm chain rule, + grad norm) -------------------------------------------
+// g_orig = (G - <G,W_eff> u v^T) / sigma with <G,W_eff> = dot / sigma.
+template <bool UPDATE>
+__global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
+                                                   float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
+                                                   double* gnorm_sq) {
+    const WorkItem it = items[blockIdx.x];
+    const AdamDesc a = adam[it.desc];
+    const long lo = (long)it.chunk * OPT_CHUNK;
+    const long hi = min(a.n, lo + OPT_CHUNK);
+    float inv_sigma = 1.f, cdot = 0.f;
+    const float* u = nullptr;
+    const float* v = nullptr;
+    if (a.sn >= 0) {
+        const SNDesc d = sn[a.sn];
+        inv_sigma = d.sigma[1];
+        cdot = (float)(d.dot[0] * (double)inv_sigma);
+        u = d.u; v = d.v;
+    }
+    const long rc = (long)a.rows * a.cols;
+    float nacc = 0.f;
+    const float step = lr / bc1;
+    for (long i = lo + threadIdx.x * 4; i < hi; i += 1024) {
+        float4 g = *reinterpret_cast<const float4*>(a.g + i);
+        if (a.sn >= 0) {
+            const long tap = i / rc;
+            const long rem = i - tap * rc;
+            const int r = (int)(rem / a.cols), c = (int)(rem - (long)r * a.cols);
+            const float ur = u[r] * cdot;
+            const float4 vv = *reinterpret_cast<const float4*>(v + tap * a.cols + c);
+            g.x = (g.x - ur * vv.x) * inv_sigma; g.y = (g.y - ur * vv.y) * inv_sigma;
+            g.z = (g.z - ur * vv.z) * inv_sigma; g.w = (g.w - ur * vv.w) * inv_sigma;
+        }
+        nacc += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+        if constexpr (UPDATE) {
+            float4 p = *reinterpret_cast<const float4*>(a.p + i);
+            float4 m = *reinterpret_cast<const float4*>(a.m + i);
+            float4 vs = *reinterpret_cast<const float4*>(a.v + i);
+            const float decay = 1.f - lr * wd;
+#define SGV_ADAM1(F)                                                    \
+            p.F *= decay;                                               \
+            m.F = m.F * b1 + (1.f - b1) * g.F;                          \
+            vs.F = vs.F * b2 + (1.f - b2) * g.F * g.F;                  \
+            p.F -= step * (m.F / (sqrtf(vs.F) / bc2sqrt + eps));
+            SGV_ADAM1(x) SGV_ADAM1(y) SGV_ADAM1(z) SGV_ADAM1(w)
+#undef SGV_ADAM1
+            *reinterpret_cast<float4*>(a.p + i) = p;
+            *reinterpret_cast<float4*>(a.m + i) = m;
+            *reinterpret_cast<float4*>(a.v + i) = vs;
+        }
+    }
+    __shared__ float sm[4];
+    const float w = wave_sum(nacc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(gnorm_sq, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+}
+int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
+              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s) {
+    (void)compute_dtype;
+    if (n > 0) hipLaunchKernelGGL((adamw_kernel<true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
+                  hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL((adamw_kernel<false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, gnorm_sq);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- compute-dtype copies: wc[tap][r][c] = W[tap][r][c]; wct[tap][c][r] = W[taps-1-tap][r][c] ---------
+// work item chunk = (tap, 32-row tile, 32-col tile)
+template <typename T>
+__global__ __launch_bounds__(256) void make_copies_kernel(const AdamDesc* adam, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const AdamDesc a = adam[it.desc];
+    const int ct = (a.cols + 31) >> 5, rt = (a.rows + 31) >> 5;
+    const int tap = it.chunk / (rt * ct);
+    const int rem = it.chunk - tap * rt * ct;
+    const int r0 = (rem / ct) << 5, c0 = (rem % ct) << 5;
+    __shared__ float tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* W = a.p + (long)tap * a.rows * a.cols;
+    T* wc = reinterpret_cast<T*>(a.wc);
+    T* wct = reinterpret_cast<T*>(a.wct);
+    for (int r = ty; r < 32; r += 8) {
+        const int rr = r0 + r, cc = c0 + tx;
+        float x = 0.f;
+        if (rr < a.rows && cc < a.cols) {
+            x = W[(long)rr * a.cols + cc];
+            if (wc) wc[(long)tap * a.rows * a.cols + (long)rr * a.cols + cc] = from_f32<T>(x);
+        }
+        tile[r][tx] = x;
+    }
+    if (!wct) return;
+    __syncthreads();
+    T* dst = wct + (long)(a.taps - 1 - tap) * a.rows * a.cols;
+    for (int r = ty; r < 32; r += 8) {
+        const int cc = c0 + r, rr = r0 + tx;
+        if (rr < a.rows && cc < a.cols) dst[(long)cc * a.rows + rr] = from_f32<T>(tile[tx][r]);
+    }
+}
+int opt_make_copies(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (compute_dtype == 1) hipLaunchKernelGGL((make_copies_kernel<bf16_t>), dim3(n), dim3(256), 0, s, adam_dev, items);
+    else hipLaunchKernelGGL((make_copies_kernel<float>), dim3(n), dim3(256), 0, s, adam_dev, items);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

@@ -1,0 +1,116 @@
+// Shared device/host declarations for libsgvae (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16_t;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+#define SGV_WAVE 64
+
+template <typename T> struct ElemTraits;
+template <> struct ElemTraits<float>  { static constexpr int EPC = 4; };   // elements per 16-byte chunk
+template <> struct ElemTraits<bf16_t> { static constexpr int EPC = 8; };
+
+__device__ __forceinline__ float to_f32(float v) { return v; }
+__device__ __forceinline__ float to_f32(bf16_t v) { return (float)v; }
+template <typename T> __device__ __forceinline__ T from_f32(float v);
+template <> __device__ __forceinline__ float from_f32<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f32<bf16_t>(float v) { return (bf16_t)v; }  // RNE (v_cvt_pk_bf16_f32)
+
+// 8 consecutive elements <-> 8 floats (16 B for bf16, 32 B for fp32); pointers must be 16-byte aligned.
+__device__ __forceinline__ void load8(const float* p, float v[8]) {
+    const float4 a = *reinterpret_cast<const float4*>(p);
+    const float4 b = *reinterpret_cast<const float4*>(p + 4);
+    v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+}
+__device__ __forceinline__ void load8(const bf16_t* p, float v[8]) {
+    const bf16x8 a = *reinterpret_cast<const bf16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)a[i];
+}
+__device__ __forceinline__ void store8(float* p, const float v[8]) {
+    *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]);
+    *reinterpret_cast<float4*>(p + 4) = make_float4(v[4], v[5], v[6], v[7]);
+}
+__device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
+    bf16x8 a;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) a[i] = (bf16_t)v[i];
+    *reinterpret_cast<bf16x8*>(p) = a;
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    return v;
+}
+
+// exact-erf GELU (nn.GELU default) and derivative
+__device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad_f(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
+}
+
+// ---- Philox4x32-10 (counter-based RNG; keyed by (seed, stream), counter = element index / 4) ----
+__device__ __forceinline__ void philox4x32(uint32_t c[4], uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+        const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+        const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+        const uint32_t n1 = (uint32_t)p1;
+        const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+        const uint32_t n3 = (uint32_t)p0;
+        c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+}
+// 4 standard normals from one Philox block (Box-Muller)
+__device__ __forceinline__ void philox_normal4(uint64_t seed, uint64_t stream, uint64_t idx4, float out[4]) {
+    uint32_t c[4] = {(uint32_t)idx4, (uint32_t)(idx4 >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+    philox4x32(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+    const float s = 2.3283064365386963e-10f;  // 2^-32
+    const float u0 = ((float)c[0] + 0.5f) * s, u1 = ((float)c[1] + 0.5f) * s;
+    const float u2 = ((float)c[2] + 0.5f) * s, u3 = ((float)c[3] + 0.5f) * s;
+    const float r0 = sqrtf(-2.0f * __logf(u0)), r1 = sqrtf(-2.0f * __logf(u2));
+    float s0, c0, s1, c1;
+    __sincosf(6.283185307179586f * u1, &s0, &c0);
+    __sincosf(6.283185307179586f * u3, &s1, &c1);
+    out[0] = r0 * c0; out[1] = r0 * s0; out[2] = r1 * c1; out[3] = r1 * s1;
+}
+
+// ---------------- GEMM parameter blocks (see gemm.hip) ----------------
+struct GemmNT {
+    const void* A; long lda;        // activations [M][lda], K columns used
+    const void* W; long ldw;        // weights [taps][N][ldw] (K contiguous)
+    long w_tap_stride;              // elements between taps
+    void* C; long ldc;              // output [M][ldc]
+    const void* addend; long ldadd; // optional, same dtype as the GEMM element type
+    const float* bias;              // optional [N]
+    const float* scale;             // optional device scalar (1/sigma)
+    float* partial;                 // split-K slabs [splitk][M][N] fp32
+    int M, N, K, taps, pad, Tlen, splitk, out_f32;
+};
+struct GemmTN {
+    const void* A; long lda;        // dY [M][lda], N1 columns used
+    const void* B; long ldb;        // X [M][ldb], N2 columns used, row-shifted by tap
+    float* out; long ldo;           // dW [taps][N1][ldo] fp32 (splitk > 1: slab z at out + z*out_slab_stride)
+    long out_tap_stride;
+    long out_slab_stride;
+    int M, N1, N2, taps, pad, Tlen, splitk, use_tr;
+};
+
+int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s);
+int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s);
+int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype);
+int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype);

@@ -1,0 +1,92 @@
+// Host-callable launchers of the elementwise / normalisation / optimizer kernels (ew.hip, optim.hip).
+#pragma once
+#include "sgv_common.h"
+
+struct GNParams {
+    const void* y = nullptr;    long ldy = 0;      // conv output (pre-norm) [B*T][C]
+    const void* res = nullptr;  long ldres = 0;    // optional residual base
+    void* out = nullptr;        long ldout = 0;    // result
+    const void* dout = nullptr; long lddout = 0;   // incoming gradient, or loss target (FROM_LOSS)
+    const float* gamma = nullptr;
+    const float* beta = nullptr;
+    float* dgamma = nullptr;
+    float* dbeta = nullptr;
+    float* dbias = nullptr;                        // bias gradient of the producing conv
+    double* sums = nullptr;                        // [B*G][2] sum, sum of squares
+    double* sums2 = nullptr;                       // [B*G][2] backward group sums
+    double* loss_sums = nullptr;                   // [2]
+    int B = 0, T = 0, C = 0, G = 1, Cg = 1, CV = 1;
+    float rscale = 1.f;                            // residual / incoming-gradient scale
+    float gscale = 1.f;                            // output gradient scale (loss weight)
+    int loss_type = 0;
+};
+
+int ew_gn_stats(int dtype, GNParams p, hipStream_t s);
+int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
+int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s);
+int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s);
+int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s);
+int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s);
+int ew_act(int dtype, int mode, GNParams p, hipStream_t s);
+int ew_add3(int dtype, const void* a, long lda, const void* b, long ldb, const void* c, long ldc, void* out, long ldo,
+            int rows, int C, hipStream_t s);
+int ew_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, long lds_, long ldd,
+                 long sbatch, long dbatch, hipStream_t s);
+int ew_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t s);
+int ew_latent_fwd(const float* last, const float* eps, float* z, int B, int Z, double* kl_sum, hipStream_t s);
+int ew_latent_bwd(const float* last, const float* eps, const float* dz, float* dlast, int B, int Z, float coef, hipStream_t s);
+int ew_stage_fwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dec_out, long ldd,
+                 void* zs_next, long ldz, float* zmap, int M, int C, float std_scale, double* kl_sum, float inv_b,
+                 hipStream_t s);
+int ew_stage_bwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dzs, long ldd, void* g_p,
+                 void* g_q, int M, int C, float coef, hipStream_t s);
+int ew_linear_head_fwd(int xdtype, const void* X, const float* W, const float* bias, const float* scale, float* Y, int B,
+                       int K, int O, hipStream_t s);
+int ew_linear_head_bwd(int xdtype, const float* dY, const void* X, const float* W, const float* scale, const void* addend,
+                       void* dX, float* dW, float* db, int B, int K, int O, hipStream_t s);
+int ew_linear_expand_fwd(int dtype, const float* X, const float* W, const float* bias, const float* scale, void* Y, int B,
+                         int K, int O, hipStream_t s);
+int ew_linear_expand_bwd(int dtype, const void* dY, const float* X, const float* W, const float* scale, float* dX, float* dW,
+                         float* db, int B, int K, int O, hipStream_t s);
+int ew_augment(int dtype, const void* data, void* out, long sample_elems, int batch, const int* idx,
+               const unsigned long long* noise_seed, const float* scale, const int* mix_idx, const float* lam, hipStream_t s);
+int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s);
+int ew_scale(float* y, float a, long n, hipStream_t s);
+int ew_cast_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int C, hipStream_t s);
+
+// ---------------- optimizer / spectral norm (optim.hip) ----------------
+// One descriptor per spectrally-normalised weight, internal layout [taps][rows][cols] fp32.
+struct SNDesc {
+    float* W;          // master weight
+    float* u;          // [rows]
+    float* v;          // [taps*cols], internal order (tap, col)
+    float* tmp_t;      // [taps*cols] scratch: W^T u
+    float* tmp_s;      // [rows]      scratch: W v
+    float* sigma;      // [2]: sigma, 1/sigma
+    double* dot;       // <G, W>
+    const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
+    int taps, rows, cols;
+    int active;        // participates in this forward
+};
+// One descriptor per trainable tensor for the fused AdamW pass.
+struct AdamDesc {
+    float* p; float* g; float* m; float* v;
+    long n;
+    int sn;            // index into the SNDesc table, or -1 (bias / GroupNorm affine)
+    int rows, cols;    // SN geometry for the rank-1 correction (taps*rows*cols == n)
+    void* wc; void* wct;  // compute-dtype copies [taps][rows][cols] and [taps'][cols][rows] (tap-flipped), or null
+    int taps;
+};
+struct WorkItem { int desc; int chunk; };
+
+int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,
+                           int ndesc, int train, hipStream_t s);
+int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipStream_t s);
+int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
+              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s);
+int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
+                  hipStream_t s);
+int opt_make_copies(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s);
+constexpr int OPT_CHUNK = 8192;      // elements per work item in the flat passes
+constexpr int SN_ROWS_PER_ITEM = 64; // rows per work item in the GEMV passes
+constexpr int SN_COLS_PER_ITEM = 1024;

@@ -1,0 +1,139 @@
+"""Kernel-level parity: the two MFMA GEMMs against numpy on bf16-exact inputs (so the only
+difference is fp32 accumulation order).  Called through the C ABI (sgv_test_gemm_*)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import simulgen_vae_amd  # noqa: F401
+from simulgen_vae_amd import engine as E
+
+pytestmark = pytest.mark.gpu
+
+
+def _bf16_round(a):
+    import torch
+    return torch.from_numpy(a).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+def _dev(a, dtype):
+    import torch
+    t = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    return t.to(torch.bfloat16).contiguous() if dtype == 1 else t.contiguous()
+
+
+def ref_conv_nt(A, W, bias, scale, addend, taps, Tlen):
+    """C[m][n] = scale*sum_{j,k} A[m+j-pad][k] W[j][n][k] + bias + addend (taps masked per sample)."""
+    M, K = A.shape
+    N = W.shape[1]
+    pad = (taps - 1) // 2
+    out = np.zeros((M, N), np.float64)
+    t = np.arange(M) % Tlen
+    for j in range(taps):
+        dt = j - pad
+        src = np.arange(M) + dt
+        ok = (t + dt >= 0) & (t + dt < Tlen)
+        As = np.zeros_like(A, dtype=np.float64)
+        As[ok] = A[src[ok]]
+        out += As @ W[j].astype(np.float64).T
+    out = out * scale
+    if bias is not None:
+        out += bias[None, :]
+    if addend is not None:
+        out += addend
+    return out
+
+
+def ref_conv_tn(dY, X, taps, Tlen):
+    M, N1 = dY.shape
+    N2 = X.shape[1]
+    pad = (taps - 1) // 2
+    out = np.zeros((taps, N1, N2), np.float64)
+    t = np.arange(M) % Tlen
+    for j in range(taps):
+        dt = j - pad
+        src = np.arange(M) + dt
+        ok = (t + dt >= 0) & (t + dt < Tlen)
+        Xs = np.zeros_like(X, dtype=np.float64)
+        Xs[ok] = X[src[ok]]
+        out[j] = dY.astype(np.float64).T @ Xs
+    return out
+
+
+NT_CASES = [
+    # M, N, K, taps, Tlen, splitk
+    (128, 128, 64, 1, 16, 1),
+    (200, 72, 40, 1, 10, 1),
+    (30, 8, 8, 3, 10, 1),
+    (260, 136, 96, 3, 13, 1),
+    (400, 200, 160, 5, 20, 1),
+    (400, 200, 160, 5, 20, 3),
+    (96, 264, 1032, 1, 12, 4),
+    (520, 320, 320, 5, 40, 2),
+]
+
+
+@pytest.mark.parametrize("dtype", [0, 1])
+@pytest.mark.parametrize("case", NT_CASES)
+def test_gemm_nt(dtype, case):
+    import torch
+    lib = E.load_library()
+    M, N, K, taps, Tlen, splitk = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = _bf16_round(rng.standard_normal((M, N)).astype(np.float32))
+    scale = np.array([0.37], np.float32)
+    dA, dW, dadd = _dev(A, dtype), _dev(W, dtype), _dev(add, dtype)
+    dbias, dscale = torch.from_numpy(bias).cuda(), torch.from_numpy(scale).cuda()
+    out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib.sgv_test_gemm_nt(dtype, dA.data_ptr(), dW.data_ptr(), out.data_ptr(), dbias.data_ptr(), dscale.data_ptr(),
+                              dadd.data_ptr(), M, N, K, taps, Tlen, splitk, 1, None)
+    assert rc == 0, lib.sgv_last_error()
+    ref = ref_conv_nt(A, W, bias, 0.37, add, taps, Tlen)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
+    # compute-dtype output path (rounds to bf16 in bf16 mode)
+    out2 = (torch.zeros((M, N), dtype=torch.bfloat16 if dtype == 1 else torch.float32, device="cuda"))
+    rc = lib.sgv_test_gemm_nt(dtype, dA.data_ptr(), dW.data_ptr(), out2.data_ptr(), dbias.data_ptr(), None,
+                              None, M, N, K, taps, Tlen, splitk, 0, None)
+    assert rc == 0, lib.sgv_last_error()
+    ref2 = ref_conv_nt(A, W, bias, 1.0, None, taps, Tlen)
+    err2 = np.abs(out2.float().cpu().numpy() - ref2).max() / np.abs(ref2).max()
+    assert err2 < (6e-3 if dtype == 1 else 2e-5), err2
+
+
+TN_CASES = [
+    # M, N1, N2, taps, Tlen, splitk
+    (128, 128, 128, 1, 16, 1),
+    (200, 72, 40, 1, 10, 1),
+    (30, 8, 8, 3, 10, 1),
+    (260, 136, 96, 3, 13, 2),
+    (400, 200, 160, 5, 20, 1),
+    (400, 200, 160, 5, 20, 3),
+    (1040, 264, 328, 1, 40, 4),
+]
+
+
+@pytest.mark.parametrize("dtype,use_tr", [(0, 0), (1, 1), (1, 0)])
+@pytest.mark.parametrize("case", TN_CASES)
+def test_gemm_tn(dtype, use_tr, case):
+    import torch
+    lib = E.load_library()
+    M, N1, N2, taps, Tlen, splitk = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    dY = _bf16_round(rng.standard_normal((M, N1)).astype(np.float32))
+    X = _bf16_round(rng.standard_normal((M, N2)).astype(np.float32))
+    ddY, dX = _dev(dY, dtype), _dev(X, dtype)
+    out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+    rc = lib.sgv_test_gemm_tn(dtype, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk,
+                              use_tr, None)
+    assert rc == 0, lib.sgv_last_error()
+    ref = ref_conv_tn(dY, X, taps, Tlen)
+    got = out.cpu().numpy()
+    assert np.isfinite(got).all()
+    err = np.abs(got - ref).max() / np.abs(ref).max()
+    assert err < 2e-5, err
