@@ -46,9 +46,10 @@ def conv1d_fwd(x, W, b):
     Cout, _, k = W.shape
     p = (k - 1) // 2
     xp = np.pad(x, ((0, 0), (0, 0), (p, p))) if p else x
+    Wt = np.ascontiguousarray(W.transpose(2, 0, 1))          # [k][Cout][Cin]: BLAS-friendly taps
     y = np.zeros((B, Cout, T), F)
     for j in range(k):
-        y += np.matmul(W[:, :, j], xp[:, :, j:j + T])
+        y += np.matmul(Wt[j], xp[:, :, j:j + T])
     if b is not None:
         y += b[None, :, None]
     return y
@@ -59,17 +60,19 @@ def conv1d_bwd(x, W, dy, need_dx=True):
     Cout, _, k = W.shape
     p = (k - 1) // 2
     xp = np.pad(x, ((0, 0), (0, 0), (p, p))) if p else x
-    dW = np.empty_like(W)
+    dWt = np.empty((k, Cout, Cin), F)
     dyf = np.ascontiguousarray(dy.transpose(1, 0, 2)).reshape(Cout, B * T)
     for j in range(k):
         xs = np.ascontiguousarray(xp[:, :, j:j + T].transpose(1, 0, 2)).reshape(Cin, B * T)
-        dW[:, :, j] = dyf @ xs.T
+        dWt[j] = dyf @ xs.T
+    dW = np.ascontiguousarray(dWt.transpose(1, 2, 0))
     db = dy.sum(axis=(0, 2), dtype=np.float64).astype(F)
     dx = None
     if need_dx:
+        WtT = np.ascontiguousarray(W.transpose(2, 1, 0))     # [k][Cin][Cout]
         dxp = np.zeros_like(xp)
         for j in range(k):
-            dxp[:, :, j:j + T] += np.matmul(W[:, :, j].T, dy)
+            dxp[:, :, j:j + T] += np.matmul(WtT[j], dy)
         dx = dxp[:, :, p:p + T] if p else dxp
     return dx, dW, db
 
@@ -153,12 +156,21 @@ def sn_forward(W, u, v, op, train):
     return (W / sigma).astype(F), sigma, u, v
 
 
+def _dot64(a, b, chunk=1 << 22):
+    a = a.ravel()
+    b = b.ravel()
+    tot = 0.0
+    for i in range(0, a.size, chunk):
+        tot += float(np.dot(a[i:i + chunk].astype(np.float64), b[i:i + chunk].astype(np.float64)))
+    return tot
+
+
 def sn_backward(G, W, sigma, u, v, op):
     """dL/dW_orig from G = dL/dW_eff with u, v constants: (G - <G,W_eff> u v^T) / sigma."""
-    Gm = sn_matrix(G, op).astype(np.float64)
-    Wm = sn_matrix(W, op).astype(np.float64)
-    c = (Gm * Wm).sum() / float(sigma)
-    dWm = (Gm - c * np.outer(u.astype(np.float64), v.astype(np.float64))) / float(sigma)
+    Gm = sn_matrix(G, op)
+    Wm = sn_matrix(W, op)
+    c = _dot64(Gm, Wm) / float(sigma)
+    dWm = (Gm - F(c) * np.outer(u, v).astype(F)) * F(1.0 / float(sigma))
     return sn_unmatrix(dWm.astype(F), W.shape, op)
 
 

@@ -1,0 +1,158 @@
+"""Engine parity on the GPU, through the C ABI: libsgvae.so vs (a) the golden fixtures the
+reference itself produced and (b) the numpy oracle, on the same seeded inputs.
+
+Tolerances: fp32 compute -> 5e-5 relative (max-norm) on activations/gradients, 1e-5 on scalars;
+bf16 compute -> stated per check below (bf16 has 8 mantissa bits; accumulation is fp32)."""
+import os
+
+import numpy as np
+import pytest
+
+from tests.gpu_common import G0, G1, G2, GOLD, engine_step, make_cfg, oracle_step, rel_l2, relerr
+from simulgen_vae_amd import engine as E
+from simulgen_vae_amd.init import init_state, synthetic_eps, synthetic_samples
+from simulgen_vae_amd.spec import param_spec
+from oracle import vae_oracle as vo
+
+pytestmark = pytest.mark.gpu
+
+
+def _golden_run(tag, cfgd, small, lossfun, dtype, steps=3):
+    import torch
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    alpha, beta, lr, sseed, dseed, eseed, B = g["meta"]
+    B = int(B)
+    cfg = make_cfg(cfgd, small, lossfun)
+    eng = E.Engine(cfg, max_batch=B, compute_dtype=dtype)
+    eng.load_state(init_state(cfg, int(sseed)))
+    out = []
+    for step in range(steps):
+        x = synthetic_samples(int(dseed), range(step * B, (step + 1) * B), cfg.num_node, cfg.num_time)
+        eps = synthetic_eps(int(eseed), step, cfg, B)
+        sc, acts = engine_step(eng, cfg, x, eps, alpha, beta, want_acts=(step == 0))
+        gn = eng.grad_norm()
+        loss = alpha * sc["recon"] + beta * sum(sc["kls"])
+        rec = dict(scalars=np.array([sc["recon"]] + sc["kls"] + [sc["mse"], loss, gn]), acts=acts)
+        if step == 0:
+            rec["grads"] = {e.name: eng.grad(e.name) for e in param_spec(cfg)
+                            if e.kind in ("bias", "weight_orig", "gn_weight", "gn_bias")}
+            rec["uv"] = {k: v for k, v in eng.state_dict().items() if k.endswith("_u") or k.endswith("_v")}
+        eng.adamw_step(lr)
+        out.append(rec)
+    return cfg, eng, g, out
+
+
+@pytest.mark.parametrize("tag,small", [("g0_small_MSE", True), ("g0_large_MSE", False)])
+def test_fp32_matches_reference_golden(tag, small):
+    cfg, eng, g, out = _golden_run(tag, G0, small, "MSE", "f32")
+    r0 = out[0]
+    np.testing.assert_allclose(r0["scalars"], g["scalars0"], rtol=2e-5)
+    assert relerr(r0["acts"]["x_hat"], g["x_hat"]) < 1e-5
+    nograd = set(g["nograd"].tolist())
+    for k in g.files:
+        if k.startswith("act."):
+            assert relerr(r0["acts"][k[4:]], g[k]) < 1e-5, k
+        elif k.startswith("uv1."):
+            assert relerr(r0["uv"][k[4:]], g[k]) < 1e-5, k
+        elif k.startswith("grad."):
+            assert relerr(r0["grads"][k[5:]], g[k]) < 5e-5, k
+    assert nograd == {k for k, v in r0["grads"].items() if v is None}
+    np.testing.assert_allclose(out[1]["scalars"], g["scalars1"], rtol=5e-5)
+    np.testing.assert_allclose(out[2]["scalars"], g["scalars2"], rtol=2e-4)
+    sd = eng.state_dict()
+    for e in param_spec(cfg):
+        assert relerr(sd[e.name], g["s3." + e.name]) < 3e-4, e.name
+    # eval-mode forward + mode='fix' decoder on the step-3 state
+    import torch
+    B = int(g["meta"][6])
+    x = synthetic_samples(int(g["meta"][4]), range(100, 100 + B), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(int(g["meta"][5]), 100, cfg, B)
+    eng.set_input(torch.from_numpy(x).cuda())
+    eng.set_eps([torch.from_numpy(e).cuda() for e in eps])
+    sc = eng.forward(train=False)
+    np.testing.assert_allclose([sc["recon"]] + sc["kls"] + [sc["mse"]], g["eval.scalars"], rtol=5e-4)
+    xh = eng.xhat().cpu().numpy()
+    assert relerr(xh, g["eval.x_hat"]) < 3e-4
+    mu, lv, xs = eng.encode()
+    assert relerr(mu, g["eval.mu"]) < 3e-4 and relerr(lv, g["eval.log_var"]) < 3e-4
+    for i, v in enumerate(xs):
+        assert relerr(v, g[f"eval.xs{i}"]) < 3e-4
+    eng.set_eps([torch.from_numpy(e).cuda() for e in eps])
+    eng.forward(train=False, fix=True)
+    assert relerr(eng.xhat().cpu().numpy(), g["fix.x_hat"]) < 3e-4
+    assert relerr(eng.activation("z", (B, cfg.latent_dim)), g["fix.z"]) < 3e-4
+    eng.close()
+
+
+@pytest.mark.parametrize("tag,cfgd,lossfun", [("g0_small_MAE", G0, "MAE"), ("g0_small_smoothL1", G0, "smoothL1"),
+                                              ("g0_small_Huber", G0, "Huber"), ("g1_small_MSE", G1, "MSE")])
+def test_fp32_matches_reference_norms(tag, cfgd, lossfun):
+    cfg, eng, g, out = _golden_run(tag, cfgd, True, lossfun, "f32")
+    np.testing.assert_allclose(out[0]["scalars"], g["scalars0"], rtol=3e-5)
+    for k in g.files:
+        if k.startswith("gradnorm."):
+            gn = np.linalg.norm(out[0]["grads"][k[9:]].astype(np.float64))
+            assert abs(gn - g[k]) <= 1e-4 * abs(g[k]) + 1e-12, k
+    np.testing.assert_allclose(out[2]["scalars"], g["scalars2"], rtol=2e-4)
+    sd = eng.state_dict()
+    for k in g.files:
+        if k.startswith("s3norm."):
+            assert abs(np.linalg.norm(sd[k[7:]].astype(np.float64)) - g[k]) <= 2e-4 * abs(g[k]), k
+    eng.close()
+
+
+@pytest.mark.parametrize("cfgd,small,B", [(G0, True, 3), (G1, True, 4), (G1, False, 2), (G2, True, 2)])
+def test_bf16_close_to_oracle(cfgd, small, B):
+    """bf16 compute (the bench dtype) vs the fp32 oracle.  Stated tolerance: ELBO 2e-3 relative on
+    these small random-weight nets (bf16 rounding of every stored map), gradient tensors 5e-2 rel-L2
+    (weights) and grad-norm 2e-2."""
+    cfg = make_cfg(cfgd, small)
+    state = init_state(cfg, 7)
+    eng = E.Engine(cfg, max_batch=B, compute_dtype="bf16")
+    eng.load_state(state)
+    orc = vo.OracleVAE(cfg, state)
+    alpha, beta = 1e6, 1e-4
+    x = synthetic_samples(20251003, range(B), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(1234, 0, cfg, B)
+    sc, acts = engine_step(eng, cfg, x, eps, alpha, beta)
+    osc, oacts, ograds = oracle_step(orc, x, eps, alpha, beta)
+    le = alpha * sc["recon"] + beta * sum(sc["kls"])
+    lo = alpha * osc["recon"] + beta * sum(osc["kls"])
+    assert abs(le - lo) / abs(lo) < 2e-3, (le, lo)
+    for k in ("enc_h0", "enc_h3", "dec_out0", "dec_out2", "x_hat"):
+        assert rel_l2(acts[k], oacts[k]) < 3e-2, (k, rel_l2(acts[k], oacts[k]))
+    bad = []
+    for name, g in ograds.items():
+        eg = eng.grad(name)
+        assert (g is None) == (eg is None), name
+        if g is None:
+            continue
+        if name.endswith("weight_orig") and rel_l2(eg, g) > 5e-2:
+            bad.append((name, rel_l2(eg, g)))
+    assert not bad, bad
+    assert abs(eng.grad_norm() - orc.grad_norm()) / orc.grad_norm() < 2e-2
+    eng.close()
+
+
+def test_engine_rejects_bad_config():
+    cfg = make_cfg(dict(latent_dim=32, hierarchical_dim=8, enc=[30, 16, 8, 8], num_node=72, num_time=10))
+    with pytest.raises(E.SgvError):
+        E.Engine(cfg, max_batch=2, compute_dtype="f32")
+
+
+def test_philox_eps_statistics():
+    """Without injected noise the engine draws eps from its Philox stream: two forwards differ and the
+    KL terms stay finite."""
+    import torch
+    cfg = make_cfg(G0)
+    eng = E.Engine(cfg, max_batch=3, compute_dtype="f32")
+    eng.load_state(init_state(cfg, 7))
+    x = synthetic_samples(20251003, range(3), cfg.num_node, cfg.num_time)
+    eng.set_input(torch.from_numpy(x).cuda())
+    a = eng.forward(train=False)
+    z1 = eng.activation("z", (3, cfg.latent_dim))
+    b = eng.forward(train=False)
+    z2 = eng.activation("z", (3, cfg.latent_dim))
+    assert np.isfinite(a["recon"]) and np.isfinite(b["recon"])
+    assert np.abs(z1 - z2).max() > 1e-3
+    eng.close()

@@ -146,3 +146,30 @@ def test_augmentation():
         out = vo.augment_sample(data[i], other, nz, dec)
         np.testing.assert_allclose(out, g["out"][i], rtol=1e-6, atol=1e-7)
     assert not rand and not randint and not beta and not noise
+
+
+@pytest.mark.parametrize("tag,cfgd,small,lossfun", [("g0_small_MSE", G0, True, "MSE"), ("g0_large_MSE", G0, False, "MSE"),
+                                                    ("g0_small_Huber", G0, True, "Huber"), ("g1_small_MSE", G1, True, "MSE")])
+def test_torch_port_matches_golden(tag, cfgd, small, lossfun):
+    """oracle/torch_port.py (the timed CPU baseline of bench.py) against the reference's fixtures."""
+    from oracle.torch_port import TorchPortVAE
+    g = np.load(os.path.join(GOLD, tag + ".npz"))
+    alpha, beta, lr, sseed, dseed, eseed, B = g["meta"]
+    B = int(B)
+    cfg = make(cfgd, small, lossfun)
+    m = TorchPortVAE(cfg, init_state(cfg, int(sseed)))
+    m.keep_grads = True
+    for step in range(3):
+        x = synthetic_samples(int(dseed), range(step * B, (step + 1) * B), cfg.num_node, cfg.num_time)
+        eps = synthetic_eps(int(eseed), step, cfg, B)
+        r = m.train_step(x, eps, alpha, beta, lr)
+        got = np.array([r["recon"]] + r["kls"] + [r["mse"], r["loss"], r["grad_norm"]])
+        np.testing.assert_allclose(got, g[f"scalars{step}"], rtol=2e-5 if step == 0 else 2e-4)
+        if step == 0:
+            assert {k for k, v in m.grads.items() if v is None} == set(g["nograd"].tolist())
+            for k in g.files:
+                if k.startswith("grad."):
+                    assert relerr(m.grads[k[5:]], g[k]) < 5e-5, k
+    for k in g.files:
+        if k.startswith("s3."):
+            assert relerr(m.P[k[3:]].detach().numpy(), g[k]) < 3e-4, k
