@@ -12,6 +12,9 @@
 // sample-boundary taps are zero-filled at chunk granularity.
 #include "sgv_common.h"
 
+// zero a 16-byte chunk with an integer mask (0 or ~0): a plain AND cannot be turned into a memory select
+__device__ __forceinline__ uint4 mask4(uint4 v, uint32_t m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); }
+
 // =========================================================================================
 // NT
 // =========================================================================================
@@ -38,59 +41,54 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
     const int s_begin = (int)((long)total * z / p.splitk);
     const int s_end = (int)((long)total * (z + 1) / p.splitk);
 
+    static_assert(LPT == 2, "two 16-byte load slots per operand per thread");
     const int kq = tid % KCH;
     const int r0 = tid / KCH;
     const T* Ag = reinterpret_cast<const T*>(p.A);
     const T* Wg = reinterpret_cast<const T*>(p.W);
-    const T* a_base[LPT];
-    const T* w_base[LPT];
-    int a_t[LPT];
-    bool a_ok[LPT], w_ok[LPT];
-#pragma unroll
-    for (int i = 0; i < LPT; ++i) {
-        const int r = r0 + i * RSTEP;
-        const int m = m0 + r, n = n0 + r;
-        a_ok[i] = m < p.M;
-        w_ok[i] = n < p.N;
-        a_t[i] = m % p.Tlen;
-        a_base[i] = Ag + (long)m * p.lda + kq * EPC;
-        w_base[i] = Wg + (long)n * p.ldw + kq * EPC;
-    }
-    uint4 ra[LPT], rw[LPT];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    // named scalars only (no per-thread arrays: hipcc demoted them to scratch memory)
+    const int am0 = m0 + r0, am1 = m0 + r0 + RSTEP;
+    const int wn0 = n0 + r0, wn1 = n0 + r0 + RSTEP;
+    const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
+    const bool wok0 = wn0 < p.N, wok1 = wn1 < p.N;
+    const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
+    const long abase0 = (long)am0 * p.lda + kq * EPC, abase1 = (long)am1 * p.lda + kq * EPC;
+    const long wbase0 = (long)wn0 * p.ldw + kq * EPC, wbase1 = (long)wn1 * p.ldw + kq * EPC;
+    uint4 ra0, ra1, rw0, rw1;
+    uint32_t ma0 = 0u, ma1 = 0u, mw0 = 0u, mw1 = 0u;   // validity masks of the in-flight loads (applied at LDS-store time)
 
-    auto gload = [&](int s) {
-        const int j = s / kchunks;
-        const int kc = (s - j * kchunks) * BK;
-        const int dt = j - p.pad;
-        const bool kok = (kc + kq * EPC) < p.K;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const bool oka = a_ok[i] && kok && ((unsigned)(a_t[i] + dt) < (unsigned)p.Tlen);
-            ra[i] = zero4;
-            if (oka) ra[i] = *reinterpret_cast<const uint4*>(a_base[i] + (long)dt * p.lda + kc);
-            const bool okw = w_ok[i] && kok;
-            rw[i] = zero4;
-            if (okw) rw[i] = *reinterpret_cast<const uint4*>(w_base[i] + (long)j * p.w_tap_stride + kc);
-        }
-    };
-    auto sstore = [&](int buf) {
-        unsigned char* sa = smem + buf * 2 * TILEB;
-        unsigned char* sw = sa + TILEB;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int off = (r0 + i * RSTEP) * ROWB + kq * 16;
-            if constexpr (IS_BF16) {
-                *reinterpret_cast<uint4*>(sa + off) = ra[i];
-                *reinterpret_cast<uint4*>(sw + off) = rw[i];
-            } else {
-                uint32_t* da = reinterpret_cast<uint32_t*>(sa + off);
-                uint32_t* dw = reinterpret_cast<uint32_t*>(sw + off);
-                da[0] = ra[i].x; da[1] = ra[i].y; da[2] = ra[i].z; da[3] = ra[i].w;
-                dw[0] = rw[i].x; dw[1] = rw[i].y; dw[2] = rw[i].z; dw[3] = rw[i].w;
-            }
-        }
-    };
+    // Predicated loads without branches: masked-off lanes read a valid dummy address (offset 0) and the
+    // result is zero-selected (EXEC stays full; the four loads of a step issue back-to-back).
+#define SGV_NT_GLOAD(S)                                                                                       \
+    {                                                                                                         \
+        const int j_ = (S) / kchunks;                                                                         \
+        const int kc_ = ((S) - j_ * kchunks) * BK;                                                            \
+        const int dt_ = j_ - p.pad;                                                                           \
+        const bool kok_ = (kc_ + kq * EPC) < p.K;                                                             \
+        const long aoff_ = (long)dt_ * p.lda + kc_;                                                           \
+        const long woff_ = (long)j_ * p.w_tap_stride + kc_;                                                   \
+        const bool pa0 = aok0 && kok_ && ((unsigned)(at0 + dt_) < (unsigned)p.Tlen);                          \
+        const bool pa1 = aok1 && kok_ && ((unsigned)(at1 + dt_) < (unsigned)p.Tlen);                          \
+        const bool pw0 = wok0 && kok_;                                                                        \
+        const bool pw1 = wok1 && kok_;                                                                        \
+        ma0 = pa0 ? ~0u : 0u; ma1 = pa1 ? ~0u : 0u; mw0 = pw0 ? ~0u : 0u; mw1 = pw1 ? ~0u : 0u;               \
+        ra0 = *reinterpret_cast<const uint4*>(Ag + (pa0 ? abase0 + aoff_ : 0L));                              \
+        ra1 = *reinterpret_cast<const uint4*>(Ag + (pa1 ? abase1 + aoff_ : 0L));                              \
+        rw0 = *reinterpret_cast<const uint4*>(Wg + (pw0 ? wbase0 + woff_ : 0L));                              \
+        rw1 = *reinterpret_cast<const uint4*>(Wg + (pw1 ? wbase1 + woff_ : 0L));                              \
+    }
+#define SGV_NT_ST1(PTR, V)                                                                                    \
+    if constexpr (IS_BF16) { *reinterpret_cast<uint4*>(PTR) = (V); }                                          \
+    else { uint32_t* d_ = reinterpret_cast<uint32_t*>(PTR); d_[0] = (V).x; d_[1] = (V).y; d_[2] = (V).z; d_[3] = (V).w; }
+#define SGV_NT_SSTORE(BUF)                                                                                    \
+    {                                                                                                         \
+        unsigned char* sa_ = smem + (BUF) * 2 * TILEB + r0 * ROWB + kq * 16;                                  \
+        unsigned char* sw_ = sa_ + TILEB;                                                                     \
+        const uint4 xa0_ = mask4(ra0, ma0), xa1_ = mask4(ra1, ma1);                                           \
+        const uint4 xw0_ = mask4(rw0, mw0), xw1_ = mask4(rw1, mw1);                                           \
+        SGV_NT_ST1(sa_, xa0_) SGV_NT_ST1(sa_ + RSTEP * ROWB, xa1_)                                            \
+        SGV_NT_ST1(sw_, xw0_) SGV_NT_ST1(sw_ + RSTEP * ROWB, xw1_)                                            \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -101,78 +99,88 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf) {
-        const unsigned char* sa = smem + buf * 2 * TILEB;
-        const unsigned char* sw = sa + TILEB;
-        if constexpr (IS_BF16) {
-#pragma unroll
-            for (int ks = 0; ks < BK / 16; ++ks) {
-                bf16x8 af[2], bfr[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const bf16x8*>(sa + (wm * 64 + i * 32 + lr) * ROWB + (ks * 2 + lh) * 16);
-                    bfr[i] = *reinterpret_cast<const bf16x8*>(sw + (wn * 64 + i * 32 + lr) * ROWB + (ks * 2 + lh) * 16);
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < BK / 2; ++ks) {
-                float af[2], bfr[2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const float*>(sa + (wm * 64 + i * 32 + lr) * ROWB + (ks * 2 + lh) * 4);
-                    bfr[i] = *reinterpret_cast<const float*>(sw + (wn * 64 + i * 32 + lr) * ROWB + (ks * 2 + lh) * 4);
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
-            }
-        }
-    };
+    const int a_frag_off = (wm * 64 + lr) * ROWB;
+    const int w_frag_off = (wn * 64 + lr) * ROWB;
+#define SGV_NT_COMPUTE(BUF)                                                                                   \
+    {                                                                                                         \
+        const unsigned char* sa_ = smem + (BUF) * 2 * TILEB + a_frag_off;                                     \
+        const unsigned char* sw_ = smem + (BUF) * 2 * TILEB + TILEB + w_frag_off;                             \
+        if constexpr (IS_BF16) {                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                          \
+                const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + (ks * 2 + lh) * 16);                \
+                const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * ROWB + (ks * 2 + lh) * 16);    \
+                const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + (ks * 2 + lh) * 16);                \
+                const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * ROWB + (ks * 2 + lh) * 16);    \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
+            }                                                                                                 \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                           \
+                const float a0_ = *reinterpret_cast<const float*>(sa_ + (ks * 2 + lh) * 4);                   \
+                const float a1_ = *reinterpret_cast<const float*>(sa_ + 32 * ROWB + (ks * 2 + lh) * 4);       \
+                const float b0_ = *reinterpret_cast<const float*>(sw_ + (ks * 2 + lh) * 4);                   \
+                const float b1_ = *reinterpret_cast<const float*>(sw_ + 32 * ROWB + (ks * 2 + lh) * 4);       \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);               \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);               \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);               \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);               \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
 
     if (s_begin < s_end) {
-        gload(s_begin);
-        sstore(0);
+        SGV_NT_GLOAD(s_begin);
+        SGV_NT_SSTORE(0);
         __syncthreads();
         int cur = 0;
-        for (int s = s_begin; s < s_end; ++s) {
-            const bool more = (s + 1) < s_end;
-            if (more) gload(s + 1);
-            compute(cur);
-            if (more) sstore(cur ^ 1);
+        for (int s = s_begin; s + 1 < s_end; ++s) {
+            SGV_NT_GLOAD(s + 1);          // next tile's loads stay in flight under this tile's MFMAs
+            __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads below the MFMAs
+            SGV_NT_COMPUTE(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            SGV_NT_SSTORE(cur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
+        SGV_NT_COMPUTE(cur);
     }
+#undef SGV_NT_GLOAD
+#undef SGV_NT_SSTORE
+#undef SGV_NT_ST1
+#undef SGV_NT_COMPUTE
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const float sc = p.scale ? *p.scale : 1.0f;
+    const bool full = (m0 + 128 <= p.M) && (n0 + 128 <= p.N);
+    const T* addp = reinterpret_cast<const T*>(p.addend);
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int col = n0 + wn * 64 + b * 32 + lr;
-            if (col >= p.N) continue;
-            const float bv = (p.bias && p.splitk == 1) ? p.bias[col] : 0.f;
+            const bool cok = full || (col < p.N);
+            const int colc = cok ? col : 0;
+            const int rbase = m0 + wm * 64 + a * 32 + 4 * lh;
+            if (p.splitk > 1) {
+                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= p.M) continue;
-                float v = acc[a][b][r];
-                if (p.splitk > 1) {
-                    p.partial[((long)z * p.M + row) * p.N + col] = v;
-                } else {
-                    v = v * sc + bv;
-                    if (p.addend) v += to_f32(reinterpret_cast<const T*>(p.addend)[(long)row * p.ldadd + col]);
-                    if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
-                    else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = from_f32<T>(v);
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && (full || row < p.M)) dst[(long)row * p.N] = acc[a][b][r];
+                }
+            } else {
+                const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && (full || row < p.M)) {
+                        float v = acc[a][b][r] * sc + bv;
+                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
+                        if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+                        else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = from_f32<T>(v);
+                    }
                 }
             }
         }
@@ -229,32 +237,33 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
     const T* Bg = reinterpret_cast<const T*>(p.B);
     const bool a_cok = (i0 + cq * EPC) < p.N1;
     const bool b_cok = (j0 + cq * EPC) < p.N2;
-    uint4 ra[LPT], rb[LPT];
-    const uint4 zero4 = make_uint4(0u, 0u, 0u, 0u);
+    static_assert(LPT == 2, "two 16-byte load slots per operand per thread");
+    uint4 ra0, ra1, rb0, rb1;
+    uint32_t ma0 = 0u, ma1 = 0u, mb0 = 0u, mb1 = 0u;
+    const long acol = i0 + cq * EPC, bcol = j0 + cq * EPC;
 
-    auto gload = [&](int s) {
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int m = s * KR + r0 + i * RSTEP;
-            const bool mok = m < p.M;
-            ra[i] = zero4;
-            if (mok && a_cok) ra[i] = *reinterpret_cast<const uint4*>(Ag + (long)m * p.lda + i0 + cq * EPC);
-            const int t = m % p.Tlen;
-            rb[i] = zero4;
-            if (mok && b_cok && ((unsigned)(t + dt) < (unsigned)p.Tlen))
-                rb[i] = *reinterpret_cast<const uint4*>(Bg + (long)(m + dt) * p.ldb + j0 + cq * EPC);
-        }
-    };
-    auto sstore = [&](int buf) {
-        unsigned char* sa = smem + buf * 2 * TILEB;
-        unsigned char* sb = sa + TILEB;
-#pragma unroll
-        for (int i = 0; i < LPT; ++i) {
-            const int off = (r0 + i * RSTEP) * ROWB + cq * 16;
-            *reinterpret_cast<uint4*>(sa + off) = ra[i];
-            *reinterpret_cast<uint4*>(sb + off) = rb[i];
-        }
-    };
+#define SGV_TN_GLOAD(S)                                                                                       \
+    {                                                                                                         \
+        const int m0_ = (S) * KR + r0, m1_ = (S) * KR + r0 + RSTEP;                                           \
+        const bool pa0 = (m0_ < p.M) && a_cok, pa1 = (m1_ < p.M) && a_cok;                                    \
+        const int t0_ = m0_ % p.Tlen, t1_ = m1_ % p.Tlen;                                                     \
+        const bool pb0 = (m0_ < p.M) && b_cok && ((unsigned)(t0_ + dt) < (unsigned)p.Tlen);                   \
+        const bool pb1 = (m1_ < p.M) && b_cok && ((unsigned)(t1_ + dt) < (unsigned)p.Tlen);                   \
+        ma0 = pa0 ? ~0u : 0u; ma1 = pa1 ? ~0u : 0u; mb0 = pb0 ? ~0u : 0u; mb1 = pb1 ? ~0u : 0u;               \
+        ra0 = *reinterpret_cast<const uint4*>(Ag + (pa0 ? (long)m0_ * p.lda + acol : 0L));                    \
+        ra1 = *reinterpret_cast<const uint4*>(Ag + (pa1 ? (long)m1_ * p.lda + acol : 0L));                    \
+        rb0 = *reinterpret_cast<const uint4*>(Bg + (pb0 ? (long)(m0_ + dt) * p.ldb + bcol : 0L));             \
+        rb1 = *reinterpret_cast<const uint4*>(Bg + (pb1 ? (long)(m1_ + dt) * p.ldb + bcol : 0L));             \
+    }
+#define SGV_TN_SSTORE(BUF)                                                                                    \
+    {                                                                                                         \
+        unsigned char* sa_ = smem + (BUF) * 2 * TILEB + r0 * ROWB + cq * 16;                                  \
+        unsigned char* sb_ = sa_ + TILEB;                                                                     \
+        *reinterpret_cast<uint4*>(sa_) = mask4(ra0, ma0);                                                     \
+        *reinterpret_cast<uint4*>(sa_ + RSTEP * ROWB) = mask4(ra1, ma1);                                      \
+        *reinterpret_cast<uint4*>(sb_) = mask4(rb0, mb0);                                                     \
+        *reinterpret_cast<uint4*>(sb_ + RSTEP * ROWB) = mask4(rb1, mb1);                                      \
+    }
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -265,83 +274,83 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    auto compute = [&](int buf) {
-        const unsigned char* sa = smem + buf * 2 * TILEB;
-        const unsigned char* sb = sa + TILEB;
-        if constexpr (IS_BF16) {
-#pragma unroll
-            for (int ks = 0; ks < KR / 16; ++ks) {
-                bf16x8 af[2], bfr[2];
-                if constexpr (USE_TR) {
-                    // ds_read_b64_tr_b16: per 16-lane group g a 4(k) x 16(col) block; lane 4q+p of the
-                    // group addresses row q, cols 4p..4p+3; lane i receives column i, rows 0..3.
-                    const int g = lane >> 4, q = (lane >> 2) & 3, pp = lane & 3;
-                    const int kb = ks * 16 + 8 * (g >> 1) + q;
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-                        const int ca = wm * 64 + i * 32 + 16 * (g & 1) + 4 * pp;
-                        const int cb = wn * 64 + i * 32 + 16 * (g & 1) + 4 * pp;
-                        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-                        const s16x4 alo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sa + (kb * LD + ca) * 2));
-                        const s16x4 ahi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sa + ((kb + 4) * LD + ca) * 2));
-                        const s16x4 blo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + (kb * LD + cb) * 2));
-                        const s16x4 bhi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(sb + ((kb + 4) * LD + cb) * 2));
-                        s16x8 av, bv;
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) { av[e] = alo[e]; av[e + 4] = ahi[e]; bv[e] = blo[e]; bv[e + 4] = bhi[e]; }
-                        af[i] = __builtin_bit_cast(bf16x8, av);
-                        bfr[i] = __builtin_bit_cast(bf16x8, bv);
-                    }
-                } else {
-#pragma unroll
-                    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) {
-                            const int k = ks * 16 + 8 * lh + e;
-                            af[i][e] = *reinterpret_cast<const bf16_t*>(sa + (k * LD + wm * 64 + i * 32 + lr) * 2);
-                            bfr[i][e] = *reinterpret_cast<const bf16_t*>(sb + (k * LD + wn * 64 + i * 32 + lr) * 2);
-                        }
-                    }
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
-            }
-        } else {
-#pragma unroll
-            for (int ks = 0; ks < KR / 2; ++ks) {
-                float af[2], bfr[2];
-                const int k = ks * 2 + lh;
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = *reinterpret_cast<const float*>(sa + (k * LD + wm * 64 + i * 32 + lr) * 4);
-                    bfr[i] = *reinterpret_cast<const float*>(sb + (k * LD + wn * 64 + i * 32 + lr) * 4);
-                }
-#pragma unroll
-                for (int a = 0; a < 2; ++a)
-#pragma unroll
-                    for (int b = 0; b < 2; ++b)
-                        acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a], bfr[b], acc[a][b], 0, 0, 0);
-            }
-        }
-    };
+    typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+#define SGV_TN_COMPUTE(BUF)                                                                                   \
+    {                                                                                                         \
+        const unsigned char* sa_ = smem + (BUF) * 2 * TILEB;                                                  \
+        const unsigned char* sb_ = sa_ + TILEB;                                                               \
+        if constexpr (IS_BF16) {                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < KR / 16; ++ks) {                                          \
+                bf16x8 a0_, a1_, b0_, b1_;                                                                    \
+                if constexpr (USE_TR) {                                                                       \
+                    /* ds_read_b64_tr_b16: per 16-lane group g a 4(k) x 16(col) block; lane 4q+p of the  */   \
+                    /* group addresses row q, cols 4p..4p+3; lane i receives column i, rows 0..3.        */   \
+                    const int g_ = lane >> 4, q_ = (lane >> 2) & 3, pp_ = lane & 3;                           \
+                    const int kb_ = ks * 16 + 8 * (g_ >> 1) + q_;                                             \
+                    const int ca_ = wm * 64 + 16 * (g_ & 1) + 4 * pp_;                                        \
+                    const int cb_ = wn * 64 + 16 * (g_ & 1) + 4 * pp_;                                        \
+                    const unsigned char* pa_ = sa_ + (kb_ * LD + ca_) * 2;                                    \
+                    const unsigned char* pb_ = sb_ + (kb_ * LD + cb_) * 2;                                    \
+                    const s16x4 a0l_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa_));            \
+                    const s16x4 a0h_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa_ + 4 * LD * 2));   \
+                    const s16x4 a1l_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa_ + 64));       \
+                    const s16x4 a1h_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa_ + 64 + 4 * LD * 2)); \
+                    const s16x4 b0l_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb_));            \
+                    const s16x4 b0h_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb_ + 4 * LD * 2));   \
+                    const s16x4 b1l_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb_ + 64));       \
+                    const s16x4 b1h_ = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pb_ + 64 + 4 * LD * 2)); \
+                    a0_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a0l_, a0h_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+                    a1_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a1l_, a1h_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+                    b0_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b0l_, b0h_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+                    b1_ = __builtin_bit_cast(bf16x8, __builtin_shufflevector(b1l_, b1h_, 0, 1, 2, 3, 4, 5, 6, 7)); \
+                } else {                                                                                      \
+                    _Pragma("unroll") for (int e = 0; e < 8; ++e) {                                           \
+                        const int k_ = ks * 16 + 8 * lh + e;                                                  \
+                        a0_[e] = *reinterpret_cast<const bf16_t*>(sa_ + (k_ * LD + wm * 64 + lr) * 2);        \
+                        a1_[e] = *reinterpret_cast<const bf16_t*>(sa_ + (k_ * LD + wm * 64 + 32 + lr) * 2);   \
+                        b0_[e] = *reinterpret_cast<const bf16_t*>(sb_ + (k_ * LD + wn * 64 + lr) * 2);        \
+                        b1_[e] = *reinterpret_cast<const bf16_t*>(sb_ + (k_ * LD + wn * 64 + 32 + lr) * 2);   \
+                    }                                                                                         \
+                }                                                                                             \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
+            }                                                                                                 \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < KR / 2; ++ks) {                                           \
+                const int k_ = ks * 2 + lh;                                                                   \
+                const float a0_ = *reinterpret_cast<const float*>(sa_ + (k_ * LD + wm * 64 + lr) * 4);        \
+                const float a1_ = *reinterpret_cast<const float*>(sa_ + (k_ * LD + wm * 64 + 32 + lr) * 4);   \
+                const float b0_ = *reinterpret_cast<const float*>(sb_ + (k_ * LD + wn * 64 + lr) * 4);        \
+                const float b1_ = *reinterpret_cast<const float*>(sb_ + (k_ * LD + wn * 64 + 32 + lr) * 4);   \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);               \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);               \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);               \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);               \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
 
     if (s_begin < s_end) {
-        gload(s_begin);
-        sstore(0);
+        SGV_TN_GLOAD(s_begin);
+        SGV_TN_SSTORE(0);
         __syncthreads();
         int cur = 0;
-        for (int s = s_begin; s < s_end; ++s) {
-            const bool more = (s + 1) < s_end;
-            if (more) gload(s + 1);
-            compute(cur);
-            if (more) sstore(cur ^ 1);
+        for (int s = s_begin; s + 1 < s_end; ++s) {
+            SGV_TN_GLOAD(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            SGV_TN_COMPUTE(cur);
+            __builtin_amdgcn_sched_barrier(0);
+            SGV_TN_SSTORE(cur ^ 1);
             __syncthreads();
             cur ^= 1;
         }
+        SGV_TN_COMPUTE(cur);
     }
+#undef SGV_TN_GLOAD
+#undef SGV_TN_SSTORE
+#undef SGV_TN_COMPUTE
 
     // split-K: every (tile, tap, z) block owns its slab region -> plain stores, deterministic
     float* outp = p.out + (long)z * p.out_slab_stride + (long)tap * p.out_tap_stride;
