@@ -113,7 +113,8 @@ struct sgv_engine {
     double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
     float* partial = nullptr; size_t partial_floats = 0;
     float* xpose_tmp = nullptr; size_t xpose_floats = 0;
-    float* recon_unit = nullptr;   // [2][N] unit-scale dgamma/dbeta of the recon GroupNorm
+    float* recon_unit = nullptr;   // [3][N] unit-scale dgamma/dbeta/dbias of the recon head
+    float* colpart = nullptr; size_t colpart_floats = 0;   // per-block column-sum workspace
     SNDesc* sn_dev = nullptr; std::vector<SNDesc> sn_host;
     AdamDesc* adam_dev = nullptr; std::vector<AdamDesc> adam_host;
     WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr, *items_copy = nullptr;
@@ -497,7 +498,7 @@ static int alloc_activations(sgv_engine* e) {
         e->eps[i + 1] = f32buf(M * e->dec[i + 1]);
         e->zmap[i] = f32buf(M * e->dec[i + 1]);
     }
-    e->recon_unit = f32buf(2L * e->N);
+    e->recon_unit = f32buf(3L * e->N);
     // backward group sums mirror the forward slots
     e->n_stats = e->n_stats_fwd * 2;
     e->act_bytes = align_up(e->act_used, 256);
@@ -787,17 +788,18 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
             p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
             p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
             p.dgamma = e->grads + g.ggamma; p.dbeta = e->grads + g.gbeta;
-            ew_gn_bwd_reduce(e->dt, p, e->stream);
-            p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb;
+            p.dbias = e->grads + L.gb; p.part = e->colpart;
+            ew_gn_bwd_reduce(e->dt, p, e->stream);       // + finalize: sums2, dgamma, dbeta, dbias
+            p.out = S.dy.p; p.ldout = S.dy.ld;
             ew_gn_bwd_apply(e->dt, p, e->stream);
             dY = S.dy;
         } else if (S.act) {
             GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
-            p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb; p.B = B; p.T = e->T; p.C = L.cout;
+            p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
             ew_act(e->dt, 1, p, e->stream);
             dY = S.dy;
         } else {
-            GNParams p; p.y = dA.p; p.ldy = dA.ld; p.dbias = e->grads + L.gb; p.B = B; p.T = e->T; p.C = L.cout;
+            GNParams p; p.y = dA.p; p.ldy = dA.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
             ew_act(e->dt, 2, p, e->stream);
             dY = dA;
         }
@@ -867,6 +869,9 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     }
     if (pf < ((size_t)32 << 20)) pf = (size_t)32 << 20;   // batch < max_batch can pick deeper splits
     e->partial_floats = pf;
+    e->colpart_floats = 0;
+    for (auto& g : e->gns) e->colpart_floats = std::max(e->colpart_floats, ew_gn_part_floats(e->maxB, e->T, g.C));
+    for (auto& l : e->layers) if (l.op != OP_LINEAR) e->colpart_floats = std::max(e->colpart_floats, ew_gn_part_floats(e->maxB, e->T, l.cout));
     e->xpose_floats = (size_t)M * std::max(e->N, 8);
     for (int i = 0; i < e->n; ++i) e->xpose_floats = std::max(e->xpose_floats, (size_t)M * e->enc[i] * 2);
 #define ALLOC(ptr, bytes)                                                                                      \
@@ -889,6 +894,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
+    ALLOC(e->colpart, e->colpart_floats * 4);
 #undef ALLOC
     rebase_all(e);
     if ((r = upload_tables(e))) { sgv_destroy(e); return r; }
@@ -901,7 +907,7 @@ int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot,
-                    e->scal, e->partial, e->xpose_tmp, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy};
+                    e->scal, e->partial, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     delete e;
@@ -1185,9 +1191,10 @@ int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
         p.loss_sums = e->scal;
         if (e->write_xhat || !train) { p.out = e->xhat.p; p.ldout = e->xhat.ld; }
         if (train) {
-            HIPCHK(hipMemsetAsync(e->recon_unit, 0, 2L * e->N * 4, e->stream));
+            HIPCHK(hipMemsetAsync(e->recon_unit, 0, 3L * e->N * 4, e->stream));
             HIPCHK(hipMemsetAsync(e->stats + S.sums2, 0, (size_t)B * g.G * 2 * 8, e->stream));
             p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
+            p.dbias = e->recon_unit + 2L * e->N; p.part = e->colpart; p.gscale = 1.0f;
         }
         ew_recon_loss(e->dt, train, p, e->stream);
     }
@@ -1311,10 +1318,11 @@ int sgv_backward(sgv_engine* e, float alpha, float beta) {
         GNParams p = gn_base(e, g, B);
         p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
         p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type; p.gscale = gs;
-        p.out = e->dy_recon.p; p.ldout = e->dy_recon.ld; p.dbias = e->grads + L.gb;
+        p.out = e->dy_recon.p; p.ldout = e->dy_recon.ld;
         ew_recon_bwd_apply(e->dt, p, e->stream);
         ew_axpy(e->grads + g.ggamma, e->recon_unit, gs, e->N, e->stream);
         ew_axpy(e->grads + g.gbeta, e->recon_unit + e->N, gs, e->N, e->stream);
+        ew_axpy(e->grads + L.gb, e->recon_unit + 2L * e->N, gs, e->N, e->stream);
         CHK(conv_bwd_dw(e, L, e->dy_recon, e->dec_out[n_st - 1], M));
         CHK(conv_bwd_dx(e, L, e->dy_recon, e->d_out[n_st - 1], nullptr, M));
         fire();

@@ -18,7 +18,7 @@ struct GNGeom {
     int CV, RL, rowsplit;
     dim3 grid;
 };
-static GNGeom gn_geom(int B, int T, int C) {
+static GNGeom gn_geom(int B, int T, int C, int target = 2048) {
     GNGeom g;
     const int nv = C / 8;
     int cv = 1;
@@ -26,8 +26,8 @@ static GNGeom gn_geom(int B, int T, int C) {
     g.CV = cv;
     g.RL = 256 / cv;
     const int colblocks = cdiv_i(nv, cv);
-    // aim for >= ~2048 blocks, at least RL rows per block
-    int rs = cdiv_i(2048, (long)colblocks * B);
+    // aim for >= ~target blocks, at least RL rows per block
+    int rs = cdiv_i(target, (long)colblocks * B);
     int maxrs = cdiv_i(T, g.RL);
     if (rs > maxrs) rs = maxrs;
     if (rs < 1) rs = 1;
@@ -125,6 +125,32 @@ __device__ __forceinline__ void gn_block_reduce(const GNParams& p, const GNCtx& 
     }
 }
 
+// Contention-free alternative for the backward passes: every block writes its NARR column-sum arrays
+// (summed over the block's rows) to part[((b*RS + rowblock)*NARR + k)*C + c]; gn_bwd_finalize / colsum
+// finalize kernels combine them.  (Per-channel float atomics from ~700 blocks per address ran 10x over
+// the bandwidth bound.)
+template <int NARR>
+__device__ __forceinline__ void gn_block_colsums(const GNParams& p, const GNCtx& c, float (&col)[NARR][8]) {
+    __shared__ float sm[NARR][2048];
+    if (c.RL > 1) {
+#pragma unroll
+        for (int k = 0; k < NARR; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sm[k][(c.ty * p.CV + c.tx) * 8 + e] = col[k][e];
+        __syncthreads();
+    }
+    if (c.ty == 0 && c.col_ok) {
+        for (int r = 1; r < c.RL; ++r)
+#pragma unroll
+            for (int k = 0; k < NARR; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) col[k][e] += sm[k][(r * p.CV + c.tx) * 8 + e];
+        float* dst = p.part + ((long)(c.b * gridDim.y + blockIdx.y) * NARR) * p.C + c.c0;
+#pragma unroll
+        for (int k = 0; k < NARR; ++k) store8(dst + (long)k * p.C, col[k]);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
@@ -199,12 +225,12 @@ __device__ __forceinline__ float loss_val(int lt, float d) {
 template <typename T, int ACT, bool FROM_LOSS, bool TRAIN>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
-    float A[8], Bc[8], gam[8];
+    float col[3][8];   // A = sum dz, B = sum dz*xhat, X = sum xhat   (over this block's rows)
     float lsel = 0.f, lsq = 0.f;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { A[e] = 0.f; Bc[e] = 0.f; gam[e] = 0.f; }
+    for (int e = 0; e < 8; ++e) { col[0][e] = 0.f; col[1][e] = 0.f; col[2][e] = 0.f; }
     if (c.col_ok) {
-        float mean[8], rstd[8], bet[8];
+        float mean[8], rstd[8], gam[8], bet[8];
         gn_consts(p, c, mean, rstd);
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c.c0 + e]; bet[e] = p.beta[c.c0 + e]; }
@@ -231,8 +257,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
                 } else {
                     dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
                 }
-                A[e] += dz;
-                Bc[e] += dz * xh;
+                col[0][e] += dz;
+                col[1][e] += dz * xh;
+                col[2][e] += xh;
             }
             if constexpr (FROM_LOSS) {
                 if (xo) store8(xo + m * p.ldout + c.c0, v);
@@ -250,66 +277,101 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
             atomicAdd(&p.loss_sums[1], (double)(sml[1] + sml[3] + sml[5] + sml[7]));
         }
     }
-    if constexpr (TRAIN) gn_block_reduce(p, c, A, Bc, gam, p.dbeta, p.dgamma, p.sums2);
+    if constexpr (TRAIN) gn_block_colsums<3>(p, c, col);
 }
 
-// dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]; optional bias-grad column sums of dY.
+// One block per (group, sample): combine the row-block partials of gn_bwd_reduce_kernel into
+//   sums2[b][g] = (s1, s2) = (sum gamma*A, sum gamma*B)            (consumed by gn_bwd_apply_kernel)
+//   dbeta_c += A_c, dgamma_c += B_c                                  (atomics across the B samples only)
+//   dbias_c += gscale * rstd * (gamma_c*A_c - T*s1/n - (s2/n)*X_c)   (= column sum of dY, analytically)
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, int RS) {
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int c_lo = g * p.Cg, c_hi = c_lo + p.Cg;
+    const float* part = p.part + ((long)b * RS * 3) * p.C;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+        float A = 0.f, Bv = 0.f;
+        for (int r = 0; r < RS; ++r) { A += part[((long)r * 3 + 0) * p.C + c]; Bv += part[((long)r * 3 + 1) * p.C + c]; }
+        const float gm = p.gamma[c];
+        s1 += gm * A; s2 += gm * Bv;
+    }
+    __shared__ float sm[8];
+    const float w1 = wave_sum(s1), w2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { sm[(threadIdx.x >> 6) * 2] = w1; sm[(threadIdx.x >> 6) * 2 + 1] = w2; }
+    __syncthreads();
+    s1 = sm[0] + sm[2] + sm[4] + sm[6];
+    s2 = sm[1] + sm[3] + sm[5] + sm[7];
+    if (threadIdx.x == 0) {
+        p.sums2[((long)b * p.G + g) * 2 + 0] = (double)s1;
+        p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
+    }
+    const double n = (double)p.Cg * (double)p.T;
+    const double sm_ = p.sums[((long)b * p.G + g) * 2 + 0], ss_ = p.sums[((long)b * p.G + g) * 2 + 1];
+    const double mean = sm_ / n;
+    double var = ss_ / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float m1 = (float)((double)s1 / n), m2 = (float)((double)s2 / n);
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+        float A = 0.f, Bv = 0.f, X = 0.f;
+        for (int r = 0; r < RS; ++r) {
+            A += part[((long)r * 3 + 0) * p.C + c];
+            Bv += part[((long)r * 3 + 1) * p.C + c];
+            X += part[((long)r * 3 + 2) * p.C + c];
+        }
+        atomicAdd(p.dbeta + c, A);
+        atomicAdd(p.dgamma + c, Bv);
+        if (p.dbias) atomicAdd(p.dbias + c, p.gscale * rstd * (p.gamma[c] * A - (float)p.T * m1 - m2 * X));
+    }
+}
+
+// out[c] (+)= sum over `rows` partial rows of part[row][c]
+__global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int rows, int C, float* out) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int r = 0; r < rows; ++r) a += part[(long)r * C + c];
+    out[c] = a;
+}
+
+// dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]   (pure streaming pass: read y, dOut; write dY)
 template <typename T, int ACT, bool FROM_LOSS>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
-    float colD[8];
+    if (!c.col_ok) return;
+    float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8];
+    gn_consts(p, c, mean, rstd);
+    const double n = (double)p.Cg * (double)p.T;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) colD[e] = 0.f;
-    if (c.col_ok) {
-        float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8];
-        gn_consts(p, c, mean, rstd);
-        const double n = (double)p.Cg * (double)p.T;
+    for (int e = 0; e < 8; ++e) {
+        gam[e] = p.gamma[c.c0 + e];
+        bet[e] = p.beta[c.c0 + e];
+        const int g = (c.c0 + e) / p.Cg;
+        m1[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
+        m2[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
+    }
+    const T* y = reinterpret_cast<const T*>(p.y);
+    const T* dout = reinterpret_cast<const T*>(p.dout);
+    T* dy = reinterpret_cast<T*>(p.out);
+    for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+        const long m = (long)c.b * p.T + t;
+        float v[8], d[8];
+        load8(y + m * p.ldy + c.c0, v);
+        load8(dout + m * p.lddout + c.c0, d);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            gam[e] = p.gamma[c.c0 + e];
-            bet[e] = p.beta[c.c0 + e];
-            const int g = (c.c0 + e) / p.Cg;
-            m1[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
-            m2[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
-        }
-        const T* y = reinterpret_cast<const T*>(p.y);
-        const T* dout = reinterpret_cast<const T*>(p.dout);
-        T* dy = reinterpret_cast<T*>(p.out);
-        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
-            const long m = (long)c.b * p.T + t;
-            float v[8], d[8];
-            load8(y + m * p.ldy + c.c0, v);
-            load8(dout + m * p.lddout + c.c0, d);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xh = (v[e] - mean[e]) * rstd[e];
-                const float z = xh * gam[e] + bet[e];
-                float dz;
-                if constexpr (FROM_LOSS) {
-                    const float o = tanhf(z);
-                    dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
-                } else {
-                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
-                }
-                const float r = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
-                v[e] = r;
-                colD[e] += r;
+            const float xh = (v[e] - mean[e]) * rstd[e];
+            const float z = xh * gam[e] + bet[e];
+            float dz;
+            if constexpr (FROM_LOSS) {
+                const float o = tanhf(z);
+                dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
+            } else {
+                dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
             }
-            store8(dy + m * p.ldout + c.c0, v);
+            v[e] = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
         }
-    }
-    if (p.dbias) {
-        __shared__ float smA[2048];
-#pragma unroll
-        for (int e = 0; e < 8; ++e) smA[(c.ty * p.CV + c.tx) * 8 + e] = colD[e];
-        __syncthreads();
-        if (c.ty == 0 && c.col_ok) {
-            for (int r = 1; r < c.RL; ++r)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) colD[e] += smA[(r * p.CV + c.tx) * 8 + e];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(p.dbias + c.c0 + e, colD[e]);
-        }
+        store8(dy + m * p.ldout + c.c0, v);
     }
 }
 
@@ -339,18 +401,11 @@ __global__ __launch_bounds__(256) void act_kernel(const GNParams p) {
             if constexpr (MODE != 2) store8(out + m * p.ldout + c.c0, v);
         }
     }
-    if (MODE != 0 && p.dbias) {
-        __shared__ float smA[2048];
+    if (MODE != 0 && p.part) {
+        float col[1][8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) smA[(c.ty * p.CV + c.tx) * 8 + e] = colD[e];
-        __syncthreads();
-        if (c.ty == 0 && c.col_ok) {
-            for (int r = 1; r < c.RL; ++r)
-#pragma unroll
-                for (int e = 0; e < 8; ++e) colD[e] += smA[(r * p.CV + c.tx) * 8 + e];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) atomicAdd(p.dbias + c.c0 + e, colD[e]);
-        }
+        for (int e = 0; e < 8; ++e) col[0][e] = colD[e];
+        gn_block_colsums<1>(p, c, col);
     }
 }
 
@@ -363,6 +418,14 @@ static void gn_dispatch_fill(GNParams& p, int B, int T_, int C) {
 #define GN_LAUNCH(KERN, P, S)                                              \
     do {                                                                   \
         GNGeom g_ = gn_geom((P).B, (P).T, (P).C);                          \
+        (P).CV = g_.CV;                                                    \
+        hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P);             \
+    } while (0)
+// reduce-type kernels write per-block column sums: coarser row split keeps that workspace traffic small
+constexpr int GN_REDUCE_TARGET = 768;
+#define GN_LAUNCH_R(KERN, P, S)                                            \
+    do {                                                                   \
+        GNGeom g_ = gn_geom((P).B, (P).T, (P).C, GN_REDUCE_TARGET);        \
         (P).CV = g_.CV;                                                    \
         hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P);             \
     } while (0)
@@ -384,10 +447,19 @@ int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s) {
     }
     return 0;
 }
-int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s) {   // gelu, stored gradient
-    if (dtype == 1) GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);
-    else GN_LAUNCH((gn_bwd_reduce_kernel<float, 1, false, true>), p, s);
+static void gn_finalize(GNParams p, hipStream_t s) {
+    GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, s, p, g_.rowsplit);
+}
+int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s) {   // gelu, stored gradient; + finalize
+    if (dtype == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);
+    else GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 1, false, true>), p, s);
+    gn_finalize(p, s);
     return 0;
+}
+size_t ew_gn_part_floats(int B, int T, int C) {
+    GNGeom g_ = gn_geom(B, T, C, GN_REDUCE_TARGET);
+    return (size_t)B * g_.rowsplit * 3 * C;
 }
 int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s) {
     if (dtype == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 1, false>), p, s);
@@ -396,12 +468,13 @@ int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s) {
 }
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + loss (+ bwd reduce)
     if (dtype == 1) {
-        if (train) GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, true>), p, s);
+        if (train) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true>), p, s);
         else GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, false>), p, s);
     } else {
-        if (train) GN_LAUNCH((gn_bwd_reduce_kernel<float, 2, true, true>), p, s);
+        if (train) GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 2, true, true>), p, s);
         else GN_LAUNCH((gn_bwd_reduce_kernel<float, 2, true, false>), p, s);
     }
+    if (train) gn_finalize(p, s);
     return 0;
 }
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s) {
@@ -410,6 +483,15 @@ int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s) {
     return 0;
 }
 int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
+    if (mode == 0 || !p.dbias) p.part = nullptr;
+    if (p.part) {
+        if (dtype == 1) { if (mode == 1) GN_LAUNCH_R((act_kernel<bf16_t, 1>), p, s); else GN_LAUNCH_R((act_kernel<bf16_t, 2>), p, s); }
+        else { if (mode == 1) GN_LAUNCH_R((act_kernel<float, 1>), p, s); else GN_LAUNCH_R((act_kernel<float, 2>), p, s); }
+        // combine the per-block column sums into the bias gradient
+        GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 256)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
+        return 0;
+    }
     if (dtype == 1) {
         if (mode == 0) GN_LAUNCH((act_kernel<bf16_t, 0>), p, s);
         else if (mode == 1) GN_LAUNCH((act_kernel<bf16_t, 1>), p, s);

@@ -12,6 +12,7 @@ struct GNParams {
     float* dgamma = nullptr;
     float* dbeta = nullptr;
     float* dbias = nullptr;                        // bias gradient of the producing conv
+    float* part = nullptr;                         // workspace for per-block column sums (ew_gn_part_floats)
     double* sums = nullptr;                        // [B*G][2] sum, sum of squares
     double* sums2 = nullptr;                       // [B*G][2] backward group sums
     double* loss_sums = nullptr;                   // [2]
@@ -24,6 +25,7 @@ struct GNParams {
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s);
+size_t ew_gn_part_floats(int B, int T, int C);
 int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s);
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s);
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s);
