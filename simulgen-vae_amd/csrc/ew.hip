@@ -325,13 +325,17 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, 
     }
 }
 
-// out[c] (+)= sum over `rows` partial rows of part[row][c]
+// out[c] = sum over `rows` partial rows of part[row][c]; one block = 64 columns x 4 row-lanes
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int rows, int C, float* out) {
-    const int c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= C) return;
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int rl = threadIdx.x >> 6;
     float a = 0.f;
-    for (int r = 0; r < rows; ++r) a += part[(long)r * C + c];
-    out[c] = a;
+    if (c < C)
+        for (int r = rl; r < rows; r += 4) a += part[(long)r * C + c];
+    __shared__ float sm[4][64];
+    sm[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) out[c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
 // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]   (pure streaming pass: read y, dOut; write dY)
@@ -489,7 +493,7 @@ int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
         else { if (mode == 1) GN_LAUNCH_R((act_kernel<float, 1>), p, s); else GN_LAUNCH_R((act_kernel<float, 2>), p, s); }
         // combine the per-block column sums into the bias gradient
         GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 256)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 64)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
         return 0;
     }
     if (dtype == 1) {

@@ -10,16 +10,41 @@
 // (v_mfma_f32_32x32x16_bf16 / v_mfma_f32_32x32x2_f32), fp32 accumulation, register-staged
 // global->LDS double buffering with one barrier per K step.  16-byte global loads; K tails and
 // sample-boundary taps are zero-filled at chunk granularity.
+#include <math.h>
 #include "sgv_common.h"
 
+// minimum waves per SIMD asked of the register allocator for the GEMM kernels: 3 (168 VGPRs; a dozen
+// prologue/epilogue spills) measured 3-6 % faster end-to-end than the uncapped 220-VGPR build
+#ifndef SGV_GEMM_MIN_WAVES
+#define SGV_GEMM_MIN_WAVES 3
+#endif
+
 // zero a 16-byte chunk with an integer mask (0 or ~0): a plain AND cannot be turned into a memory select
+// XCD-aware block -> work-item map.  Blocks are dealt round-robin over the 8 XCDs (b and b+8 share an
+// XCD and its 4 MiB L2), so give XCD x the x-th CONTIGUOUS chunk of the logical order: the ~96 blocks
+// an XCD runs concurrently then form a compact patch of the tile grid and share operand panels in L2.
+// Bijective for any n (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
 __device__ __forceinline__ uint4 mask4(uint4 v, uint32_t m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); }
+
+// 16-byte buffer load: 32-bit byte offset against a wave-uniform descriptor; offsets at/after num_records
+// return zeros from the hardware range check, which is how masked taps / K tails / tile edges are zero-filled
+// (no branches, no mask registers).  OOB_OFF is above every operand size the launchers accept.
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+constexpr uint32_t OOB_OFF = 0x7FFFFFF0u;
+__device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t off) {
+    return __builtin_bit_cast(uint4, __builtin_amdgcn_raw_buffer_load_b128(r, off, 0, 0));
+}
 
 // =========================================================================================
 // NT
 // =========================================================================================
 template <typename T, int KCH>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
+__global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = KCH * EPC;
     constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -32,62 +57,66 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + 127) >> 7;
-    const int tm = blockIdx.x / tiles_n, tn = blockIdx.x - tm * tiles_n;
+    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+    const int ntiles = tiles_n * tiles_m;
+    // 1-D grid of ntiles*splitk blocks; split-K slice slowest, then the tile raster.  Raster: the LARGER
+    // operand is partitioned across XCDs (each XCD streams its part once), the smaller one is replicated:
+    // M >= N -> N fastest (consecutive blocks share the activation panel), else M fastest.
+    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    const int z = logical / ntiles;
+    const int tile = logical - z * ntiles;
+    int tm, tn;
+    if (p.M >= p.N) { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
+    else { tn = tile / tiles_m; tm = tile - tn * tiles_m; }
     const int m0 = tm << 7, n0 = tn << 7;
     const int kchunks = (p.K + BK - 1) / BK;
     const int total = p.taps * kchunks;
-    const int z = blockIdx.y;
     const int s_begin = (int)((long)total * z / p.splitk);
     const int s_end = (int)((long)total * (z + 1) / p.splitk);
 
     static_assert(LPT == 2, "two 16-byte load slots per operand per thread");
     const int kq = tid % KCH;
     const int r0 = tid / KCH;
-    const T* Ag = reinterpret_cast<const T*>(p.A);
-    const T* Wg = reinterpret_cast<const T*>(p.W);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
     // named scalars only (no per-thread arrays: hipcc demoted them to scratch memory)
     const int am0 = m0 + r0, am1 = m0 + r0 + RSTEP;
     const int wn0 = n0 + r0, wn1 = n0 + r0 + RSTEP;
     const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
     const bool wok0 = wn0 < p.N, wok1 = wn1 < p.N;
     const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
-    const long abase0 = (long)am0 * p.lda + kq * EPC, abase1 = (long)am1 * p.lda + kq * EPC;
-    const long wbase0 = (long)wn0 * p.ldw + kq * EPC, wbase1 = (long)wn1 * p.ldw + kq * EPC;
-    uint4 ra0, ra1, rw0, rw1;
-    uint32_t ma0 = 0u, ma1 = 0u, mw0 = 0u, mw1 = 0u;   // validity masks of the in-flight loads (applied at LDS-store time)
+    constexpr int ESZ = (int)sizeof(T);
+    const uint32_t abase0 = (uint32_t)(((long)am0 * p.lda + kq * EPC) * ESZ), abase1 = (uint32_t)(((long)am1 * p.lda + kq * EPC) * ESZ);
+    const uint32_t wbase0 = wok0 ? (uint32_t)(((long)wn0 * p.ldw + kq * EPC) * ESZ) : OOB_OFF;
+    const uint32_t wbase1 = wok1 ? (uint32_t)(((long)wn1 * p.ldw + kq * EPC) * ESZ) : OOB_OFF;
+    // two register sets (A, B): loads for tile s+2 are issued while tile s is multiplied and tile s+1 is
+    // still in flight (prefetch distance 2; the compiler's in-order vmcnt(4) retires only the older set)
+    uint4 ra0A, ra1A, rw0A, rw1A, ra0B, ra1B, rw0B, rw1B;
 
-    // Predicated loads without branches: masked-off lanes read a valid dummy address (offset 0) and the
-    // result is zero-selected (EXEC stays full; the four loads of a step issue back-to-back).
-#define SGV_NT_GLOAD(S)                                                                                       \
+#define SGV_NT_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
         const int j_ = (S) / kchunks;                                                                         \
         const int kc_ = ((S) - j_ * kchunks) * BK;                                                            \
         const int dt_ = j_ - p.pad;                                                                           \
         const bool kok_ = (kc_ + kq * EPC) < p.K;                                                             \
-        const long aoff_ = (long)dt_ * p.lda + kc_;                                                           \
-        const long woff_ = (long)j_ * p.w_tap_stride + kc_;                                                   \
+        const int aoff_ = (int)(((long)dt_ * p.lda + kc_) * ESZ);                                             \
+        const int woff_ = (int)(((long)j_ * p.w_tap_stride + kc_) * ESZ);                                     \
         const bool pa0 = aok0 && kok_ && ((unsigned)(at0 + dt_) < (unsigned)p.Tlen);                          \
         const bool pa1 = aok1 && kok_ && ((unsigned)(at1 + dt_) < (unsigned)p.Tlen);                          \
-        const bool pw0 = wok0 && kok_;                                                                        \
-        const bool pw1 = wok1 && kok_;                                                                        \
-        ma0 = pa0 ? ~0u : 0u; ma1 = pa1 ? ~0u : 0u; mw0 = pw0 ? ~0u : 0u; mw1 = pw1 ? ~0u : 0u;               \
-        ra0 = *reinterpret_cast<const uint4*>(Ag + (pa0 ? abase0 + aoff_ : 0L));                              \
-        ra1 = *reinterpret_cast<const uint4*>(Ag + (pa1 ? abase1 + aoff_ : 0L));                              \
-        rw0 = *reinterpret_cast<const uint4*>(Wg + (pw0 ? wbase0 + woff_ : 0L));                              \
-        rw1 = *reinterpret_cast<const uint4*>(Wg + (pw1 ? wbase1 + woff_ : 0L));                              \
+        ra0##X = bload16(rsA, pa0 ? abase0 + (uint32_t)aoff_ : OOB_OFF);                                      \
+        ra1##X = bload16(rsA, pa1 ? abase1 + (uint32_t)aoff_ : OOB_OFF);                                      \
+        rw0##X = bload16(rsW, kok_ ? wbase0 + (uint32_t)woff_ : OOB_OFF);                                     \
+        rw1##X = bload16(rsW, kok_ ? wbase1 + (uint32_t)woff_ : OOB_OFF);                                     \
     }
 #define SGV_NT_ST1(PTR, V)                                                                                    \
     if constexpr (IS_BF16) { *reinterpret_cast<uint4*>(PTR) = (V); }                                          \
     else { uint32_t* d_ = reinterpret_cast<uint32_t*>(PTR); d_[0] = (V).x; d_[1] = (V).y; d_[2] = (V).z; d_[3] = (V).w; }
-#define SGV_NT_SSTORE(BUF)                                                                                    \
+#define SGV_NT_SSTORE(BUF, X)                                                                                 \
     {                                                                                                         \
         unsigned char* sa_ = smem + (BUF) * 2 * TILEB + r0 * ROWB + kq * 16;                                  \
         unsigned char* sw_ = sa_ + TILEB;                                                                     \
-        const uint4 xa0_ = mask4(ra0, ma0), xa1_ = mask4(ra1, ma1);                                           \
-        const uint4 xw0_ = mask4(rw0, mw0), xw1_ = mask4(rw1, mw1);                                           \
-        SGV_NT_ST1(sa_, xa0_) SGV_NT_ST1(sa_ + RSTEP * ROWB, xa1_)                                            \
-        SGV_NT_ST1(sw_, xw0_) SGV_NT_ST1(sw_ + RSTEP * ROWB, xw1_)                                            \
+        SGV_NT_ST1(sa_, ra0##X) SGV_NT_ST1(sa_ + RSTEP * ROWB, ra1##X)                                        \
+        SGV_NT_ST1(sw_, rw0##X) SGV_NT_ST1(sw_ + RSTEP * ROWB, rw1##X)                                        \
     }
 
     f32x16 acc[2][2];
@@ -130,22 +159,46 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(const GemmNT p) {
         }                                                                                                     \
     }
 
+#define SGV_NT_STEP(XL, XS)    /* load tile s+2 into set XL, multiply tile s, stage set XS (tile s+1) */  \
+    {                                                                                                         \
+        SGV_NT_GLOAD(s + 2, XL);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);   /* keep hipcc from sinking the loads below the MFMAs */          \
+        SGV_NT_COMPUTE(cur);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        SGV_NT_SSTORE(cur ^ 1, XS);                                                                           \
+        __syncthreads();                                                                                      \
+        cur ^= 1; ++s;                                                                                        \
+    }
     if (s_begin < s_end) {
-        SGV_NT_GLOAD(s_begin);
-        SGV_NT_SSTORE(0);
+        int s = s_begin, cur = 0;
+        SGV_NT_GLOAD(s, A);
+        if (s + 1 < s_end) SGV_NT_GLOAD(s + 1, B);
+        SGV_NT_SSTORE(0, A);
         __syncthreads();
-        int cur = 0;
-        for (int s = s_begin; s + 1 < s_end; ++s) {
-            SGV_NT_GLOAD(s + 1);          // next tile's loads stay in flight under this tile's MFMAs
-            __builtin_amdgcn_sched_barrier(0);   // keep hipcc from sinking the loads below the MFMAs
+        // invariant at loop top: LDS[cur] holds tile s, set B holds tile s+1 (in flight)
+        while (s + 3 < s_end) {
+            SGV_NT_STEP(A, B)
+            SGV_NT_STEP(B, A)
+        }
+        const int rem = s_end - s;   // 1..3 tiles left
+        if (rem == 3) {
+            SGV_NT_STEP(A, B)
             SGV_NT_COMPUTE(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            SGV_NT_SSTORE(cur ^ 1);
+            SGV_NT_SSTORE(cur ^ 1, A);
             __syncthreads();
             cur ^= 1;
+            SGV_NT_COMPUTE(cur);
+        } else if (rem == 2) {
+            SGV_NT_COMPUTE(cur);
+            SGV_NT_SSTORE(cur ^ 1, B);
+            __syncthreads();
+            cur ^= 1;
+            SGV_NT_COMPUTE(cur);
+        } else {
+            SGV_NT_COMPUTE(cur);
         }
-        SGV_NT_COMPUTE(cur);
     }
+#undef SGV_NT_STEP
 #undef SGV_NT_GLOAD
 #undef SGV_NT_SSTORE
 #undef SGV_NT_ST1
@@ -207,7 +260,7 @@ __global__ __launch_bounds__(256) void gemm_nt_reduce_kernel(const GemmNT p) {
 // TN
 // =========================================================================================
 template <typename T, bool USE_TR>
-__global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
+__global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const GemmTN p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr bool IS_BF16 = sizeof(T) == 2;
     constexpr int KR = IS_BF16 ? 32 : 16;      // reduction rows (m) per step
@@ -222,10 +275,18 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_2 = (p.N2 + 127) >> 7;
-    const int t1 = blockIdx.x / tiles_2, t2 = blockIdx.x - t1 * tiles_2;
+    const int tiles_2 = (p.N2 + 127) >> 7, tiles_1 = (p.N1 + 127) >> 7;
+    const int ntiles = tiles_1 * tiles_2;
+    // 1-D grid: (tap, split-K slice) slowest, then the tile raster with the dimension that has fewer
+    // tiles fastest (consecutive blocks share the larger operand's panel), XCD-chunked.
+    const int logical = xcd_remap(blockIdx.x, ntiles * p.taps * p.splitk);
+    const int tz = logical / ntiles;
+    const int tile = logical - tz * ntiles;
+    int t1, t2;
+    if (p.N1 >= p.N2) { t1 = tile / tiles_2; t2 = tile - t1 * tiles_2; }
+    else { t2 = tile / tiles_1; t1 = tile - t2 * tiles_1; }
     const int i0 = t1 << 7, j0 = t2 << 7;
-    const int tap = blockIdx.y / p.splitk, z = blockIdx.y - tap * p.splitk;
+    const int tap = tz / p.splitk, z = tz - tap * p.splitk;
     const int dt = tap - p.pad;
     const int ksteps = (p.M + KR - 1) / KR;
     const int s_begin = (int)((long)ksteps * z / p.splitk);
@@ -233,36 +294,38 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 
     const int cq = tid % CPR;
     const int r0 = tid / CPR;
-    const T* Ag = reinterpret_cast<const T*>(p.A);
-    const T* Bg = reinterpret_cast<const T*>(p.B);
+    static_assert(LPT == 2, "two 16-byte load slots per operand per thread");
+    constexpr int ESZ = (int)sizeof(T);
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsB = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
     const bool a_cok = (i0 + cq * EPC) < p.N1;
     const bool b_cok = (j0 + cq * EPC) < p.N2;
-    static_assert(LPT == 2, "two 16-byte load slots per operand per thread");
-    uint4 ra0, ra1, rb0, rb1;
-    uint32_t ma0 = 0u, ma1 = 0u, mb0 = 0u, mb1 = 0u;
-    const long acol = i0 + cq * EPC, bcol = j0 + cq * EPC;
+    const uint32_t acol = a_cok ? (uint32_t)((i0 + cq * EPC) * ESZ) : OOB_OFF;
+    const uint32_t bcol = b_cok ? (uint32_t)((j0 + cq * EPC) * ESZ) : OOB_OFF;
+    const uint32_t lda_b = (uint32_t)(p.lda * ESZ), ldb_b = (uint32_t)(p.ldb * ESZ);
+    uint4 ra0A, ra1A, rb0A, rb1A, ra0B, ra1B, rb0B, rb1B;
 
-#define SGV_TN_GLOAD(S)                                                                                       \
+    // rows past M and taps that leave the sample window point out of range -> hardware returns zeros
+#define SGV_TN_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
         const int m0_ = (S) * KR + r0, m1_ = (S) * KR + r0 + RSTEP;                                           \
-        const bool pa0 = (m0_ < p.M) && a_cok, pa1 = (m1_ < p.M) && a_cok;                                    \
+        const bool pa0 = (m0_ < p.M), pa1 = (m1_ < p.M);                                                      \
         const int t0_ = m0_ % p.Tlen, t1_ = m1_ % p.Tlen;                                                     \
-        const bool pb0 = (m0_ < p.M) && b_cok && ((unsigned)(t0_ + dt) < (unsigned)p.Tlen);                   \
-        const bool pb1 = (m1_ < p.M) && b_cok && ((unsigned)(t1_ + dt) < (unsigned)p.Tlen);                   \
-        ma0 = pa0 ? ~0u : 0u; ma1 = pa1 ? ~0u : 0u; mb0 = pb0 ? ~0u : 0u; mb1 = pb1 ? ~0u : 0u;               \
-        ra0 = *reinterpret_cast<const uint4*>(Ag + (pa0 ? (long)m0_ * p.lda + acol : 0L));                    \
-        ra1 = *reinterpret_cast<const uint4*>(Ag + (pa1 ? (long)m1_ * p.lda + acol : 0L));                    \
-        rb0 = *reinterpret_cast<const uint4*>(Bg + (pb0 ? (long)(m0_ + dt) * p.ldb + bcol : 0L));             \
-        rb1 = *reinterpret_cast<const uint4*>(Bg + (pb1 ? (long)(m1_ + dt) * p.ldb + bcol : 0L));             \
+        const bool pb0 = pa0 && ((unsigned)(t0_ + dt) < (unsigned)p.Tlen);                                    \
+        const bool pb1 = pa1 && ((unsigned)(t1_ + dt) < (unsigned)p.Tlen);                                    \
+        ra0##X = bload16(rsA, pa0 ? (uint32_t)m0_ * lda_b + acol : OOB_OFF);                                  \
+        ra1##X = bload16(rsA, pa1 ? (uint32_t)m1_ * lda_b + acol : OOB_OFF);                                  \
+        rb0##X = bload16(rsB, pb0 ? (uint32_t)(m0_ + dt) * ldb_b + bcol : OOB_OFF);                           \
+        rb1##X = bload16(rsB, pb1 ? (uint32_t)(m1_ + dt) * ldb_b + bcol : OOB_OFF);                           \
     }
-#define SGV_TN_SSTORE(BUF)                                                                                    \
+#define SGV_TN_SSTORE(BUF, X)                                                                                 \
     {                                                                                                         \
         unsigned char* sa_ = smem + (BUF) * 2 * TILEB + r0 * ROWB + cq * 16;                                  \
         unsigned char* sb_ = sa_ + TILEB;                                                                     \
-        *reinterpret_cast<uint4*>(sa_) = mask4(ra0, ma0);                                                     \
-        *reinterpret_cast<uint4*>(sa_ + RSTEP * ROWB) = mask4(ra1, ma1);                                      \
-        *reinterpret_cast<uint4*>(sb_) = mask4(rb0, mb0);                                                     \
-        *reinterpret_cast<uint4*>(sb_ + RSTEP * ROWB) = mask4(rb1, mb1);                                      \
+        *reinterpret_cast<uint4*>(sa_) = ra0##X;                                                              \
+        *reinterpret_cast<uint4*>(sa_ + RSTEP * ROWB) = ra1##X;                                               \
+        *reinterpret_cast<uint4*>(sb_) = rb0##X;                                                              \
+        *reinterpret_cast<uint4*>(sb_ + RSTEP * ROWB) = rb1##X;                                               \
     }
 
     f32x16 acc[2][2];
@@ -332,22 +395,45 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
         }                                                                                                     \
     }
 
+#define SGV_TN_STEP(XL, XS)                                                                                  \
+    {                                                                                                         \
+        SGV_TN_GLOAD(s + 2, XL);                                                                              \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        SGV_TN_COMPUTE(cur);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        SGV_TN_SSTORE(cur ^ 1, XS);                                                                           \
+        __syncthreads();                                                                                      \
+        cur ^= 1; ++s;                                                                                        \
+    }
     if (s_begin < s_end) {
-        SGV_TN_GLOAD(s_begin);
-        SGV_TN_SSTORE(0);
+        int s = s_begin, cur = 0;
+        SGV_TN_GLOAD(s, A);
+        if (s + 1 < s_end) SGV_TN_GLOAD(s + 1, B);
+        SGV_TN_SSTORE(0, A);
         __syncthreads();
-        int cur = 0;
-        for (int s = s_begin; s + 1 < s_end; ++s) {
-            SGV_TN_GLOAD(s + 1);
-            __builtin_amdgcn_sched_barrier(0);
+        while (s + 3 < s_end) {
+            SGV_TN_STEP(A, B)
+            SGV_TN_STEP(B, A)
+        }
+        const int rem = s_end - s;
+        if (rem == 3) {
+            SGV_TN_STEP(A, B)
             SGV_TN_COMPUTE(cur);
-            __builtin_amdgcn_sched_barrier(0);
-            SGV_TN_SSTORE(cur ^ 1);
+            SGV_TN_SSTORE(cur ^ 1, A);
             __syncthreads();
             cur ^= 1;
+            SGV_TN_COMPUTE(cur);
+        } else if (rem == 2) {
+            SGV_TN_COMPUTE(cur);
+            SGV_TN_SSTORE(cur ^ 1, B);
+            __syncthreads();
+            cur ^= 1;
+            SGV_TN_COMPUTE(cur);
+        } else {
+            SGV_TN_COMPUTE(cur);
         }
-        SGV_TN_COMPUTE(cur);
     }
+#undef SGV_TN_STEP
 #undef SGV_TN_GLOAD
 #undef SGV_TN_SSTORE
 #undef SGV_TN_COMPUTE
@@ -375,30 +461,36 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(const GemmTN p) {
 // =========================================================================================
 static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Split-K choice: minimise (occupancy rounds) x (K steps per block) + the slab combine pass.
+// 256 CUs x 3 resident 256-thread blocks (40 KB LDS, ~150 VGPR) = 768 slots; a grid of 800 blocks takes
+// two rounds, so e.g. 200 tiles prefer 3 slices (600 blocks) over 4.
+static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int min_steps) {
+    const double slots = 768.0;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int sk = 1; sk <= 32; ++sk) {
+        if (sk > 1 && steps / sk < min_steps) break;
+        const double rounds = ceil((double)tiles * sk / slots);
+        const double per = ceil((double)steps / sk) + 8.0;             // + prologue/epilogue per block
+        double cost = rounds * per;
+        if (sk > 1) cost += (2.0 * sk * slab_bytes_per_slice / 3.0e12) / 0.6e-6;   // combine pass, in step units
+        if (cost < best_cost * 0.97) { best_cost = cost; best = sk; }
+    }
+    return best;
+}
+
 int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype) {
     const int bk = dtype == 1 ? 32 : 16;
-    const int tiles = cdiv(M, 128) * cdiv(N, 128);
-    const int total = taps * cdiv(K, bk);
-    if (tiles >= 384) return 1;
-    int want = cdiv(768, tiles);
-    int cap = total / 8;
-    if (cap < 1) cap = 1;
-    if (want > cap) want = cap;
-    if (want > 32) want = 32;
-    return want < 1 ? 1 : want;
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
+    const long total = (long)taps * cdiv(K, bk);
+    return pick_splitk(tiles, total, (double)M * N * 4.0, 8);
 }
 
 int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype) {
     const int kr = dtype == 1 ? 32 : 16;
-    const int tiles = cdiv(N1, 128) * cdiv(N2, 128) * taps;
-    const int total = cdiv(M, kr);
-    if (tiles >= 384) return 1;
-    int want = cdiv(768, tiles);
-    int cap = total / 4;
-    if (cap < 1) cap = 1;
-    if (want > cap) want = cap;
-    if (want > 32) want = 32;
-    return want < 1 ? 1 : want;
+    const long tiles = (long)cdiv(N1, 128) * cdiv(N2, 128) * taps;
+    const long total = cdiv(M, kr);
+    return pick_splitk(tiles, total, (double)taps * N1 * N2 * 4.0, 4);
 }
 
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
@@ -407,9 +499,14 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (p.K % epc || p.lda % epc || p.ldw % epc || p.w_tap_stride % epc) return -1;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.W & 15)) return -1;
     if (p.splitk > 1 && !p.partial) return -1;
-    dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128), p.splitk);
-    if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, p);
-    else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, p);
+    const int esz = dtype == 1 ? 2 : 4;
+    GemmNT q = p;
+    q.a_bytes = ((long)(p.M - 1) * p.lda + p.K) * esz;
+    q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
+    if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
+    dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk);
+    if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
+    else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
     if (p.splitk > 1) {
         long total = (long)p.M * p.N;
         int blocks = (int)((total + 255) / 256);
@@ -426,12 +523,17 @@ int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
     if (p.N1 % epc || p.N2 % epc || p.lda % epc || p.ldb % epc) return -1;
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15)) return -1;
     if (p.splitk > 1 && p.out_slab_stride <= 0) return -1;
-    dim3 grid(cdiv(p.N1, 128) * cdiv(p.N2, 128), p.taps * p.splitk);
+    const int esz = dtype == 1 ? 2 : 4;
+    GemmTN q = p;
+    q.a_bytes = ((long)(p.M - 1) * p.lda + p.N1) * esz;
+    q.b_bytes = ((long)(p.M - 1) * p.ldb + p.N2) * esz;
+    if (q.a_bytes >= 0x7FFFFFF0L || q.b_bytes >= 0x7FFFFFF0L) return -1;
+    dim3 grid(cdiv(p.N1, 128) * cdiv(p.N2, 128) * p.taps * p.splitk);
     if (dtype == 1) {
-        if (p.use_tr) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true>), grid, dim3(256), 0, s, p);
-        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, false>), grid, dim3(256), 0, s, p);
+        if (p.use_tr) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, false>), grid, dim3(256), 0, s, q);
     } else {
-        hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), 0, s, p);
+        hipLaunchKernelGGL((gemm_tn_kernel<float, false>), grid, dim3(256), 0, s, q);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

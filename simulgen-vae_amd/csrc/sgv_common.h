@@ -100,6 +100,7 @@ struct GemmNT {
     const float* scale;             // optional device scalar (1/sigma)
     float* partial;                 // split-K slabs [splitk][M][N] fp32
     int M, N, K, taps, pad, Tlen, splitk, out_f32;
+    long a_bytes, w_bytes;          // filled by launch_gemm_nt: extents for the buffer descriptors
 };
 struct GemmTN {
     const void* A; long lda;        // dY [M][lda], N1 columns used
@@ -108,6 +109,7 @@ struct GemmTN {
     long out_tap_stride;
     long out_slab_stride;
     int M, N1, N2, taps, pad, Tlen, splitk, use_tr;
+    long a_bytes, b_bytes;          // filled by launch_gemm_tn
 };
 
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s);

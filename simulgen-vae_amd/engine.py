@@ -15,7 +15,7 @@ import numpy as np
 from .spec import LOSS_IDS, VAEConfig, param_spec
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libsgvae.so")
+LIB_PATH = os.environ.get("SGV_LIB") or os.path.join(_HERE, "csrc", "libsgvae.so")
 MAX_LEVELS = 8
 MAX_SCALARS = 12
 DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
