@@ -110,6 +110,11 @@ int sgv_set_option(sgv_engine* e, const char* key, int value);
  * iteration runs (model.train()); mode_fix != 0: Decoder.forward(mode="fix") (decoder.py:209-210).
  * scalars_host (may be NULL): SGV_MAX_SCALARS floats, filled after a stream sync.  [sync if given] */
 int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host);
+/* Decoder.forward(z, xs, mode) from caller-supplied latents (utils.py:499, latent_conditioner_e2e.py:371,
+ * reconstruction_evaluator.py:174): z_dev fp32 [B,latent], xs_dev fp32 [n_levels-1][B,hier] in the list
+ * order Encoder.forward returns; eval-mode spectral norm.  Scalars as sgv_forward (the loss entries compare
+ * against whatever input is current and are meaningless without one).  Result via sgv_get_xhat. */
+int sgv_decode(sgv_engine* e, const float* z_dev, const float* xs_dev, int batch, int mode_fix, float* scalars_host);
 /* Encoder.forward only (utils.py:492): mu, log_var [B,latent], xs [n_levels-1][B,hier] to host. [sync] */
 int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host);
 /* Reconstruction of the last forward, reference layout [B, num_node, num_time] fp32 on device. */

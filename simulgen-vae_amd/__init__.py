@@ -7,3 +7,16 @@ reference's Python interface for this path).
 from .spec import VAEConfig, param_spec, layer_list  # noqa: F401
 
 __all__ = ["VAEConfig", "param_spec", "layer_list"]
+
+
+def install_reference_api():
+    """Make `import modules.<name>` resolve to this package's mirror of the reference interface
+    (modules.VAE_network.VAE, modules.train.train, modules.utils.parse_condition_file, ...), so scripts
+    written against the reference (SimulGen-VAE.py) run against the MI355X engine unchanged."""
+    import importlib
+    import sys
+    pkg = importlib.import_module(__name__ + ".modules")
+    sys.modules["modules"] = pkg
+    for sub in ("VAE_network", "train", "utils", "augmentation", "losses"):
+        sys.modules["modules." + sub] = importlib.import_module(__name__ + ".modules." + sub)
+    return pkg

@@ -1136,25 +1136,13 @@ static int encoder_fwd(sgv_engine* e, int B) {
     return 0;
 }
 
-int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
-    if (!e) return fail(SGV_ERR_ARG, "null engine");
-    if (e->batch < 1) return fail(SGV_ERR_STATE, "no input set");
-    if (train && mode_fix) return fail(SGV_ERR_ARG, "mode_fix is an inference path");
-    if (!e->copies_fresh) CHK(refresh_copies(e));
-    const int B = e->batch, n = e->n, n_st = e->n_st;
+// Decoder.forward (decoder.py:170-216) from e->zlat / e->xs_raw, then the recon head + loss pass.
+static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
+    const int n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
-    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
-    HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
-    CHK(run_sn(e, train));
-    CHK(encoder_fwd(e, B));
-    // noise
-    for (int s = 0; s < n_st; ++s) {
-        if (!e->eps_set[s]) {
-            const long cnt = s == 0 ? (long)B * e->Z : M * e->dec[s];
-            ew_randn(e->eps[s], cnt, e->seed, (e->draw++) * 8 + s, e->stream);
-        }
+    for (int s = 1; s < n_st; ++s) {
+        if (!e->eps_set[s]) ew_randn(e->eps[s], M * e->dec[s], e->seed, (e->draw++) * 8 + s, e->stream);
     }
-    ew_latent_fwd(e->last, e->eps[0], e->zlat, B, e->Z, e->scal + 2, e->stream);
     {
         const Layer& l = e->layers[e->start_lin];
         ew_linear_expand_fwd(e->dt, e->zlat, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->sbuf.p, B, l.cin, l.cout, e->stream);
@@ -1179,39 +1167,80 @@ int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
                      e->zs[i + 1].p, e->zs[i + 1].ld, e->zmap[i], (int)M, C, mode_fix ? 1e-10f : 1.0f, e->scal + 3 + i, 1.0f / B, e->stream);
     }
     // recon head: conv -> GroupNorm stats -> tanh + loss (+ backward reductions in training)
-    {
-        Stage& S = e->recon.st[0];
-        const Layer& L = e->layers[S.layer];
-        const GNLayer& g = e->gns[S.gn];
-        CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M));
-        GNParams p = gn_base(e, g, B);
-        p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
-        ew_gn_stats(e->dt, p, e->stream);
-        p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type;
-        p.loss_sums = e->scal;
-        if (e->write_xhat || !train) { p.out = e->xhat.p; p.ldout = e->xhat.ld; }
-        if (train) {
-            HIPCHK(hipMemsetAsync(e->recon_unit, 0, 3L * e->N * 4, e->stream));
-            HIPCHK(hipMemsetAsync(e->stats + S.sums2, 0, (size_t)B * g.G * 2 * 8, e->stream));
-            p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
-            p.dbias = e->recon_unit + 2L * e->N; p.part = e->colpart; p.gscale = 1.0f;
-        }
-        ew_recon_loss(e->dt, train, p, e->stream);
+    Stage& S = e->recon.st[0];
+    const Layer& L = e->layers[S.layer];
+    const GNLayer& g = e->gns[S.gn];
+    CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M));
+    GNParams p = gn_base(e, g, B);
+    p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
+    ew_gn_stats(e->dt, p, e->stream);
+    p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type;
+    p.loss_sums = e->scal;
+    if (e->write_xhat || !train) { p.out = e->xhat.p; p.ldout = e->xhat.ld; }
+    if (train) {
+        HIPCHK(hipMemsetAsync(e->recon_unit, 0, 3L * e->N * 4, e->stream));
+        p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
+        p.dbias = e->recon_unit + 2L * e->N; p.part = e->colpart; p.gscale = 1.0f;
     }
+    ew_recon_loss(e->dt, train, p, e->stream);
+    return 0;
+}
+
+static int read_scalars(sgv_engine* e, int B, float* scalars_host) {
+    double h[16];
+    HIPCHK(hipMemcpyAsync(h, e->scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    const double numel = (double)B * e->T * e->N;
+    for (int i = 0; i < SGV_MAX_SCALARS; ++i) scalars_host[i] = 0.f;
+    scalars_host[0] = (float)(h[0] / numel);
+    scalars_host[1] = (float)h[2];
+    for (int i = 0; i + 1 < e->n_st; ++i) scalars_host[2 + i] = (float)h[3 + i];
+    scalars_host[1 + e->n_st] = (float)(h[1] / numel);
+    return 0;
+}
+
+int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (e->batch < 1) return fail(SGV_ERR_STATE, "no input set");
+    if (train && mode_fix) return fail(SGV_ERR_ARG, "mode_fix is an inference path");
+    if (!e->copies_fresh) CHK(refresh_copies(e));
+    const int B = e->batch;
+    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
+    CHK(run_sn(e, train));
+    CHK(encoder_fwd(e, B));
+    if (!e->eps_set[0]) ew_randn(e->eps[0], (long)B * e->Z, e->seed, (e->draw++) * 8, e->stream);
+    ew_latent_fwd(e->last, e->eps[0], e->zlat, B, e->Z, e->scal + 2, e->stream);
+    CHK(decoder_fwd(e, B, train, mode_fix));
     e->have_fwd = true;
     e->fwd_train = train != 0;
-    for (int s = 0; s < n_st; ++s) e->eps_set[s] = 0;
-    if (scalars_host) {
-        double h[16];
-        HIPCHK(hipMemcpyAsync(h, e->scal, sizeof(h), hipMemcpyDeviceToHost, e->stream));
-        HIPCHK(hipStreamSynchronize(e->stream));
-        const double numel = (double)M * e->N;
-        for (int i = 0; i < SGV_MAX_SCALARS; ++i) scalars_host[i] = 0.f;
-        scalars_host[0] = (float)(h[0] / numel);
-        scalars_host[1] = (float)h[2];
-        for (int i = 0; i + 1 < n_st; ++i) scalars_host[2 + i] = (float)h[3 + i];
-        scalars_host[1 + n_st] = (float)(h[1] / numel);
+    for (int s = 0; s < e->n_st; ++s) e->eps_set[s] = 0;
+    if (scalars_host) CHK(read_scalars(e, B, scalars_host));
+    return SGV_OK;
+}
+
+int sgv_decode(sgv_engine* e, const float* z_dev, const float* xs_dev, int batch, int mode_fix, float* scalars_host) {
+    if (!e || !z_dev) return fail(SGV_ERR_ARG, "null argument");
+    if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "batch %d outside [1,%d]", batch, e->maxB);
+    if (!e->copies_fresh) CHK(refresh_copies(e));
+    const int B = batch;
+    e->batch = B;
+    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
+    CHK(run_sn(e, 0));
+    HIPCHK(hipMemcpyAsync(e->zlat, z_dev, (size_t)B * e->Z * 4, hipMemcpyDeviceToDevice, e->stream));
+    if (xs_dev) {
+        // list order of Encoder.forward's return: [xs_{n-2}, ..., xs_0]
+        for (int j = 0; j < e->n - 1; ++j)
+            HIPCHK(hipMemcpyAsync(e->xs_raw[e->n - 2 - j], xs_dev + (size_t)j * B * e->H, (size_t)B * e->H * 4, hipMemcpyDeviceToDevice, e->stream));
+    } else {
+        return fail(SGV_ERR_ARG, "sgv_decode needs xs (Decoder.forward with xs=None leaves z unchanged between stages in the reference; not supported)");
     }
+    CHK(decoder_fwd(e, B, 0, mode_fix));
+    e->have_fwd = true;
+    e->fwd_train = false;
+    for (int s = 0; s < e->n_st; ++s) e->eps_set[s] = 0;
+    if (scalars_host) CHK(read_scalars(e, B, scalars_host));
     return SGV_OK;
 }
 

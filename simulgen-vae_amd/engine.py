@@ -24,7 +24,7 @@ DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 ABI_SYMBOLS = [
     "sgv_last_error", "sgv_create", "sgv_destroy", "sgv_param_count", "sgv_param_info", "sgv_load_state",
     "sgv_export_state", "sgv_export_grad", "sgv_export_adam", "sgv_prepare", "sgv_set_input", "sgv_set_eps",
-    "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
+    "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
@@ -73,6 +73,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.sgv_forward.argtypes = [vp, i32, i32, vp]
     lib.sgv_encode.argtypes = [vp, vp, vp, vp]
+    lib.sgv_decode.argtypes = [vp, vp, vp, i32, i32, vp]
     lib.sgv_get_xhat.argtypes = [vp, vp]
     lib.sgv_get_activation.argtypes = [vp, C.c_char_p, vp, C.c_size_t]
     lib.sgv_backward.argtypes = [vp, f32, f32]
@@ -216,6 +217,18 @@ class Engine:
             return None
         n = self.n_kl
         return dict(recon=buf[0], kls=[buf[1 + i] for i in range(n)], mse=buf[1 + n])
+
+    def decode(self, z, xs, fix: bool = False):
+        """Decoder.forward(z, xs, mode): z torch fp32 CUDA [B,latent]; xs list of [B,hier] in Encoder order."""
+        t = self.torch
+        B = z.shape[0]
+        xs_t = t.stack([x.to(t.float32) for x in xs]).contiguous().cuda()
+        z = z.to(t.float32).contiguous().cuda()
+        buf = (C.c_float * MAX_SCALARS)()
+        _check(self.lib, self.lib.sgv_decode(self.h, C.c_void_p(z.data_ptr()), C.c_void_p(xs_t.data_ptr()), B, int(fix), buf),
+               "sgv_decode")
+        self.batch = B
+        return [buf[2 + i] for i in range(self.n_kl - 1)]
 
     def encode(self):
         B, Z, Hd = self.batch, self.cfg.latent_dim, self.cfg.hierarchical_dim

@@ -1,0 +1,174 @@
+"""`train()` with the signature, schedules, log line, return values and output files of the reference's
+modules.train.train (modules/train.py:50-256); the step itself runs in libsgvae.so.
+
+Deviations, on purpose: scalar losses are accumulated per step but read back without forcing a
+device sync per parameter tensor (the reference does ~200 `.item()` per step, train.py:156-174);
+under torch.distributed the gradients are averaged with an overlapped RCCL all-reduce (the
+reference's --use_ddp never synchronises gradients)."""
+from __future__ import annotations
+
+import logging
+import math
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from .VAE_network import VAE
+
+
+class WarmupKLLoss:
+    """train.py:18-41."""
+
+    def __init__(self, epoch, init_beta, start_warmup, end_warmup, beta_target):
+        self.epoch, self.init_beta = epoch, init_beta
+        self.start_warmup, self.end_warmup, self.beta_target = start_warmup, end_warmup, beta_target
+
+    def get_loss(self, step, losses):
+        loss = 0
+        for l in losses:
+            loss += l
+        if step < self.start_warmup:
+            beta = self.init_beta
+        elif self.start_warmup <= step < self.end_warmup:
+            beta = (step - self.start_warmup) * (self.beta_target - self.init_beta) / (self.end_warmup - self.start_warmup) \
+                + self.init_beta
+        else:
+            beta = self.beta_target
+        return [beta, loss]
+
+
+def cosine_warm_restarts_lr(base_lr, epochs, epoch, t_mult=2, eta_min_factor=1e-4):
+    """LR in effect during `epoch`: CosineAnnealingWarmRestarts(T_0=epochs//4, T_mult=2, eta_min=LR*1e-4)
+    stepped once per epoch (train.py:94-96,237)."""
+    t0 = epochs // 4
+    if t0 <= 0:
+        raise ValueError(f"Expected positive integer T_0, but got {t0}")   # torch's message; epochs < 4
+    eta_min = base_lr * eta_min_factor
+    t_i, t_cur = t0, epoch
+    while t_cur >= t_i:
+        t_cur -= t_i
+        t_i *= t_mult
+    return eta_min + (base_lr - eta_min) * (1 + math.cos(math.pi * t_cur / t_i)) / 2
+
+
+class _DevArray:
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+
+
+class GradAllReduce:
+    """Bucketed, overlapped mean all-reduce of the engine's flat gradient arena over RCCL."""
+
+    def __init__(self, engine):
+        ptr, n = engine.grad_buffer()
+        self.flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+        self.pending = []
+        engine.set_bucket_callback(self._on_bucket)
+
+    def _on_bucket(self, b, off, cnt):
+        self.pending.append(dist.all_reduce(self.flat[off:off + cnt], op=dist.ReduceOp.AVG, async_op=True))
+
+    def __call__(self, engine):
+        for w in self.pending:
+            w.wait()
+        self.pending.clear()
+
+
+def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_enc, num_filter_dec, num_node, latent_dim,
+          hierarchical_dim, num_time, alpha, lossfun, small, load_all, debug_mode=0, compute_dtype="bf16"):
+    logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
+    rank = dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+    world = dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    if rank == 0:
+        os.makedirs("checkpoints", exist_ok=True)
+        os.makedirs("output", exist_ok=True)
+        os.makedirs("model_save", exist_ok=True)
+    # schedulers first: the reference fails here for epochs < 4 before any step runs (train.py:94-96)
+    cosine_warm_restarts_lr(LR, epochs, 0)
+    model = VAE(latent_dim, hierarchical_dim, num_filter_enc, num_filter_dec, num_node, num_time, lossfun=lossfun,
+                batch_size=batch_size, small=small, use_checkpointing=False, compute_dtype=compute_dtype)
+    eng = model._eng(batch_size)
+    eng.set_option("write_xhat", 0)
+    warmup_kl = WarmupKLLoss(epochs, 1e-4, int(epochs * 0.3), int(epochs * 0.8), 1)   # init_beta hard-coded
+    allreduce = GradAllReduce(eng) if world > 1 else None
+    fused = hasattr(train_dataloader, "batch_plans")
+    data = train_dataloader.resident(eng) if fused else None
+
+    loss_print = np.zeros(epochs)
+    loss_val_print = np.zeros(epochs)
+    recon_print = np.zeros(epochs)
+    kl_print = np.zeros(epochs)
+    recon_loss_val_print = np.zeros(epochs)
+
+    def run_forward_losses(sc, beta):
+        kl = float(sum(sc["kls"]))
+        recon = sc["recon"] * alpha
+        return recon + kl * beta, recon, kl * beta
+
+    for epoch in range(epochs):
+        t_start = time.time()
+        model.train(True)
+        beta, _ = warmup_kl.get_loss(epoch, [])
+        lr = cosine_warm_restarts_lr(LR, epochs, epoch)
+        loss_save = recon_save = kl_save = 0.0
+        grad_sum, nb = 0.0, 0
+        batches = train_dataloader.batch_plans() if fused else iter(train_dataloader)
+        for item in batches:
+            if fused:
+                idx, seeds, scale, mix, lam = item
+                eng.augment_collate(data, idx, seeds, scale, mix, lam)
+            else:
+                eng.set_input(model._prep(item))
+            sc = eng.forward(train=True)
+            eng.backward(alpha, beta)
+            if allreduce is not None:
+                allreduce(eng)
+            grad_sum += eng.grad_norm()
+            eng.adamw_step(lr)
+            l, r, k = run_forward_losses(sc, beta)
+            loss_save += l
+            recon_save += r
+            kl_save += k
+            nb += 1
+        if nb == 0:
+            raise ZeroDivisionError("empty training loader")
+        if epoch % 20 == 0 or epoch == epochs - 1:
+            model.eval()
+            vl = vr = 0.0
+            vb = 0
+            vbatches = val_dataloader.batch_plans() if hasattr(val_dataloader, "batch_plans") else iter(val_dataloader)
+            for item in vbatches:
+                if hasattr(val_dataloader, "batch_plans"):
+                    idx, seeds, scale, mix, lam = item
+                    eng.augment_collate(val_dataloader.resident(eng), idx, seeds, scale, mix, lam)
+                else:
+                    eng.set_input(model._prep(item))
+                sc = eng.forward(train=False)
+                l, r, _ = run_forward_losses(sc, beta)
+                vl += l
+                vr += r
+                vb += 1
+            loss_val_print[epoch] = vl / vb            # ZeroDivisionError on an empty split, as the reference (D7)
+            recon_loss_val_print[epoch] = vr / vb
+            model.train()
+        elif epoch > 0:
+            loss_val_print[epoch] = loss_val_print[epoch - 1]
+            recon_loss_val_print[epoch] = recon_loss_val_print[epoch - 1]
+        loss_print[epoch] = loss_save / nb
+        recon_print[epoch] = recon_save / nb
+        kl_print[epoch] = kl_save / beta / nb
+        dur = time.time() - t_start
+        if rank == 0:
+            logging.info("\r[Epoch {}/{}] Loss: {:.4E}   val_loss: {:.2E}   Recon:{:.4E}   Recon_val:{:.4E}   KL:{:.4E}   "
+                         "Beta:{:.4E}   AvgGrad:{:.4E}   Time: {:.2f}s   ETA: {:.2f}h    LR: {:.2E}".format(
+                             epoch + 1, epochs, loss_print[epoch], loss_val_print[epoch], recon_print[epoch],
+                             recon_loss_val_print[epoch], kl_print[epoch], beta, grad_sum / nb, dur,
+                             (epochs - epoch) * dur / 3600, lr))
+    if rank == 0:
+        torch.save(model.state_dict(), "checkpoints/SimulGen-VAE.pth")
+        torch.save(model, "model_save/SimulGen-VAE")
+    train.last_model = model
+    return loss_print, recon_print, kl_print, loss_val_print

@@ -1,0 +1,183 @@
+"""CPU tests of the host-side mirror (simulgen-vae_amd/modules): config parsing, schedules, the
+augmentation draw order, and the data-parallel definition with 2 gloo ranks."""
+import os
+import random
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+import simulgen_vae_amd
+from simulgen_vae_amd.init import init_state, synthetic_eps, synthetic_samples
+from simulgen_vae_amd.spec import VAEConfig, param_spec
+
+simulgen_vae_amd.install_reference_api()
+from modules import augmentation as aug  # noqa: E402
+from modules import train as tr  # noqa: E402
+from modules import utils as ut  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden")
+
+CONDITION = """Common params
+Dim1		8 # number of parameters
+Dim2		32 # number of timesteps
+Dim3		4096 # num nodes
+num_var 1
+RESERVED	0
+RESERVED	7
+'
+%LSH-VAE parameters
+Training_epochs	4
+Batch_size	4
+LearningR	0.001
+Latent_dim	8	# Hierarchical latent Dim1
+Latent_dim_end	32 # Main latent Dim1
+Loss_type	3	# 1: MSE, 2, MAE, 3: smoothL1, 4: Huber
+Stretch	0
+alpha		1000000
+Recon_iter	1
+Dim2_red		32
+Dim3_start      0
+Dim3_end		4096
+'
+%LatentConditioner
+num_param	0
+param_dir	/images
+n_epoch	5000
+latent_conditioner_lr	0.001	# comment
+latent_conditioner_batch	64
+input_type	image	#image, csvs
+param_data_type .png
+"""
+
+
+def test_condition_file_and_preset(tmp_path):
+    f = tmp_path / "condition.txt"
+    f.write_text(CONDITION)
+    p = ut.parse_condition_file(str(f))
+    assert p["RESERVED"] == "7"                  # last duplicate key wins
+    assert "%LSH-VAE" not in p and "Common" in p  # section markers skipped; 'Common params' is a key/value line
+    c = ut.parse_training_parameters(p)
+    assert (c["num_param"], c["num_time"], c["num_node"], c["batch_size"], c["n_epochs"]) == (8, 32, 4096, 4, 4)
+    assert c["latent_dim"] == 8 and c["latent_dim_end"] == 32 and c["alpha"] == 1000000 and c["LR"] == 1e-3
+    assert ut.LOSS_NAMES[c["loss_type"]] == "smoothL1"
+    assert c["latent_conditioner_weight_decay"] == 1e-4 and c["use_e2e_training"] == 0   # defaults
+    del p["alpha"]
+    with pytest.raises(KeyError):
+        ut.parse_training_parameters(p)
+    pre = tmp_path / "preset.txt"
+    pre.write_text("data_No, init_beta_divisior, num_filter_enc, latent_conditioner_filter\n1\n0\n1024 512 256 128\n32 64 128\n")
+    r = ut.read_preset(str(pre))
+    assert r["num_filter_enc"] == [1024, 512, 256, 128] and r["data_No"] == 1
+
+
+def test_schedules_match_reference_golden():
+    g = np.load(os.path.join(GOLD, "schedules.npz"))
+    for E in (4, 8, 20, 40):
+        np.testing.assert_allclose([tr.cosine_warm_restarts_lr(1e-3, E, e) for e in range(E)], g[f"lr_E{E}"], rtol=1e-9)
+    for E in (4, 10, 20):
+        w = tr.WarmupKLLoss(E, 1e-4, int(E * 0.3), int(E * 0.8), 1)
+        np.testing.assert_allclose([w.get_loss(e, [0.0])[0] for e in range(E)], g[f"beta_E{E}"], rtol=1e-12)
+    with pytest.raises(ValueError):
+        tr.cosine_warm_restarts_lr(1e-3, 3, 0)
+
+
+def test_augmentation_draw_order_matches_reference(monkeypatch):
+    """Replay the reference's recorded random draws through AugmentedDataset.plan: same decisions,
+    scale factors, mixup partners and lambdas, and (with the recorded noise) the same samples."""
+    g = np.load(os.path.join(GOLD, "augment.npz"))
+    P, N, T = g["shape"]
+    data = synthetic_samples(20251003, range(P), N, T)
+    rand, randint, beta, noise = list(g["rand"]), list(g["randint"]), list(g["beta"]), list(g["noise"])
+
+    class R:
+        random = staticmethod(lambda: rand.pop(0))
+        randint = staticmethod(lambda a, b: int(randint.pop(0)))
+        getrandbits = staticmethod(lambda k: 12345)
+
+    monkeypatch.setattr(aug, "random", R)
+    monkeypatch.setattr(aug.np.random, "beta", lambda a, b: beta.pop(0))
+    ds = aug.AugmentedDataset(data, load_all=False)
+    for i in range(P):
+        # the reference draws the noise decision first; getrandbits is ours and consumes nothing recorded
+        seed, scale, mix, lam = ds.plan(i)
+        x = data[i].copy()
+        if seed:
+            x = x + noise.pop(0) * np.float32(0.05)
+        x = x * np.float32(scale)
+        if mix >= 0:
+            x = lam * x + (1 - lam) * data[mix]
+        np.testing.assert_allclose(x, g["out"][i], rtol=1e-6, atol=1e-7)
+    assert not rand and not randint and not beta and not noise
+
+
+def test_loader_split_and_sharding():
+    torch.manual_seed(0)
+    random.seed(0)
+    x = np.zeros((10, 8, 4), np.float32)
+    tl, vl = aug.create_augmented_dataloaders(x, batch_size=3, load_all=False)
+    assert len(tl.indices) == 8 and len(vl.indices) == 2 and not set(tl.indices) & set(vl.indices)
+    plans = list(tl.batch_plans())
+    assert [len(p[0]) for p in plans] == [3, 3, 2]
+    assert sorted(i for p in plans for i in p[0]) == sorted(tl.indices)
+    assert all(p[1] == [0] * len(p[0]) and p[3] == [-1] * len(p[0]) for p in vl.batch_plans())   # no aug on val
+    idx = list(range(11))
+    a, b = ut.shard_indices(idx, 0, 2, 3), ut.shard_indices(idx, 1, 2, 3)
+    assert len(a) == len(b) == 5 and not set(a) & set(b)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _ddp_worker(rank, world, port, out):
+    import torch.distributed as dist
+    from oracle import vae_oracle as vo
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    enc = [32, 16, 8, 8]
+    cfg = VAEConfig(32, 8, enc, enc[::-1], 72, 10, "MSE", True)
+    B = 4
+    x = synthetic_samples(20251003, range(B), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(1234, 0, cfg, B)
+    sl = slice(rank * B // world, (rank + 1) * B // world)
+    m = vo.OracleVAE(cfg, init_state(cfg, 7))
+    m.forward(x[sl], [e[sl] for e in eps])
+    grads = m.backward(1e6, 1e-4)
+    names = [e.name for e in param_spec(cfg) if grads.get(e.name) is not None]
+    flat = torch.from_numpy(np.concatenate([grads[n].ravel() for n in names]))
+    # bucketed mean all-reduce exactly as modules.train.GradAllReduce issues it (offset/count slices)
+    nb = 5
+    edges = np.linspace(0, flat.numel(), nb + 1).astype(int)
+    works = [dist.all_reduce(flat[edges[i]:edges[i + 1]], op=dist.ReduceOp.SUM, async_op=True) for i in range(nb)]
+    for w in works:
+        w.wait()
+    flat /= world
+    if rank == 0:
+        np.save(out, flat.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_mean_gradient_equals_full_batch(tmp_path):
+    """DDP definition: mean over ranks of per-shard gradients == single-process gradient of
+    the concatenated batch (every loss term is a batch mean, GroupNorm is per-sample)."""
+    import torch.multiprocessing as mp
+    from oracle import vae_oracle as vo
+    out = str(tmp_path / "g.npy")
+    mp.spawn(_ddp_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    got = np.load(out)
+    enc = [32, 16, 8, 8]
+    cfg = VAEConfig(32, 8, enc, enc[::-1], 72, 10, "MSE", True)
+    x = synthetic_samples(20251003, range(4), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(1234, 0, cfg, 4)
+    m = vo.OracleVAE(cfg, init_state(cfg, 7))
+    m.forward(x, eps)
+    grads = m.backward(1e6, 1e-4)
+    ref = np.concatenate([grads[e.name].ravel() for e in param_spec(cfg) if grads.get(e.name) is not None])
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-5
