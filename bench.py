@@ -86,6 +86,7 @@ def main():
     ap.add_argument("--dataset", type=int, default=64, help="synthetic samples resident in HBM per rank")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
     args = ap.parse_args()
 
@@ -242,6 +243,7 @@ def main():
                 cores = len(os.sched_getaffinity(0))
             except Exception:
                 pass
+            cores = min(cores, args.cpu_threads)   # a 1-GPU box's CPU share is 16 cores; 256 torch threads thrash
             v, dt, r = cpu_baseline(args.cpu_sample_batch, cores)
             result["cpu_baseline"] = {"value": round(v, 4), "unit": "samples/s", "cores": cores, "kind": "port",
                                       "sample": f"oracle/torch_port.py (PyTorch-CPU fp32 port of the reference step), 1 timed "

@@ -11,6 +11,7 @@
 // global->LDS double buffering with one barrier per K step.  16-byte global loads; K tails and
 // sample-boundary taps are zero-filled at chunk granularity.
 #include <math.h>
+#include <stdlib.h>
 #include "sgv_common.h"
 
 // minimum waves per SIMD asked of the register allocator for the GEMM kernels: 3 (168 VGPRs; a dozen
@@ -28,6 +29,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     const int q = n >> 3, r = n & 7;
     const int xcd = bid & 7, local = bid >> 3;
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + local;
+}
+// Grouped raster inside an XCD chunk: patches of 8 tile-rows, row index fastest inside a patch, so the ~96
+// blocks an XCD runs at once cover an ~8 x 12 patch and share ~20 operand panels (which fit its 4 MiB L2)
+// instead of the ~45 of a thin strip.
+__device__ __forceinline__ void grouped_raster(int pid, int tiles_r, int tiles_c, int& tr, int& tc) {
+    constexpr int G = 8;
+    const int per_group = G * tiles_c;
+    const int gid = pid / per_group;
+    const int first = gid * G;
+    const int gsz = min(tiles_r - first, G);
+    const int in_g = pid - gid * per_group;
+    tc = in_g / gsz;
+    tr = first + (in_g - tc * gsz);
 }
 __device__ __forceinline__ uint4 mask4(uint4 v, uint32_t m) { return make_uint4(v.x & m, v.y & m, v.z & m, v.w & m); }
 
@@ -59,15 +73,12 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
     const int ntiles = tiles_n * tiles_m;
-    // 1-D grid of ntiles*splitk blocks; split-K slice slowest, then the tile raster.  Raster: the LARGER
-    // operand is partitioned across XCDs (each XCD streams its part once), the smaller one is replicated:
-    // M >= N -> N fastest (consecutive blocks share the activation panel), else M fastest.
+    // 1-D grid of ntiles*splitk blocks: XCD-chunked, split-K slice slowest, grouped tile raster within.
     const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
     const int z = logical / ntiles;
     const int tile = logical - z * ntiles;
     int tm, tn;
-    if (p.M >= p.N) { tm = tile / tiles_n; tn = tile - tm * tiles_n; }
-    else { tn = tile / tiles_m; tm = tile - tn * tiles_m; }
+    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
     const int m0 = tm << 7, n0 = tn << 7;
     const int kchunks = (p.K + BK - 1) / BK;
     const int total = p.taps * kchunks;
@@ -95,8 +106,11 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
 
 #define SGV_NT_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
-        const int j_ = (S) / kchunks;                                                                         \
-        const int kc_ = ((S) - j_ * kchunks) * BK;                                                            \
+        /* channel chunk outer, tap inner: the taps of one chunk re-read the same activation rows (shifted */ \
+        /* by +-2) while they are still in L1/L2; tap-outer order re-streamed the whole panel per tap      */ \
+        const int kci_ = (S) / p.taps;                                                                        \
+        const int j_ = (S) - kci_ * p.taps;                                                                   \
+        const int kc_ = kci_ * BK;                                                                            \
         const int dt_ = j_ - p.pad;                                                                           \
         const bool kok_ = (kc_ + kq * EPC) < p.K;                                                             \
         const int aoff_ = (int)(((long)dt_ * p.lda + kc_) * ESZ);                                             \
@@ -208,6 +222,267 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     const float sc = p.scale ? *p.scale : 1.0f;
     const bool full = (m0 + 128 <= p.M) && (n0 + 128 <= p.N);
     const T* addp = reinterpret_cast<const T*>(p.addend);
+    if constexpr (IS_BF16) {
+        if (p.splitk == 1 && !p.out_f32) {
+            // bf16 output: stage the 128x128 tile through the (now idle) LDS buffers and write whole 256-byte
+            // rows with 16-byte stores.  Storing straight from the accumulators costs 64 two-byte stores per
+            // lane that each touch half a cache line; on the K=1024 recon-head GEMM that epilogue dominated.
+            constexpr int CP = 272;   // LDS row pitch of the C tile (256 B + 16 B pad)
+            static_assert(128 * CP <= 4 * TILEB, "C tile must fit in the staging buffers");
+            __syncthreads();          // every wave is done reading its last operand tile
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int lcol = wn * 64 + b * 32 + lr;
+                    const int gcol = n0 + lcol;
+                    const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lrow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
+                    }
+                }
+            }
+            __syncthreads();
+            bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = tid + i * 256;          // 2048 chunks of 8 bf16
+                const int lrow = c >> 4, lc8 = (c & 15) * 8;
+                const int grow = m0 + lrow, gcol = n0 + lc8;
+                if (grow < p.M && gcol < p.N) {       // N % 8 == 0: a chunk is entirely in or out
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
+                    if (addp) {
+                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wn * 64 + b * 32 + lr;
+            const bool cok = full || (col < p.N);
+            const int colc = cok ? col : 0;
+            const int rbase = m0 + wm * 64 + a * 32 + 4 * lh;
+            if (p.splitk > 1) {
+                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && (full || row < p.M)) dst[(long)row * p.N] = acc[a][b][r];
+                }
+            } else {
+                const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && (full || row < p.M)) {
+                        float v = acc[a][b][r] * sc + bv;
+                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
+                        if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+                        else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = from_f32<T>(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
+// =========================================================================================
+// NT, LDS-DMA version: operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), 3-stage ring,
+// prefetch distance 2, one raw s_barrier per K step, no ds_write / staging VGPRs.
+//   * LDS image per stage: A[128 rows][64 B] | W[128 rows][64 B], unpadded (an LDS-DMA wave-instruction writes
+//     M0-base + lane*16, i.e. 16 consecutive rows).  Bank conflicts are avoided by an XOR swizzle applied on the
+//     SOURCE side: LDS slot p of row r holds source chunk p ^ ((r>>2)&3); readers use the same involution.
+//   * masked taps / K tails / tile edges: the lane's buffer offset is pointed out of range and the hardware
+//     writes zeros into LDS (verified on MI355X: tests/micro/lds_dma_probe.hip).
+//   * each wave counts only its own DMA ops: 4 per tile, so `s_waitcnt vmcnt(4)` = "my part of tile s landed,
+//     tile s+1 may still be in flight"; the barrier after it publishes all four waves' parts.
+// =========================================================================================
+typedef __attribute__((address_space(3))) void lds_void;
+template <typename T>
+__global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(const GemmNT p) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 4 * EPC;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int TILEB = 128 * 64;
+    constexpr int STAGEB = 2 * TILEB;
+    constexpr int NS = 3;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+    const int ntiles = tiles_n * tiles_m;
+    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    const int z = logical / ntiles;
+    const int tile = logical - z * ntiles;
+    int tm, tn;
+    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm << 7, n0 = tn << 7;
+    const int kchunks = (p.K + BK - 1) / BK;
+    const int total = p.taps * kchunks;
+    const int s_begin = (int)((long)total * z / p.splitk);
+    const int s_end = (int)((long)total * (z + 1) / p.splitk);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    // DMA roles: wave w fills tile rows [32w, 32w+32) of each operand with two 1-KiB instructions (16 rows each)
+    const int dr0 = wave * 32 + (lane >> 2), dr1 = dr0 + 16;
+    const int dp = lane & 3;
+    const int dc0 = dp ^ ((dr0 >> 2) & 3), dc1 = dp ^ ((dr1 >> 2) & 3);   // source chunk for this LDS slot
+    const int am0 = m0 + dr0, am1 = m0 + dr1, wn0 = n0 + dr0, wn1 = n0 + dr1;
+    const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
+    const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
+    const uint32_t abase0 = (uint32_t)(((long)am0 * p.lda + dc0 * EPC) * ESZ), abase1 = (uint32_t)(((long)am1 * p.lda + dc1 * EPC) * ESZ);
+    const uint32_t wbase0 = wn0 < p.N ? (uint32_t)(((long)wn0 * p.ldw + dc0 * EPC) * ESZ) : OOB_OFF;
+    const uint32_t wbase1 = wn1 < p.N ? (uint32_t)(((long)wn1 * p.ldw + dc1 * EPC) * ESZ) : OOB_OFF;
+    unsigned char* const dmaA = smem + wave * 2048;          // wave-uniform LDS bases (stage 0)
+    unsigned char* const dmaW = smem + TILEB + wave * 2048;
+
+#define SGV_DMA_ISSUE(STAGE, S)                                                                               \
+    {                                                                                                         \
+        const int kci_ = (S) / p.taps;                                                                        \
+        const int j_ = (S) - kci_ * p.taps;                                                                   \
+        const int kc_ = kci_ * BK;                                                                            \
+        const int dt_ = j_ - p.pad;                                                                           \
+        const int aoff_ = (int)(((long)dt_ * p.lda + kc_) * ESZ);                                             \
+        const int woff_ = (int)(((long)j_ * p.w_tap_stride + kc_) * ESZ);                                     \
+        const bool k0_ = (kc_ + dc0 * EPC) < p.K, k1_ = (kc_ + dc1 * EPC) < p.K;                              \
+        const bool pa0 = aok0 && k0_ && ((unsigned)(at0 + dt_) < (unsigned)p.Tlen);                           \
+        const bool pa1 = aok1 && k1_ && ((unsigned)(at1 + dt_) < (unsigned)p.Tlen);                           \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB), 16, pa0 ? abase0 + (uint32_t)aoff_ : OOB_OFF, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + 1024), 16, pa1 ? abase1 + (uint32_t)aoff_ : OOB_OFF, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB), 16, k0_ ? wbase0 + (uint32_t)woff_ : OOB_OFF, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 1024), 16, k1_ ? wbase1 + (uint32_t)woff_ : OOB_OFF, 0, 0, 0); \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int swz = (lr >> 2) & 3;                           // rows wm*64 + i*32 + lr: bits 2..3 come from lr
+    const int a_frag_off = (wm * 64 + lr) * 64;
+    const int w_frag_off = TILEB + (wn * 64 + lr) * 64;
+#define SGV_DMA_COMPUTE(STAGE)                                                                                \
+    {                                                                                                         \
+        const unsigned char* sa_ = smem + (STAGE) * STAGEB + a_frag_off;                                      \
+        const unsigned char* sw_ = smem + (STAGE) * STAGEB + w_frag_off;                                      \
+        if constexpr (IS_BF16) {                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+                const int po_ = ((ks * 2 + lh) ^ swz) * 16;                                                   \
+                const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                               \
+                const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 64 + po_);                     \
+                const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                               \
+                const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 64 + po_);                     \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
+            }                                                                                                 \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
+                const int k_ = ks * 2 + lh;                                                                   \
+                const int po_ = (((k_ >> 2) ^ swz) * 16) + (k_ & 3) * 4;                                      \
+                const float a0_ = *reinterpret_cast<const float*>(sa_ + po_);                                 \
+                const float a1_ = *reinterpret_cast<const float*>(sa_ + 32 * 64 + po_);                       \
+                const float b0_ = *reinterpret_cast<const float*>(sw_ + po_);                                 \
+                const float b1_ = *reinterpret_cast<const float*>(sw_ + 32 * 64 + po_);                       \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);               \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);               \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);               \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);               \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+    const int nst = s_end - s_begin;
+    if (nst > 0) {
+        SGV_DMA_ISSUE(0, s_begin);
+        if (nst > 1) SGV_DMA_ISSUE(1, s_begin + 1);
+        int st = 0;                                   // stage holding tile i
+        int i = 0;
+        for (; i + 2 < nst; ++i) {
+            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // my 4 DMA ops of tile i have landed
+            __builtin_amdgcn_s_barrier();                          // ... and so have the other waves'
+            const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3: last read in step i-1
+            if (st2 == 0) { SGV_DMA_ISSUE(0, s_begin + i + 2); }
+            else if (st2 == 1) { SGV_DMA_ISSUE(1, s_begin + i + 2); }
+            else { SGV_DMA_ISSUE(2, s_begin + i + 2); }
+            asm volatile("" ::: "memory");
+            if (st == 0) { SGV_DMA_COMPUTE(0); } else if (st == 1) { SGV_DMA_COMPUTE(1); } else { SGV_DMA_COMPUTE(2); }
+            st = st == 2 ? 0 : st + 1;
+        }
+        for (; i < nst; ++i) {                                     // last two tiles: nothing left to issue
+            if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            if (st == 0) { SGV_DMA_COMPUTE(0); } else if (st == 1) { SGV_DMA_COMPUTE(1); } else { SGV_DMA_COMPUTE(2); }
+            st = st == 2 ? 0 : st + 1;
+        }
+    }
+#undef SGV_DMA_ISSUE
+#undef SGV_DMA_COMPUTE
+
+    // ---- epilogue (same as gemm_nt_kernel) ----
+    const float sc = p.scale ? *p.scale : 1.0f;
+    const bool full = (m0 + 128 <= p.M) && (n0 + 128 <= p.N);
+    const T* addp = reinterpret_cast<const T*>(p.addend);
+    if constexpr (IS_BF16) {
+        if (p.splitk == 1 && !p.out_f32) {
+            constexpr int CP = 272;
+            static_assert(128 * CP <= NS * STAGEB, "C tile must fit in the ring");
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int lcol = wn * 64 + b * 32 + lr;
+                    const int gcol = n0 + lcol;
+                    const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lrow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
+                    }
+                }
+            }
+            __syncthreads();
+            bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int c = tid + i * 256;
+                const int lrow = c >> 4, lc8 = (c & 15) * 8;
+                const int grow = m0 + lrow, gcol = n0 + lc8;
+                if (grow < p.M && gcol < p.N) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
+                    if (addp) {
+                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
+                }
+            }
+            return;
+        }
+    }
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -277,14 +552,12 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
     const int wm = wave >> 1, wn = wave & 1;
     const int tiles_2 = (p.N2 + 127) >> 7, tiles_1 = (p.N1 + 127) >> 7;
     const int ntiles = tiles_1 * tiles_2;
-    // 1-D grid: (tap, split-K slice) slowest, then the tile raster with the dimension that has fewer
-    // tiles fastest (consecutive blocks share the larger operand's panel), XCD-chunked.
+    // 1-D grid: XCD-chunked, (tap, split-K slice) slowest, grouped tile raster within.
     const int logical = xcd_remap(blockIdx.x, ntiles * p.taps * p.splitk);
     const int tz = logical / ntiles;
     const int tile = logical - tz * ntiles;
     int t1, t2;
-    if (p.N1 >= p.N2) { t1 = tile / tiles_2; t2 = tile - t1 * tiles_2; }
-    else { t2 = tile / tiles_1; t1 = tile - t2 * tiles_1; }
+    grouped_raster(tile, tiles_1, tiles_2, t1, t2);
     const int i0 = t1 << 7, j0 = t2 << 7;
     const int tap = tz / p.splitk, z = tz - tap * p.splitk;
     const int dt = tap - p.pad;
@@ -505,8 +778,14 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
     dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk);
-    if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
-    else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
+    static const int use_dma = getenv("SGV_GEMM_DMA") ? atoi(getenv("SGV_GEMM_DMA")) : 0;   // LDS-DMA variant: opt-in (same ~0.65 PF plateau as the register-staged one)
+    if (use_dma) {
+        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, dim3(256), 0, s, q);
+    } else {
+        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
+    }
     if (p.splitk > 1) {
         long total = (long)p.M * p.N;
         int blocks = (int)((total + 255) / 256);

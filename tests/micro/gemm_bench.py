@@ -1,0 +1,39 @@
+"""Standalone GEMM microbenchmark through the C ABI (for rocprofv3 counter passes).
+   python tests/micro/gemm_bench.py nt M N K taps [reps]   |   tn M N1 N2 taps [reps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import torch
+import simulgen_vae_amd
+from simulgen_vae_amd import engine as E
+lib = E.load_library()
+kind = sys.argv[1]
+a, b, c, taps = (int(v) for v in sys.argv[2:6])
+reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
+T = 200
+torch.manual_seed(0)
+if kind == "nt":
+    M, N, K = a, b, c
+    A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
+    W = (torch.randn(taps, N, K, device="cuda") * 0.05).to(torch.bfloat16)
+    C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
+    sk = int(os.environ.get("SPLITK", "1"))
+    def run():
+        rc = lib.sgv_test_gemm_nt(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, None)
+        assert rc == 0, lib.sgv_last_error()
+    flops = 2.0 * M * N * K * taps
+else:
+    M, N1, N2 = a, b, c
+    dY = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
+    X = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
+    out = torch.empty(taps, N1, N2, device="cuda", dtype=torch.float32)
+    def run():
+        rc = lib.sgv_test_gemm_tn(1, dY.data_ptr(), X.data_ptr(), out.data_ptr(), M, N1, N2, taps, T, 1, 1, None)
+        assert rc == 0, lib.sgv_last_error()
+    flops = 2.0 * M * N1 * N2 * taps
+run(); torch.cuda.synchronize()
+ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+ts = []
+for _ in range(reps):
+    ev0.record(); run(); ev1.record(); torch.cuda.synchronize(); ts.append(ev0.elapsed_time(ev1))
+best = min(ts)
+print(f"{kind} {a}x{b}x{c} taps={taps}: best {best*1e3:.0f} us  {flops/best/1e9:.0f} TFLOP/s (incl. launch+sync overhead)")
