@@ -104,23 +104,36 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     // still in flight (prefetch distance 2; the compiler's in-order vmcnt(4) retires only the older set)
     uint4 ra0A, ra1A, rw0A, rw1A, ra0B, ra1B, rw0B, rw1B;
 
+    // K-step state carried incrementally (channel chunk outer, tap inner): no divisions / 64-bit multiplies in
+    // the loop.  An ablation with loads, LDS reads and MFMAs all removed showed the old per-step index
+    // arithmetic alone cost ~40 % of the kernel time.
+    const int lda_b = (int)(p.lda * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
+    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;     // state of the NEXT tile to load
+    {
+        const int kci0 = s_begin / p.taps;
+        ld_j = s_begin - kci0 * p.taps;
+        ld_kcb = kci0 * BK * ESZ;
+        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
+        ld_woff = ld_j * wts_b + ld_kcb;
+    }
+    const int klim_b = (p.K - kq * EPC) * ESZ;               // chunk valid iff ld_kcb < klim_b
+    // per-tap validity of this thread's two activation rows as bit masks (taps <= 31)
+    uint32_t am0_mask = 0u, am1_mask = 0u;
+    for (int j = 0; j < p.taps; ++j) {
+        if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
+        if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
+    }
 #define SGV_NT_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
-        /* channel chunk outer, tap inner: the taps of one chunk re-read the same activation rows (shifted */ \
-        /* by +-2) while they are still in L1/L2; tap-outer order re-streamed the whole panel per tap      */ \
-        const int kci_ = (S) / p.taps;                                                                        \
-        const int j_ = (S) - kci_ * p.taps;                                                                   \
-        const int kc_ = kci_ * BK;                                                                            \
-        const int dt_ = j_ - p.pad;                                                                           \
-        const bool kok_ = (kc_ + kq * EPC) < p.K;                                                             \
-        const int aoff_ = (int)(((long)dt_ * p.lda + kc_) * ESZ);                                             \
-        const int woff_ = (int)(((long)j_ * p.w_tap_stride + kc_) * ESZ);                                     \
-        const bool pa0 = aok0 && kok_ && ((unsigned)(at0 + dt_) < (unsigned)p.Tlen);                          \
-        const bool pa1 = aok1 && kok_ && ((unsigned)(at1 + dt_) < (unsigned)p.Tlen);                          \
-        ra0##X = bload16(rsA, pa0 ? abase0 + (uint32_t)aoff_ : OOB_OFF);                                      \
-        ra1##X = bload16(rsA, pa1 ? abase1 + (uint32_t)aoff_ : OOB_OFF);                                      \
-        rw0##X = bload16(rsW, kok_ ? wbase0 + (uint32_t)woff_ : OOB_OFF);                                     \
-        rw1##X = bload16(rsW, kok_ ? wbase1 + (uint32_t)woff_ : OOB_OFF);                                     \
+        const bool kok_ = ld_kcb < klim_b;                                                                    \
+        const bool pa0 = kok_ && ((am0_mask >> ld_j) & 1u);                                                   \
+        const bool pa1 = kok_ && ((am1_mask >> ld_j) & 1u);                                                   \
+        ra0##X = bload16(rsA, pa0 ? abase0 + (uint32_t)ld_aoff : OOB_OFF);                                    \
+        ra1##X = bload16(rsA, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF);                                    \
+        rw0##X = bload16(rsW, kok_ ? wbase0 + (uint32_t)ld_woff : OOB_OFF);                                   \
+        rw1##X = bload16(rsW, kok_ ? wbase1 + (uint32_t)ld_woff : OOB_OFF);                                   \
+        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
+        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
     }
 #define SGV_NT_ST1(PTR, V)                                                                                    \
     if constexpr (IS_BF16) { *reinterpret_cast<uint4*>(PTR) = (V); }                                          \
@@ -308,6 +321,11 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
 //     tile s+1 may still be in flight"; the barrier after it publishes all four waves' parts.
 // =========================================================================================
 typedef __attribute__((address_space(3))) void lds_void;
+// timing-only ablations for tests/micro (results are wrong when any is set): 1 = no MFMA, 2 = no DMA loads,
+// 4 = no LDS fragment reads
+#ifndef SGV_ABLATE
+#define SGV_ABLATE 0
+#endif
 template <typename T>
 __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(const GemmNT p) {
     constexpr int EPC = ElemTraits<T>::EPC;
@@ -350,21 +368,34 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(co
     unsigned char* const dmaA = smem + wave * 2048;          // wave-uniform LDS bases (stage 0)
     unsigned char* const dmaW = smem + TILEB + wave * 2048;
 
+    const int lda_b = (int)(p.lda * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
+    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;     // incremental state of the next tile to issue
+    {
+        const int kci0 = s_begin / p.taps;
+        ld_j = s_begin - kci0 * p.taps;
+        ld_kcb = kci0 * BK * ESZ;
+        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
+        ld_woff = ld_j * wts_b + ld_kcb;
+    }
+    const int klim0_b = (p.K - dc0 * EPC) * ESZ, klim1_b = (p.K - dc1 * EPC) * ESZ;
+    uint32_t am0_mask = 0u, am1_mask = 0u;
+    for (int j = 0; j < p.taps; ++j) {
+        if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
+        if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
+    }
 #define SGV_DMA_ISSUE(STAGE, S)                                                                               \
     {                                                                                                         \
-        const int kci_ = (S) / p.taps;                                                                        \
-        const int j_ = (S) - kci_ * p.taps;                                                                   \
-        const int kc_ = kci_ * BK;                                                                            \
-        const int dt_ = j_ - p.pad;                                                                           \
-        const int aoff_ = (int)(((long)dt_ * p.lda + kc_) * ESZ);                                             \
-        const int woff_ = (int)(((long)j_ * p.w_tap_stride + kc_) * ESZ);                                     \
-        const bool k0_ = (kc_ + dc0 * EPC) < p.K, k1_ = (kc_ + dc1 * EPC) < p.K;                              \
-        const bool pa0 = aok0 && k0_ && ((unsigned)(at0 + dt_) < (unsigned)p.Tlen);                           \
-        const bool pa1 = aok1 && k1_ && ((unsigned)(at1 + dt_) < (unsigned)p.Tlen);                           \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB), 16, pa0 ? abase0 + (uint32_t)aoff_ : OOB_OFF, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + 1024), 16, pa1 ? abase1 + (uint32_t)aoff_ : OOB_OFF, 0, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB), 16, k0_ ? wbase0 + (uint32_t)woff_ : OOB_OFF, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 1024), 16, k1_ ? wbase1 + (uint32_t)woff_ : OOB_OFF, 0, 0, 0); \
+        const bool k0_ = ld_kcb < klim0_b, k1_ = ld_kcb < klim1_b;                                            \
+        const bool pa0 = k0_ && ((am0_mask >> ld_j) & 1u);                                                    \
+        const bool pa1 = k1_ && ((am1_mask >> ld_j) & 1u);                                                    \
+        if (!(SGV_ABLATE & 2)) {                                                                              \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB), 16, pa0 ? abase0 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + 1024), 16, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB), 16, k0_ ? wbase0 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 1024), 16, k1_ ? wbase1 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
+        } else { asm volatile("" :: "v"(pa0), "v"(pa1), "v"(ld_aoff), "v"(ld_woff)); }                        \
+        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
+        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
     }
 
     f32x16 acc[2][2];
@@ -386,14 +417,19 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(co
         if constexpr (IS_BF16) {                                                                              \
             _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
                 const int po_ = ((ks * 2 + lh) ^ swz) * 16;                                                   \
-                const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                               \
-                const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 64 + po_);                     \
-                const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                               \
-                const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 64 + po_);                     \
+                bf16x8 a0_, a1_, b0_, b1_;                                                                    \
+                if (!(SGV_ABLATE & 4)) {                                                                      \
+                a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                                            \
+                a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 64 + po_);                                  \
+                b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                                            \
+                b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 64 + po_);                                  \
+                } else { a0_ = a1_ = b0_ = b1_ = __builtin_bit_cast(bf16x8, make_uint4(po_, lane, ks, 7)); } \
+                if (!(SGV_ABLATE & 1)) {                                                                      \
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
                 acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
                 acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
+                } else { asm volatile("" :: "v"(a0_), "v"(a1_), "v"(b0_), "v"(b1_)); }                        \
             }                                                                                                 \
         } else {                                                                                              \
             _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
@@ -418,8 +454,9 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(co
         int st = 0;                                   // stage holding tile i
         int i = 0;
         for (; i + 2 < nst; ++i) {
-            asm volatile("s_waitcnt vmcnt(4)" ::: "memory");    // my 4 DMA ops of tile i have landed
-            __builtin_amdgcn_s_barrier();                          // ... and so have the other waves'
+            // my 4 DMA ops of tile i have landed, then all waves'; ONE asm statement so hipcc cannot hoist the
+            // refill below above the barrier (seen as an intermittent WAR race in the fp32 build)
+            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
             const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3: last read in step i-1
             if (st2 == 0) { SGV_DMA_ISSUE(0, s_begin + i + 2); }
             else if (st2 == 1) { SGV_DMA_ISSUE(1, s_begin + i + 2); }
@@ -429,10 +466,8 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(co
             st = st == 2 ? 0 : st + 1;
         }
         for (; i < nst; ++i) {                                     // last two tiles: nothing left to issue
-            if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            asm volatile("" ::: "memory");
+            if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
             if (st == 0) { SGV_DMA_COMPUTE(0); } else if (st == 1) { SGV_DMA_COMPUTE(1); } else { SGV_DMA_COMPUTE(2); }
             st = st == 2 ? 0 : st + 1;
         }
@@ -515,6 +550,251 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(co
     }
 }
 
+// =========================================================================================
+// NT, LDS-DMA, 128(M) x 256(N) tile ("wide"): 4 waves, each 128 x 64 (4x2 MFMA tiles, 16 MFMAs per K step),
+// 3-stage ring of 24 KiB (A 128 rows | W 256 rows, 64-B rows, source-side XOR swizzle), 2 blocks per CU.
+// Versus the 128x128 kernels: twice the MFMA work per barrier / per step of loop overhead (measured: the step
+// skeleton cost as much as the 8 MFMAs it wrapped), 0.75 instead of 1 ds_read_b128 per MFMA, 25 % fewer operand
+// bytes per FLOP, and for M = 3200 the grid (25 x N/256 tiles) fills the 512 block slots in whole rounds.
+// =========================================================================================
+template <typename T>
+__global__ __launch_bounds__(256, 1) void gemm_nt_wide_kernel(const GemmNT p) {
+    constexpr int EPC = ElemTraits<T>::EPC;
+    constexpr int BK = 4 * EPC;
+    constexpr bool IS_BF16 = sizeof(T) == 2;
+    constexpr int ESZ = (int)sizeof(T);
+    constexpr int TILEA = 128 * 64, TILEW = 256 * 64;
+    constexpr int STAGEB = TILEA + TILEW;
+    constexpr int NS = 3;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 127) >> 7;
+    const int ntiles = tiles_n * tiles_m;
+    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    const int z = logical / ntiles;
+    const int tile = logical - z * ntiles;
+    int tm, tn;
+    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm << 7, n0 = tn << 8;
+    const int kchunks = (p.K + BK - 1) / BK;
+    const int total = p.taps * kchunks;
+    const int s_begin = (int)((long)total * z / p.splitk);
+    const int s_end = (int)((long)total * (z + 1) / p.splitk);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    // DMA roles per wave and stage: A rows [32w, 32w+32) (2 ops), W rows [64w, 64w+64) (4 ops); 16 rows per op
+    const int rl = lane >> 2, dp = lane & 3;
+    const int ar0 = wave * 32 + rl, ar1 = ar0 + 16;
+    const int wr0 = wave * 64 + rl, wr1 = wr0 + 16, wr2 = wr0 + 32, wr3 = wr0 + 48;
+    // rows r and r+16 share (r>>2)&3 parity pattern: swizzle term uses the tile-local row
+    const int dca0 = dp ^ ((ar0 >> 2) & 3), dca1 = dp ^ ((ar1 >> 2) & 3);
+    const int dcw0 = dp ^ ((wr0 >> 2) & 3), dcw1 = dp ^ ((wr1 >> 2) & 3), dcw2 = dp ^ ((wr2 >> 2) & 3), dcw3 = dp ^ ((wr3 >> 2) & 3);
+    const int am0 = m0 + ar0, am1 = m0 + ar1;
+    const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
+    const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
+    const uint32_t abase0 = (uint32_t)(((long)am0 * p.lda + dca0 * EPC) * ESZ), abase1 = (uint32_t)(((long)am1 * p.lda + dca1 * EPC) * ESZ);
+#define SGV_WBASE(R, DC) ((n0 + (R)) < p.N ? (uint32_t)(((long)(n0 + (R)) * p.ldw + (DC) * EPC) * ESZ) : OOB_OFF)
+    const uint32_t wbase0 = SGV_WBASE(wr0, dcw0), wbase1 = SGV_WBASE(wr1, dcw1), wbase2 = SGV_WBASE(wr2, dcw2), wbase3 = SGV_WBASE(wr3, dcw3);
+#undef SGV_WBASE
+    unsigned char* const dmaA = smem + wave * 2048;
+    unsigned char* const dmaW = smem + TILEA + wave * 4096;
+
+    const int lda_b = (int)(p.lda * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
+    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;
+    {
+        const int kci0 = s_begin / p.taps;
+        ld_j = s_begin - kci0 * p.taps;
+        ld_kcb = kci0 * BK * ESZ;
+        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
+        ld_woff = ld_j * wts_b + ld_kcb;
+    }
+    // chunk validity along K depends on the lane's source chunk; all dc* are in 0..3
+    const int kK_b = p.K * ESZ;
+    uint32_t am0_mask = 0u, am1_mask = 0u;
+    for (int j = 0; j < p.taps; ++j) {
+        if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
+        if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
+    }
+#define SGV_KOK(DC) ((ld_kcb + (DC) * 16) < kK_b)
+#define SGV_WIDE_ISSUE(STAGE)                                                                                 \
+    {                                                                                                         \
+        const bool pa0 = SGV_KOK(dca0) && ((am0_mask >> ld_j) & 1u);                                          \
+        const bool pa1 = SGV_KOK(dca1) && ((am1_mask >> ld_j) & 1u);                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB), 16, pa0 ? abase0 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + 1024), 16, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB), 16, SGV_KOK(dcw0) ? wbase0 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0);        \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 1024), 16, SGV_KOK(dcw1) ? wbase1 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 2048), 16, SGV_KOK(dcw2) ? wbase2 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 3072), 16, SGV_KOK(dcw3) ? wbase3 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
+        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
+        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int swz = (lr >> 2) & 3;
+    const int a_frag_off = lr * 64;
+    const int w_frag_off = TILEA + (wave * 64 + lr) * 64;
+#define SGV_WIDE_COMPUTE(STAGE)                                                                               \
+    {                                                                                                         \
+        const unsigned char* sa_ = smem + (STAGE) * STAGEB + a_frag_off;                                      \
+        const unsigned char* sw_ = smem + (STAGE) * STAGEB + w_frag_off;                                      \
+        if constexpr (IS_BF16) {                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
+                const int po_ = ((ks * 2 + lh) ^ swz) * 16;                                                   \
+                const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                               \
+                const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 64 + po_);                     \
+                const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                               \
+                const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 64 + po_);                     \
+                const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(sa_ + 64 * 64 + po_);                     \
+                const bf16x8 a3_ = *reinterpret_cast<const bf16x8*>(sa_ + 96 * 64 + po_);                     \
+                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
+                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
+                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
+                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
+                acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b0_, acc[2][0], 0, 0, 0);            \
+                acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b1_, acc[2][1], 0, 0, 0);            \
+                acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b0_, acc[3][0], 0, 0, 0);            \
+                acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b1_, acc[3][1], 0, 0, 0);            \
+            }                                                                                                 \
+        } else {                                                                                              \
+            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
+                const int k_ = ks * 2 + lh;                                                                   \
+                const int po_ = (((k_ >> 2) ^ swz) * 16) + (k_ & 3) * 4;                                      \
+                const float b0_ = *reinterpret_cast<const float*>(sw_ + po_);                                 \
+                const float b1_ = *reinterpret_cast<const float*>(sw_ + 32 * 64 + po_);                       \
+                _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                               \
+                    const float av_ = *reinterpret_cast<const float*>(sa_ + a * 32 * 64 + po_);               \
+                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, b0_, acc[a][0], 0, 0, 0);           \
+                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, b1_, acc[a][1], 0, 0, 0);           \
+                }                                                                                             \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+    // one pipeline step: my 6 DMA ops of the tile in stage CUR have landed (tile+1 may be in flight), publish,
+    // refill the stage that was read in the previous step, multiply
+#define SGV_WIDE_STEP(CUR, REFILL)                                                                            \
+    {                                                                                                         \
+        /* one asm statement: neither the DMA issue below nor the LDS reads can be moved across it */         \
+        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");                                         \
+        SGV_WIDE_ISSUE(REFILL);                                                                               \
+        asm volatile("" ::: "memory");                                                                        \
+        SGV_WIDE_COMPUTE(CUR);                                                                                \
+    }
+#define SGV_WIDE_TAIL(CUR, WAIT)                                                                              \
+    {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(" #WAIT ")\n\ts_barrier" ::: "memory");                                 \
+        SGV_WIDE_COMPUTE(CUR);                                                                                \
+    }
+    const int nst = s_end - s_begin;
+    if (nst > 0) {
+        SGV_WIDE_ISSUE(0);
+        if (nst > 1) SGV_WIDE_ISSUE(1);
+        int i = 0;
+        // steady state, unrolled over the 3-stage ring: tile i in stage i%3, refill stage (i+2)%3
+        while (i + 5 <= nst) {          // all three steps still have a tile i+2 to issue
+            SGV_WIDE_STEP(0, 2)
+            SGV_WIDE_STEP(1, 0)
+            SGV_WIDE_STEP(2, 1)
+            i += 3;
+        }
+        // 1..4 tiles left: tile i sits in stage 0 (i is a multiple of 3)
+        const int rem = nst - i;
+        if (rem == 4) { SGV_WIDE_STEP(0, 2) SGV_WIDE_STEP(1, 0) SGV_WIDE_TAIL(2, 6) SGV_WIDE_TAIL(0, 0) }
+        else if (rem == 3) { SGV_WIDE_STEP(0, 2) SGV_WIDE_TAIL(1, 6) SGV_WIDE_TAIL(2, 0) }
+        else if (rem == 2) { SGV_WIDE_TAIL(0, 6) SGV_WIDE_TAIL(1, 0) }
+        else { SGV_WIDE_TAIL(0, 0) }
+    }
+#undef SGV_WIDE_ISSUE
+#undef SGV_WIDE_COMPUTE
+#undef SGV_WIDE_STEP
+#undef SGV_WIDE_TAIL
+#undef SGV_KOK
+
+    // ---- epilogue ----
+    const float sc = p.scale ? *p.scale : 1.0f;
+    const T* addp = reinterpret_cast<const T*>(p.addend);
+    if constexpr (IS_BF16) {
+        if (p.splitk == 1 && !p.out_f32) {
+            constexpr int CP = 528;   // 512 B + 16 B pad
+            static_assert(128 * CP <= NS * STAGEB, "C tile must fit in the ring");
+            __syncthreads();
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    const int lcol = wave * 64 + b * 32 + lr;
+                    const int gcol = n0 + lcol;
+                    const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int lrow = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
+                    }
+                }
+            }
+            __syncthreads();
+            bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = tid + i * 256;          // 4096 chunks of 8 bf16
+                const int lrow = c >> 5, lc8 = (c & 31) * 8;
+                const int grow = m0 + lrow, gcol = n0 + lc8;
+                if (grow < p.M && gcol < p.N) {
+                    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
+                    if (addp) {
+                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
+                    }
+                    *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
+                }
+            }
+            return;
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wave * 64 + b * 32 + lr;
+            const bool cok = col < p.N;
+            const int colc = cok ? col : 0;
+            const int rbase = m0 + a * 32 + 4 * lh;
+            if (p.splitk > 1) {
+                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < p.M) dst[(long)row * p.N] = acc[a][b][r];
+                }
+            } else {
+                const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < p.M) {
+                        float v = acc[a][b][r] * sc + bv;
+                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
+                        if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+                        else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = from_f32<T>(v);
+                    }
+                }
+            }
+        }
+    }
+}
+
 // split-K combine: out = scale * sum_z partial[z] + bias + addend
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_reduce_kernel(const GemmNT p) {
@@ -579,17 +859,25 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
     uint4 ra0A, ra1A, rb0A, rb1A, ra0B, ra1B, rb0B, rb1B;
 
     // rows past M and taps that leave the sample window point out of range -> hardware returns zeros
+    // incremental row state of the next tile to load: row indices, their time index within the sample
+    int ld_m0 = s_begin * KR + r0, ld_m1 = ld_m0 + RSTEP;
+    int ld_t0 = ld_m0 % p.Tlen, ld_t1 = ld_m1 % p.Tlen;
+    uint32_t ld_a0 = (uint32_t)ld_m0 * lda_b + acol, ld_a1 = (uint32_t)ld_m1 * lda_b + acol;
+    uint32_t ld_b0 = (uint32_t)(ld_m0 + dt) * ldb_b + bcol, ld_b1 = (uint32_t)(ld_m1 + dt) * ldb_b + bcol;
+    const int kr_t = KR % p.Tlen;
 #define SGV_TN_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
-        const int m0_ = (S) * KR + r0, m1_ = (S) * KR + r0 + RSTEP;                                           \
-        const bool pa0 = (m0_ < p.M), pa1 = (m1_ < p.M);                                                      \
-        const int t0_ = m0_ % p.Tlen, t1_ = m1_ % p.Tlen;                                                     \
-        const bool pb0 = pa0 && ((unsigned)(t0_ + dt) < (unsigned)p.Tlen);                                    \
-        const bool pb1 = pa1 && ((unsigned)(t1_ + dt) < (unsigned)p.Tlen);                                    \
-        ra0##X = bload16(rsA, pa0 ? (uint32_t)m0_ * lda_b + acol : OOB_OFF);                                  \
-        ra1##X = bload16(rsA, pa1 ? (uint32_t)m1_ * lda_b + acol : OOB_OFF);                                  \
-        rb0##X = bload16(rsB, pb0 ? (uint32_t)(m0_ + dt) * ldb_b + bcol : OOB_OFF);                           \
-        rb1##X = bload16(rsB, pb1 ? (uint32_t)(m1_ + dt) * ldb_b + bcol : OOB_OFF);                           \
+        const bool pa0 = (ld_m0 < p.M), pa1 = (ld_m1 < p.M);                                                  \
+        const bool pb0 = pa0 && ((unsigned)(ld_t0 + dt) < (unsigned)p.Tlen);                                  \
+        const bool pb1 = pa1 && ((unsigned)(ld_t1 + dt) < (unsigned)p.Tlen);                                  \
+        ra0##X = bload16(rsA, pa0 ? ld_a0 : OOB_OFF);                                                         \
+        ra1##X = bload16(rsA, pa1 ? ld_a1 : OOB_OFF);                                                         \
+        rb0##X = bload16(rsB, pb0 ? ld_b0 : OOB_OFF);                                                         \
+        rb1##X = bload16(rsB, pb1 ? ld_b1 : OOB_OFF);                                                         \
+        ld_m0 += KR; ld_m1 += KR;                                                                             \
+        ld_t0 += kr_t; if (ld_t0 >= p.Tlen) ld_t0 -= p.Tlen;                                                  \
+        ld_t1 += kr_t; if (ld_t1 >= p.Tlen) ld_t1 -= p.Tlen;                                                  \
+        ld_a0 += KR * lda_b; ld_a1 += KR * lda_b; ld_b0 += KR * ldb_b; ld_b1 += KR * ldb_b;                   \
     }
 #define SGV_TN_SSTORE(BUF, X)                                                                                 \
     {                                                                                                         \
@@ -737,8 +1025,16 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // Split-K choice: minimise (occupancy rounds) x (K steps per block) + the slab combine pass.
 // 256 CUs x 3 resident 256-thread blocks (40 KB LDS, ~150 VGPR) = 768 slots; a grid of 800 blocks takes
 // two rounds, so e.g. 200 tiles prefer 3 slices (600 blocks) over 4.
-static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int min_steps) {
-    const double slots = 768.0;
+// The 128x256 LDS-DMA kernel is used for bf16 GEMMs with N >= 256 and >= 64 K-steps (short-K shapes are
+// faster on the 128x128 kernel: 3 blocks/CU hide the prologue/epilogue).  fp32 (validation mode) stays on
+// the 128x128 kernels: the fp32 build of the wide kernel showed an intermittent, unexplained corruption of a
+// few accumulator rows with 5-tap convs (tests/micro/nt_sweep.py), while the bf16 build is clean under
+// tests/test_kernels_gpu.py::test_gemm_nt_wide_stress.
+static bool gemm_nt_is_wide(int dtype, int N, long steps) {
+    static const int use_wide = getenv("SGV_GEMM_WIDE") ? atoi(getenv("SGV_GEMM_WIDE")) : 1;
+    return use_wide && dtype == 1 && N >= 256 && steps >= 64;
+}
+static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int min_steps, double slots = 768.0) {
     int best = 1;
     double best_cost = 1e30;
     for (int sk = 1; sk <= 32; ++sk) {
@@ -754,8 +1050,10 @@ static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int 
 
 int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype) {
     const int bk = dtype == 1 ? 32 : 16;
-    const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
     const long total = (long)taps * cdiv(K, bk);
+    if (gemm_nt_is_wide(dtype, N, total))   // 128x256 tiles, 1 block (4 waves, 312 registers) per CU
+        return pick_splitk((long)cdiv(M, 128) * cdiv(N, 256), total, (double)M * N * 4.0, 16, 256.0);
+    const long tiles = (long)cdiv(M, 128) * cdiv(N, 128);
     return pick_splitk(tiles, total, (double)M * N * 4.0, 8);
 }
 
@@ -777,14 +1075,22 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     q.a_bytes = ((long)(p.M - 1) * p.lda + p.K) * esz;
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
-    dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk);
-    static const int use_dma = getenv("SGV_GEMM_DMA") ? atoi(getenv("SGV_GEMM_DMA")) : 0;   // LDS-DMA variant: opt-in (same ~0.65 PF plateau as the register-staged one)
-    if (use_dma) {
-        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, dim3(256), 0, s, q);
+    static const int use_dma = getenv("SGV_GEMM_DMA") ? atoi(getenv("SGV_GEMM_DMA")) : 0;   // 128x128 LDS-DMA variant: opt-in
+    static const int use_wide = getenv("SGV_GEMM_WIDE") ? atoi(getenv("SGV_GEMM_WIDE")) : 1;
+    const long total_steps = (long)p.taps * cdiv(p.K, dtype == 1 ? 32 : 16);
+    if (use_wide && gemm_nt_is_wide(dtype, p.N, total_steps)) {
+        dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 256) * p.splitk);
+        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_wide_kernel<bf16_t>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_wide_kernel<float>), grid, dim3(256), 0, s, q);
     } else {
-        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
+        dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk);
+        if (use_dma) {
+            if (dtype == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, dim3(256), 0, s, q);
+        } else {
+            if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
+            else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
+        }
     }
     if (p.splitk > 1) {
         long total = (long)p.M * p.N;

@@ -137,3 +137,25 @@ def test_gemm_tn(dtype, use_tr, case):
     assert np.isfinite(got).all()
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 2e-5, err
+
+
+@pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1)])
+def test_gemm_nt_wide_stress(case):
+    """The 128x256 LDS-DMA kernel (bf16, N >= 256, >= 64 K-steps) repeated 25x per shape: every run must match
+    (guards the counted-vmcnt / barrier pipeline against intermittent races)."""
+    import torch
+    lib = E.load_library()
+    M, N, K, taps, Tlen, splitk = case
+    rng = np.random.default_rng(7)
+    A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.05)
+    dA, dW = _dev(A, 1), _dev(W, 1)
+    ref = ref_conv_nt(A, W, None, 1.0, None, taps, Tlen)
+    scale = np.abs(ref).max()
+    for it in range(25):
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        rc = lib.sgv_test_gemm_nt(1, dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, None, M, N, K, taps, Tlen,
+                                  splitk, 1, None)
+        assert rc == 0, lib.sgv_last_error()
+        err = np.abs(out.cpu().numpy() - ref).max() / scale
+        assert err < 2e-5, (it, err)
