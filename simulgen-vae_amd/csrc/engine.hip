@@ -56,7 +56,7 @@ struct Layer {
     bool used = true, has_grad = true, need_wct = true;
     int lin_kind = LIN_NONE, lin_C = 0;      // head: K = lin_C*T; expand: O = lin_C*T
     size_t w = NPOS, b = NPOS, u = NPOS, v = NPOS;  // param arena (floats)
-    size_t gw = NPOS, gb = NPOS;                    // grad arena (floats)
+    size_t gw = NPOS, gb = NPOS, gdot = NPOS;       // grad arena (floats); gdot: <G,W_eff> scalar (small zone)
     size_t wc = NPOS, wct = NPOS;                   // compute-copy arena (elements)
     int sn = -1;
     int splitk_tn = 1;
@@ -109,7 +109,7 @@ struct sgv_engine {
     double* stats = nullptr; size_t n_stats = 0, n_stats_fwd = 0;  // [fwd sums | bwd sums2]
     float* sn_tmp = nullptr; size_t n_sn_tmp = 0;
     float* sn_sigma = nullptr;
-    double* sn_dot = nullptr;
+    float* sn_dot_dummy = nullptr;
     double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
     float* partial = nullptr; size_t partial_floats = 0;
     float* xpose_tmp = nullptr; size_t xpose_floats = 0;
@@ -117,8 +117,8 @@ struct sgv_engine {
     float* colpart = nullptr; size_t colpart_floats = 0;   // per-block column-sum workspace
     SNDesc* sn_dev = nullptr; std::vector<SNDesc> sn_host;
     AdamDesc* adam_dev = nullptr; std::vector<AdamDesc> adam_host;
-    WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr, *items_copy = nullptr;
-    int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0, n_items_copy = 0;
+    WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr, *items_copy = nullptr, *items_wct = nullptr;
+    int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0, n_items_copy = 0, n_items_wct = 0;
     // graph
     std::vector<Block> encA, encR, decU, decD, decP1, decP2, decX, decQ1, decQ2;
     Block decS, recon;
@@ -395,7 +395,7 @@ static int layout_grads(sgv_engine* e) {
     }
     e->n_grads_w = ng;
     size_t small_start = ng;
-    for (auto& l : e->layers) if (l.has_grad) l.gb = take(l.cout);
+    for (auto& l : e->layers) if (l.has_grad) { l.gdot = take(1); l.gb = take(l.cout); }
     for (auto& g : e->gns) if (g.has_grad) { g.ggamma = take(g.C); g.gbeta = take(g.C); }
     e->buckets.push_back({small_start, ng - small_start});
     e->n_grads = ng;
@@ -563,7 +563,7 @@ static int upload_tables(sgv_engine* e) {
     const int L = (int)e->layers.size();
     e->sn_host.resize(L);
     size_t to = 0;
-    std::vector<WorkItem> i_sn, i_dot, i_adam, i_copy;
+    std::vector<WorkItem> i_sn, i_dot, i_adam, i_copy, i_wct;
     for (int i = 0; i < L; ++i) {
         Layer& l = e->layers[i];
         SNDesc d;
@@ -571,7 +571,7 @@ static int upload_tables(sgv_engine* e) {
         d.tmp_t = e->sn_tmp + to; to += align_up((size_t)l.cin * l.k, 4);
         d.tmp_s = e->sn_tmp + to; to += align_up((size_t)l.cout, 4);
         d.sigma = e->sn_sigma + 2 * i;
-        d.dot = e->sn_dot + i;
+        d.dot = l.has_grad ? e->grads + l.gdot : e->sn_dot_dummy;
         d.G = l.has_grad ? e->grads + l.gw : nullptr;
         d.taps = l.k; d.rows = l.cout; d.cols = l.cin; d.active = l.used ? 1 : 0;
         e->sn_host[i] = d;
@@ -579,7 +579,7 @@ static int upload_tables(sgv_engine* e) {
             const int rb = (l.cout + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (l.cin + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
             for (int c = 0; c < l.k * rb * cb; ++c) i_sn.push_back({i, c});
         }
-        if (l.has_grad) {
+        if (l.has_grad && l.op == OP_LINEAR) {   // conv layers get <G,W_eff> from their dY kernels (ew.hip)
             const long nch = (l.nw() + OPT_CHUNK - 1) / OPT_CHUNK;
             for (long c = 0; c < nch; ++c) i_dot.push_back({i, (int)c});
         }
@@ -613,6 +613,10 @@ static int upload_tables(sgv_engine* e) {
             }
             const int rt = (l.cout + 31) / 32, ct = (l.cin + 31) / 32;
             for (int c = 0; c < l.k * rt * ct; ++c) i_copy.push_back({id, c});
+            if (wct) {
+                const int rt6 = (l.cout + 63) / 64, ct6 = (l.cin + 63) / 64;
+                for (int c = 0; c < l.k * rt6 * ct6; ++c) i_wct.push_back({id, c});
+            }
         }
     }
     for (auto& g : e->gns) {
@@ -632,8 +636,9 @@ static int upload_tables(sgv_engine* e) {
     if (up(i_dot.data(), sizeof(WorkItem) * i_dot.size(), (void**)&e->items_dot)) return fail(SGV_ERR_HIP, "table upload failed");
     if (up(i_adam.data(), sizeof(WorkItem) * i_adam.size(), (void**)&e->items_adam)) return fail(SGV_ERR_HIP, "table upload failed");
     if (up(i_copy.data(), sizeof(WorkItem) * i_copy.size(), (void**)&e->items_copy)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_wct.data(), sizeof(WorkItem) * i_wct.size(), (void**)&e->items_wct)) return fail(SGV_ERR_HIP, "table upload failed");
     e->n_items_sn = (int)i_sn.size(); e->n_items_dot = (int)i_dot.size();
-    e->n_items_adam = (int)i_adam.size(); e->n_items_copy = (int)i_copy.size();
+    e->n_items_adam = (int)i_adam.size(); e->n_items_copy = (int)i_copy.size(); e->n_items_wct = (int)i_wct.size();
     return 0;
 }
 
@@ -791,15 +796,19 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
             p.dbias = e->grads + L.gb; p.part = e->colpart;
             ew_gn_bwd_reduce(e->dt, p, e->stream);       // + finalize: sums2, dgamma, dbeta, dbias
             p.out = S.dy.p; p.ldout = S.dy.ld;
+            p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;   // <G,W_eff> = sum dY*(y - bias)
             ew_gn_bwd_apply(e->dt, p, e->stream);
             dY = S.dy;
         } else if (S.act) {
             GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
             p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
+            p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;
             ew_act(e->dt, 1, p, e->stream);
             dY = S.dy;
         } else {
             GNParams p; p.y = dA.p; p.ldy = dA.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
+            if (!S.y.f32) return fail(SGV_ERR_STATE, "conv without norm/activation must have an fp32 output (%s)", L.prefix.c_str());
+            p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b; p.yf32 = (const float*)S.y.p; p.ldyf = S.y.ld;
             ew_act(e->dt, 2, p, e->stream);
             dY = dA;
         }
@@ -890,7 +899,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->stats, e->n_stats * 8);
     ALLOC(e->sn_tmp, e->n_sn_tmp * 4);
     ALLOC(e->sn_sigma, e->layers.size() * 2 * 4);
-    ALLOC(e->sn_dot, e->layers.size() * 8);
+    ALLOC(e->sn_dot_dummy, 64);
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
@@ -906,8 +915,8 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
 int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
-    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot,
-                    e->scal, e->partial, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy};
+    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot_dummy,
+                    e->scal, e->partial, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     delete e;
@@ -1348,6 +1357,7 @@ int sgv_backward(sgv_engine* e, float alpha, float beta) {
         p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
         p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type; p.gscale = gs;
         p.out = e->dy_recon.p; p.ldout = e->dy_recon.ld;
+        p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;
         ew_recon_bwd_apply(e->dt, p, e->stream);
         ew_axpy(e->grads + g.ggamma, e->recon_unit, gs, e->N, e->stream);
         ew_axpy(e->grads + g.gbeta, e->recon_unit + e->N, gs, e->N, e->stream);
@@ -1405,20 +1415,15 @@ int sgv_backward(sgv_engine* e, float alpha, float beta) {
         const Tensor x_prev = i == 0 ? e->x_in : e->enc_h[i - 1];
         CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], i > 0 ? &e->d_h[i - 1] : nullptr, B));
     }
-    fire();
-    fire();   // small zone
-    return SGV_OK;
-}
-
-static int compute_dots(sgv_engine* e) {
-    HIPCHK(hipMemsetAsync(e->sn_dot, 0, e->layers.size() * 8, e->stream));
+    // <G,W_eff> of the (small) Linear layers from their weights; conv layers accumulated theirs above
     if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
-    return 0;
+    fire();
+    fire();   // small zone (biases, GroupNorm affine, <G,W_eff> scalars)
+    return SGV_OK;
 }
 
 int sgv_grad_norm(sgv_engine* e, double* out) {
     if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
-    CHK(compute_dots(e));
     HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
     if (opt_grad_norm(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, e->scal + 15, e->stream)) return fail(SGV_ERR_HIP, "grad-norm launch failed");
     double h = 0.0;
@@ -1430,7 +1435,6 @@ int sgv_grad_norm(sgv_engine* e, double* out) {
 
 int sgv_adamw_step(sgv_engine* e, float lr) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
-    CHK(compute_dots(e));
     e->step += 1;
     const double b1 = 0.9, b2 = 0.999;
     const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
@@ -1438,7 +1442,11 @@ int sgv_adamw_step(sgv_engine* e, float lr) {
     HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
     if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    CHK(refresh_copies(e));
+    // bf16 mode: AdamW wrote the [tap][Cout][Cin] compute copy itself; only the transposed copy is left
+    if (e->dt == SGV_DTYPE_BF16 || true) {
+        if (opt_make_wct(e->adam_dev, e->items_wct, e->n_items_wct, e->dt, e->stream)) return fail(SGV_ERR_HIP, "make_wct launch failed");
+        e->copies_fresh = true;
+    }
     return SGV_OK;
 }
 

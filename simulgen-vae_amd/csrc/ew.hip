@@ -151,6 +151,16 @@ __device__ __forceinline__ void gn_block_colsums(const GNParams& p, const GNCtx&
     }
 }
 
+// block sum of one float per thread -> atomicAdd to *dst (all 256 threads must call)
+__device__ __forceinline__ void block_atomic_add(float v, float* dst) {
+    __shared__ float smr[4];
+    const float w = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smr[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(dst, smr[0] + smr[1] + smr[2] + smr[3]);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
@@ -342,41 +352,47 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
 template <typename T, int ACT, bool FROM_LOSS>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
-    if (!c.col_ok) return;
-    float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8];
-    gn_consts(p, c, mean, rstd);
-    const double n = (double)p.Cg * (double)p.T;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        gam[e] = p.gamma[c.c0 + e];
-        bet[e] = p.beta[c.c0 + e];
-        const int g = (c.c0 + e) / p.Cg;
-        m1[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
-        m2[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
-    }
-    const T* y = reinterpret_cast<const T*>(p.y);
-    const T* dout = reinterpret_cast<const T*>(p.dout);
-    T* dy = reinterpret_cast<T*>(p.out);
-    for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
-        const long m = (long)c.b * p.T + t;
-        float v[8], d[8];
-        load8(y + m * p.ldy + c.c0, v);
-        load8(dout + m * p.lddout + c.c0, d);
+    float dotacc = 0.f;
+    if (c.col_ok) {
+        float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8], cb[8];
+        gn_consts(p, c, mean, rstd);
+        const double n = (double)p.Cg * (double)p.T;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            const float xh = (v[e] - mean[e]) * rstd[e];
-            const float z = xh * gam[e] + bet[e];
-            float dz;
-            if constexpr (FROM_LOSS) {
-                const float o = tanhf(z);
-                dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
-            } else {
-                dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
-            }
-            v[e] = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
+            gam[e] = p.gamma[c.c0 + e];
+            bet[e] = p.beta[c.c0 + e];
+            cb[e] = p.cbias ? p.cbias[c.c0 + e] : 0.f;
+            const int g = (c.c0 + e) / p.Cg;
+            m1[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
+            m2[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
         }
-        store8(dy + m * p.ldout + c.c0, v);
+        const T* y = reinterpret_cast<const T*>(p.y);
+        const T* dout = reinterpret_cast<const T*>(p.dout);
+        T* dy = reinterpret_cast<T*>(p.out);
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+            const long m = (long)c.b * p.T + t;
+            float v[8], d[8];
+            load8(y + m * p.ldy + c.c0, v);
+            load8(dout + m * p.lddout + c.c0, d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (v[e] - mean[e]) * rstd[e];
+                const float z = xh * gam[e] + bet[e];
+                float dz;
+                if constexpr (FROM_LOSS) {
+                    const float o = tanhf(z);
+                    dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
+                } else {
+                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
+                }
+                const float r = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
+                dotacc += r * (v[e] - cb[e]);          // dY * (conv output without bias) -> <G, W_eff>
+                v[e] = r;
+            }
+            store8(dy + m * p.ldout + c.c0, v);
+        }
     }
+    if (p.cdot) block_atomic_add(dotacc, p.cdot);
 }
 
 // activation without GroupNorm: MODE 0: out = gelu(y); MODE 1: out = dout*rscale*gelu'(y) (+ colsum -> dbias)
@@ -385,26 +401,38 @@ template <typename T, int MODE>
 __global__ __launch_bounds__(256) void act_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
     float colD[8];
+    float dotacc = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) colD[e] = 0.f;
     if (c.col_ok) {
         const T* y = reinterpret_cast<const T*>(p.y);
         const T* dout = reinterpret_cast<const T*>(p.dout);
         T* out = reinterpret_cast<T*>(p.out);
+        float cb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cb[e] = (MODE != 0 && p.cbias) ? p.cbias[c.c0 + e] : 0.f;
         for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
             const long m = (long)c.b * p.T + t;
             float v[8], d[8];
             load8(y + m * p.ldy + c.c0, v);
             if constexpr (MODE == 1) load8(dout + m * p.lddout + c.c0, d);
+            if constexpr (MODE == 2) { if (p.yf32) load8(p.yf32 + m * p.ldyf + c.c0, d); }
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 if constexpr (MODE == 0) v[e] = gelu_f(v[e]);
-                else if constexpr (MODE == 1) { v[e] = d[e] * p.rscale * gelu_grad_f(v[e]); }
+                else if constexpr (MODE == 1) {
+                    const float yv = v[e];
+                    v[e] = d[e] * p.rscale * gelu_grad_f(yv);
+                    dotacc += v[e] * (yv - cb[e]);
+                } else {
+                    if (p.yf32) dotacc += v[e] * (d[e] - cb[e]);     // v = dY, d = conv output (fp32)
+                }
                 colD[e] += v[e];
             }
             if constexpr (MODE != 2) store8(out + m * p.ldout + c.c0, v);
         }
     }
+    if (MODE != 0 && p.cdot) block_atomic_add(dotacc, p.cdot);
     if (MODE != 0 && p.part) {
         float col[1][8];
 #pragma unroll

@@ -130,7 +130,9 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const SNDesc* descs, c
     const float w = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(d.dot, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+    // <G, W_eff> = <G, W> / sigma.  Only the small Linear layers take this weight-sized route; conv layers get
+    // the same number as sum dY*(y - bias) inside their dY-producing kernels (ew.hip).
+    if (threadIdx.x == 0) atomicAdd(d.dot, (sm[0] + sm[1] + sm[2] + sm[3]) * d.sigma[1]);
 }
 int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipStream_t s) {
     if (n > 0) hipLaunchKernelGGL(sn_grad_dot_kernel, dim3(n), dim3(256), 0, s, descs_dev, items);
@@ -139,7 +141,7 @@ int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipSt
 
 // ---- fused AdamW (+ spectral-norm chain rule, + grad norm) -------------------------------------------
 // g_orig = (G - <G,W_eff> u v^T) / sigma with <G,W_eff> = dot / sigma.
-template <bool UPDATE>
+template <bool UPDATE, bool WC_BF16>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
                                                    double* gnorm_sq) {
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
     if (a.sn >= 0) {
         const SNDesc d = sn[a.sn];
         inv_sigma = d.sigma[1];
-        cdot = (float)(d.dot[0] * (double)inv_sigma);
+        cdot = d.dot[0];
         u = d.u; v = d.v;
     }
     const long rc = (long)a.rows * a.cols;
@@ -186,6 +188,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
             *reinterpret_cast<float4*>(a.p + i) = p;
             *reinterpret_cast<float4*>(a.m + i) = m;
             *reinterpret_cast<float4*>(a.v + i) = vs;
+            if (WC_BF16 && a.wc) {   // bf16 compute copy written in the same pass (saves re-reading the master)
+                typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                bf16x4_t o;
+                o[0] = (__bf16)p.x; o[1] = (__bf16)p.y; o[2] = (__bf16)p.z; o[3] = (__bf16)p.w;
+                *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(a.wc) + i) = o;
+            }
         }
     }
     __shared__ float sm[4];
@@ -196,13 +204,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
 }
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
               float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s) {
-    (void)compute_dtype;
-    if (n > 0) hipLaunchKernelGGL((adamw_kernel<true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+    if (n > 0 && compute_dtype == 1) hipLaunchKernelGGL((adamw_kernel<true, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+    else if (n > 0) hipLaunchKernelGGL((adamw_kernel<true, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
                   hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL((adamw_kernel<false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, gnorm_sq);
+    if (n > 0) hipLaunchKernelGGL((adamw_kernel<false, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, gnorm_sq);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -237,6 +245,36 @@ __global__ __launch_bounds__(256) void make_copies_kernel(const AdamDesc* adam, 
         const int cc = c0 + r, rr = r0 + tx;
         if (rr < a.rows && cc < a.cols) dst[(long)cc * a.rows + rr] = from_f32<T>(tile[tx][r]);
     }
+}
+// transposed copy only, sourced from the compute copy AdamW just wrote (bf16) or the master (fp32 mode):
+// wct[taps-1-tap][c][r] = w[tap][r][c]; 64x64 tiles
+template <typename T>
+__global__ __launch_bounds__(256) void make_wct_kernel(const AdamDesc* adam, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const AdamDesc a = adam[it.desc];
+    const int ct = (a.cols + 63) >> 6, rt = (a.rows + 63) >> 6;
+    const int tap = it.chunk / (rt * ct);
+    const int rem = it.chunk - tap * rt * ct;
+    const int r0 = (rem / ct) << 6, c0 = (rem % ct) << 6;
+    __shared__ T tile[64][64 + 8];
+    const T* src = (a.wc ? reinterpret_cast<const T*>(a.wc) : reinterpret_cast<const T*>(a.p)) + (long)tap * a.rows * a.cols;
+    T* dst = reinterpret_cast<T*>(a.wct) + (long)(a.taps - 1 - tap) * a.rows * a.cols;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int r = ty; r < 64; r += 4) {
+        const int rr = r0 + r, cc = c0 + tx;
+        tile[r][tx] = (rr < a.rows && cc < a.cols) ? src[(long)rr * a.cols + cc] : (T)0.f;
+    }
+    __syncthreads();
+    for (int r = ty; r < 64; r += 4) {
+        const int cc = c0 + r, rr = r0 + tx;
+        if (rr < a.rows && cc < a.cols) dst[(long)cc * a.rows + rr] = tile[tx][r];
+    }
+}
+int opt_make_wct(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (compute_dtype == 1) hipLaunchKernelGGL((make_wct_kernel<bf16_t>), dim3(n), dim3(256), 0, s, adam_dev, items);
+    else hipLaunchKernelGGL((make_wct_kernel<float>), dim3(n), dim3(256), 0, s, adam_dev, items);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int opt_make_copies(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s) {
     if (n <= 0) return 0;

@@ -13,6 +13,9 @@ struct GNParams {
     float* dbeta = nullptr;
     float* dbias = nullptr;                        // bias gradient of the producing conv
     float* part = nullptr;                         // workspace for per-block column sums (ew_gn_part_floats)
+    float* cdot = nullptr;                         // += sum dY*(y - cbias) = <G, W_eff> of the producing conv
+    const float* cbias = nullptr;                  // that conv's bias
+    const float* yf32 = nullptr; long ldyf = 0;    // act mode 2: the conv output (fp32) paired with dY in `y`
     double* sums = nullptr;                        // [B*G][2] sum, sum of squares
     double* sums2 = nullptr;                       // [B*G][2] backward group sums
     double* loss_sums = nullptr;                   // [2]
@@ -65,7 +68,7 @@ struct SNDesc {
     float* tmp_t;      // [taps*cols] scratch: W^T u
     float* tmp_s;      // [rows]      scratch: W v
     float* sigma;      // [2]: sigma, 1/sigma
-    double* dot;       // <G, W>
+    float* dot;        // <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
     const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
     int taps, rows, cols;
     int active;        // participates in this forward
@@ -89,6 +92,7 @@ int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* it
 int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
                   hipStream_t s);
 int opt_make_copies(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s);
+int opt_make_wct(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s);
 constexpr int OPT_CHUNK = 8192;      // elements per work item in the flat passes
 constexpr int SN_ROWS_PER_ITEM = 64; // rows per work item in the GEMV passes
 constexpr int SN_COLS_PER_ITEM = 1024;

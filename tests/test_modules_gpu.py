@@ -73,6 +73,6 @@ def test_train_plumbing_run(tmp_path, monkeypatch):
     xb = torch.from_numpy(x[:B])
     mu1 = m1.encoder(xb)[0].cpu().numpy()
     mu2 = m2.encoder(xb)[0].cpu().numpy()
-    np.testing.assert_allclose(mu1, mu2, rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(mu1, mu2, rtol=1e-4, atol=1e-5)   # split-K heads use float atomics: order varies
     with pytest.raises(ValueError):
         tr.train(2, B, tl, vl, 1e-3, enc, enc[::-1], N, 32, 8, T, 1e6, "MSE", True, True)   # epochs < 4
