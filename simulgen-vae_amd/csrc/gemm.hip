@@ -1028,6 +1028,279 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_wide64_kernel(const GemmNT p) 
     }
 }
 
+// =========================================================================================
+// NT, LDS-DMA, 128 x 256 tile, K-step 64, SOFTWARE-PIPELINED ("wide64p", bf16 only).  Same tiles/ring as wide64, but
+// with one wave per SIMD every exposed LDS latency stalls the MFMA pipe, so fragments are double-buffered:
+//   L(k1) M(k0) | L(k2) M(k1) | L(k3) M(k2) | wait lgkm+vmcnt, barrier, refill THIS stage, L(k0 of next tile) | M(k3)
+// i.e. the reads of sub-step k+1 are issued before the MFMAs of k, and the stage hand-off sits in front of the last
+// MFMA group.  The refill targets the stage just read (all waves have retired their reads: lgkmcnt(0) + barrier).
+// wide64 itself: each stage holds
+// 64 K elements (128-byte rows; 3 stages x 48 KiB = 144 KiB of the 160 KiB LDS, one block per CU): 32 MFMAs per
+// wave per barrier, 12 DMA ops per wave per stage (vmcnt(12)), 96 KiB of operand bytes in flight per CU.
+// LDS slot p (16 B) of row r holds source chunk p ^ ((r>>1)&7): two 128-B rows share a 256-B bank row, so the 8
+// chunk slots x 2 row parities of a ds_read_b128 lane group are all distinct.
+// =========================================================================================
+__global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p) {
+    typedef bf16_t T;
+    constexpr int EPC = 8, BK = 64, ESZ = 2;
+    constexpr int TILEA = 128 * 128, TILEW = 256 * 128;
+    constexpr int STAGEB = TILEA + TILEW;       // 48 KiB
+    constexpr int NS = 3;
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 127) >> 7;
+    const int ntiles = tiles_n * tiles_m;
+    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
+    const int z = logical / ntiles;
+    const int tile = logical - z * ntiles;
+    int tm, tn;
+    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
+    const int m0 = tm << 7, n0 = tn << 8;
+    const int kchunks = (p.K + BK - 1) / BK;
+    const int total = p.taps * kchunks;
+    const int s_begin = (int)((long)total * z / p.splitk);
+    const int s_end = (int)((long)total * (z + 1) / p.splitk);
+
+    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
+    // DMA roles: one op = 8 rows x 128 B.  Wave w: A rows [32w, 32w+32) (4 ops), W rows [64w, 64w+64) (8 ops).
+    const int rl = lane >> 3, dp = lane & 7;
+    // tile-local rows of op q: base + 8q + rl; (row>>1)&7 = ((8q + rl)>>1)&7 since bases are multiples of 32
+    // -> the swizzle term only depends on (8q + rl): ((rl>>1) + 4q) & 7
+    const int lda_b = (int)(p.lda * ESZ), ldw_b = (int)(p.ldw * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
+    uint32_t aoffs[4], woffs[8];
+    uint32_t amask[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int row = wave * 32 + q * 8 + rl;
+        const int dc = dp ^ ((row >> 1) & 7);
+        const int am = m0 + row;
+        aoffs[q] = (uint32_t)((long)am * lda_b + dc * 16);
+        uint32_t mk = 0u;
+        const int at = am % p.Tlen;
+        for (int j = 0; j < p.taps; ++j)
+            if (am < p.M && (unsigned)(at + j - p.pad) < (unsigned)p.Tlen) mk |= 1u << j;
+        amask[q] = mk | ((uint32_t)dc << 8);      // bits 8..10: source chunk (for the K-tail test)
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+        const int row = wave * 64 + q * 8 + rl;
+        const int dc = dp ^ ((row >> 1) & 7);
+        const int wn = n0 + row;
+        woffs[q] = wn < p.N ? (uint32_t)((long)wn * ldw_b + dc * 16) : OOB_OFF;
+    }
+    // all 12 ops of a lane use source chunks dp ^ s with s in 0..7; K-tail validity is per chunk:
+    // chunk c of the current step is valid iff ld_kcb + 16*c < K bytes
+    unsigned char* const dmaA = smem + wave * 4096;
+    unsigned char* const dmaW = smem + TILEA + wave * 8192;
+    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;
+    {
+        const int kci0 = s_begin / p.taps;
+        ld_j = s_begin - kci0 * p.taps;
+        ld_kcb = kci0 * BK * ESZ;
+        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
+        ld_woff = ld_j * wts_b + ld_kcb;
+    }
+    const int kK_b = p.K * ESZ;
+#define SGV_W64_A(Q, STAGE)                                                                                   \
+    {                                                                                                         \
+        const bool ok_ = ((amask[Q] >> ld_j) & 1u) && ((ld_kcb + (int)((amask[Q] >> 8) & 7u) * 16) < kK_b);   \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + (Q) * 1024), 16,  \
+                                                 ok_ ? aoffs[Q] + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0);      \
+    }
+#define SGV_W64_W(Q, STAGE)                                                                                   \
+    {                                                                                                         \
+        const int dc_ = dp ^ ((((Q) * 8 + rl) >> 1) & 7);                                                     \
+        const bool ok_ = (ld_kcb + dc_ * 16) < kK_b;                                                          \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + (Q) * 1024), 16,  \
+                                                 ok_ ? woffs[Q] + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0);      \
+    }
+#define SGV_W64_ISSUE(STAGE)                                                                                  \
+    {                                                                                                         \
+        SGV_W64_A(0, STAGE) SGV_W64_A(1, STAGE) SGV_W64_A(2, STAGE) SGV_W64_A(3, STAGE)                       \
+        SGV_W64_W(0, STAGE) SGV_W64_W(1, STAGE) SGV_W64_W(2, STAGE) SGV_W64_W(3, STAGE)                       \
+        SGV_W64_W(4, STAGE) SGV_W64_W(5, STAGE) SGV_W64_W(6, STAGE) SGV_W64_W(7, STAGE)                       \
+        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
+        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
+    }
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int swz = (lr >> 1) & 7;                 // rows a*32 + lr / wave*64 + b*32 + lr: bits 1..3 come from lr
+    const int a_frag_off = lr * 128;
+    const int w_frag_off = TILEA + (wave * 64 + lr) * 128;
+    bf16x8 fa0, fa1, fa2, fa3, fb0, fb1;      // fragment set A
+    bf16x8 ga0, ga1, ga2, ga3, gb0, gb1;      // fragment set B
+#define SGV_P_LOAD(X, STAGE, KS)                                                                              \
+    {                                                                                                         \
+        const unsigned char* sa_ = smem + (STAGE) * STAGEB + a_frag_off;                                      \
+        const unsigned char* sw_ = smem + (STAGE) * STAGEB + w_frag_off;                                      \
+        const int po_ = (((KS) * 2 + lh) ^ swz) * 16;                                                         \
+        X##b0 = *reinterpret_cast<const bf16x8*>(sw_ + po_);                                                  \
+        X##b1 = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 128 + po_);                                       \
+        X##a0 = *reinterpret_cast<const bf16x8*>(sa_ + po_);                                                  \
+        X##a1 = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 128 + po_);                                       \
+        X##a2 = *reinterpret_cast<const bf16x8*>(sa_ + 64 * 128 + po_);                                       \
+        X##a3 = *reinterpret_cast<const bf16x8*>(sa_ + 96 * 128 + po_);                                       \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+#define SGV_P_MMA(X)                                                                                          \
+    {                                                                                                         \
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a0, X##b0, acc[0][0], 0, 0, 0);                \
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a0, X##b1, acc[0][1], 0, 0, 0);                \
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a1, X##b0, acc[1][0], 0, 0, 0);                \
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a1, X##b1, acc[1][1], 0, 0, 0);                \
+        acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a2, X##b0, acc[2][0], 0, 0, 0);                \
+        acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a2, X##b1, acc[2][1], 0, 0, 0);                \
+        acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a3, X##b0, acc[3][0], 0, 0, 0);                \
+        acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##a3, X##b1, acc[3][1], 0, 0, 0);                \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+    // one tile: entered with set f = fragments (tile, k0); HANDOFF is the code between M(k2) and M(k3)
+#define SGV_P_TILE(CUR, HANDOFF)                                                                              \
+    {                                                                                                         \
+        SGV_P_LOAD(g, CUR, 1) SGV_P_MMA(f)                                                                    \
+        SGV_P_LOAD(f, CUR, 2) SGV_P_MMA(g)                                                                    \
+        SGV_P_LOAD(g, CUR, 3) SGV_P_MMA(f)                                                                    \
+        HANDOFF                                                                                               \
+        SGV_P_MMA(g)                                                                                          \
+    }
+    // hand-off with a next tile: retire my reads of this stage, wait for my part of the next tile (12 newer DMA
+    // ops may stay in flight), publish, refill this stage (if a tile is left), read the next tile's first fragments
+#define SGV_P_HAND(CUR, NXT, WAIT, REFILL)                                                                    \
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(" #WAIT ")\n\ts_barrier" ::: "memory");             \
+    if (REFILL) { SGV_W64_ISSUE(CUR); }                                                                       \
+    asm volatile("" ::: "memory");                                                                            \
+    SGV_P_LOAD(f, NXT, 0)
+    const int nst = s_end - s_begin;
+    if (nst > 0) {
+        SGV_W64_ISSUE(0);
+        if (nst > 1) SGV_W64_ISSUE(1);
+        if (nst > 2) SGV_W64_ISSUE(2);
+        if (nst > 2) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
+        else if (nst > 1) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        SGV_P_LOAD(f, 0, 0)
+        int i = 0;
+        // steady state: tiles i, i+1, i+2 in stages 0,1,2; every hand-off still has tile i+3 to issue and tile i+2
+        // in flight behind the one it waits for
+        while (i + 6 <= nst) {
+            SGV_P_TILE(0, SGV_P_HAND(0, 1, 12, true))
+            SGV_P_TILE(1, SGV_P_HAND(1, 2, 12, true))
+            SGV_P_TILE(2, SGV_P_HAND(2, 0, 12, true))
+            i += 3;
+        }
+        // 1..5 tiles left, tile i in stage 0; tiles up to min(nst, i+3)-1 are already issued
+        int rem = nst - i;
+        if (rem == 5) {        // issue i+3, i+4 then drain
+            SGV_P_TILE(0, SGV_P_HAND(0, 1, 12, true))
+            SGV_P_TILE(1, SGV_P_HAND(1, 2, 12, true))
+            SGV_P_TILE(2, SGV_P_HAND(2, 0, 12, false))
+            SGV_P_TILE(0, SGV_P_HAND(0, 1, 0, false))
+            SGV_P_TILE(1, )
+        } else if (rem == 4) {
+            SGV_P_TILE(0, SGV_P_HAND(0, 1, 12, true))
+            SGV_P_TILE(1, SGV_P_HAND(1, 2, 12, false))
+            SGV_P_TILE(2, SGV_P_HAND(2, 0, 0, false))
+            SGV_P_TILE(0, )
+        } else if (rem == 3) {
+            SGV_P_TILE(0, SGV_P_HAND(0, 1, 12, false))
+            SGV_P_TILE(1, SGV_P_HAND(1, 2, 0, false))
+            SGV_P_TILE(2, )
+        } else if (rem == 2) {
+            SGV_P_TILE(0, SGV_P_HAND(0, 1, 0, false))
+            SGV_P_TILE(1, )
+        } else {
+            SGV_P_TILE(0, )
+        }
+    }
+#undef SGV_P_LOAD
+#undef SGV_P_MMA
+#undef SGV_P_TILE
+#undef SGV_P_HAND
+#undef SGV_W64_A
+#undef SGV_W64_W
+#undef SGV_W64_ISSUE
+
+    // ---- epilogue (as gemm_nt_wide_kernel) ----
+    const float sc = p.scale ? *p.scale : 1.0f;
+    const T* addp = reinterpret_cast<const T*>(p.addend);
+    if (p.splitk == 1 && !p.out_f32) {
+        constexpr int CP = 528;
+        __syncthreads();
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int lcol = wave * 64 + b * 32 + lr;
+                const int gcol = n0 + lcol;
+                const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int lrow = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
+                }
+            }
+        }
+        __syncthreads();
+        bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int c = tid + i * 256;
+            const int lrow = c >> 5, lc8 = (c & 31) * 8;
+            const int grow = m0 + lrow, gcol = n0 + lc8;
+            if (grow < p.M && gcol < p.N) {
+                bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
+                if (addp) {
+                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
+                }
+                *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = n0 + wave * 64 + b * 32 + lr;
+            const bool cok = col < p.N;
+            const int colc = cok ? col : 0;
+            const int rbase = m0 + a * 32 + 4 * lh;
+            if (p.splitk > 1) {
+                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < p.M) dst[(long)row * p.N] = acc[a][b][r];
+                }
+            } else {
+                const float bv = p.bias ? p.bias[colc] : 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = rbase + (r & 3) + 8 * (r >> 2);
+                    if (cok && row < p.M) {
+                        float v = acc[a][b][r] * sc + bv;
+                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
+                        reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
+                    }
+                }
+            }
+        }
+    }
+}
+
 // split-K combine: out = scale * sum_z partial[z] + bias + addend
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_reduce_kernel(const GemmNT p) {
@@ -1314,7 +1587,9 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (use_wide && gemm_nt_is_wide(dtype, p.N, total_steps)) {
         dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 256) * p.splitk);
         static const int use_w64 = getenv("SGV_GEMM_W64") ? atoi(getenv("SGV_GEMM_W64")) : 1;
-        if (dtype == 1 && use_w64) hipLaunchKernelGGL(gemm_nt_wide64_kernel, grid, dim3(256), 0, s, q);
+        static const int use_w64p = getenv("SGV_GEMM_W64P") ? atoi(getenv("SGV_GEMM_W64P")) : 1;
+        if (dtype == 1 && use_w64 && use_w64p) hipLaunchKernelGGL(gemm_nt_wide64p_kernel, grid, dim3(256), 0, s, q);
+        else if (dtype == 1 && use_w64) hipLaunchKernelGGL(gemm_nt_wide64_kernel, grid, dim3(256), 0, s, q);
         else if (dtype == 1) hipLaunchKernelGGL((gemm_nt_wide_kernel<bf16_t>), grid, dim3(256), 0, s, q);
         else hipLaunchKernelGGL((gemm_nt_wide_kernel<float>), grid, dim3(256), 0, s, q);
     } else {
