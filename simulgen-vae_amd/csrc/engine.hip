@@ -395,7 +395,7 @@ static int layout_grads(sgv_engine* e) {
     }
     e->n_grads_w = ng;
     size_t small_start = ng;
-    for (auto& l : e->layers) if (l.has_grad) { l.gdot = take(1); l.gb = take(l.cout); }
+    for (auto& l : e->layers) if (l.has_grad) { l.gdot = take(SGV_DOT_SLOTS); l.gb = take(l.cout); }
     for (auto& g : e->gns) if (g.has_grad) { g.ggamma = take(g.C); g.gbeta = take(g.C); }
     e->buckets.push_back({small_start, ng - small_start});
     e->n_grads = ng;
@@ -899,7 +899,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->stats, e->n_stats * 8);
     ALLOC(e->sn_tmp, e->n_sn_tmp * 4);
     ALLOC(e->sn_sigma, e->layers.size() * 2 * 4);
-    ALLOC(e->sn_dot_dummy, 64);
+    ALLOC(e->sn_dot_dummy, SGV_DOT_SLOTS * sizeof(float));
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);

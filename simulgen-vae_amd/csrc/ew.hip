@@ -55,19 +55,35 @@ __device__ __forceinline__ GNCtx gn_ctx(const GNParams& p) {
     return c;
 }
 
-// per-element mean / rstd of the element's group from the fp64 group sums
-__device__ __forceinline__ void gn_consts(const GNParams& p, const GNCtx& c, float mean[8], float rstd[8]) {
-    const double n = (double)p.Cg * (double)p.T;
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-        const int g = (c.c0 + e) / p.Cg;
+// per-element mean / rstd (and, WITH_M, the backward means m1 = s1/n, m2 = s2/n) of the element's group.
+// The fp64 divide/sqrt chain runs once per block on G threads and is broadcast through LDS: done per
+// thread it cost more than the streaming work of the small layers.  Must be called by all 256 threads.
+template <bool WITH_M = false>
+__device__ __forceinline__ void gn_consts(const GNParams& p, const GNCtx& c, float mean[8], float rstd[8],
+                                          float* m1 = nullptr, float* m2 = nullptr) {
+    __shared__ float gc[16][4];
+    if ((int)threadIdx.x < p.G) {
+        const int g = threadIdx.x;
+        const double n = (double)p.Cg * (double)p.T;
         const double s = p.sums[((long)c.b * p.G + g) * 2 + 0];
         const double ss = p.sums[((long)c.b * p.G + g) * 2 + 1];
         const double m = s / n;
         double var = ss / n - m * m;
         if (var < 0.0) var = 0.0;
-        mean[e] = (float)m;
-        rstd[e] = (float)(1.0 / sqrt(var + 1e-5));
+        gc[g][0] = (float)m;
+        gc[g][1] = (float)(1.0 / sqrt(var + 1e-5));
+        if constexpr (WITH_M) {
+            gc[g][2] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
+            gc[g][3] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
+        }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const int g = min((c.c0 + e) / p.Cg, p.G - 1);
+        mean[e] = gc[g][0];
+        rstd[e] = gc[g][1];
+        if constexpr (WITH_M) { m1[e] = gc[g][2]; m2[e] = gc[g][3]; }
     }
 }
 
@@ -151,14 +167,15 @@ __device__ __forceinline__ void gn_block_colsums(const GNParams& p, const GNCtx&
     }
 }
 
-// block sum of one float per thread -> atomicAdd to *dst (all 256 threads must call)
+// block sum of one float per thread -> atomicAdd into one of the SGV_DOT_SLOTS slots at dst (all 256 threads must call)
 __device__ __forceinline__ void block_atomic_add(float v, float* dst) {
     __shared__ float smr[4];
     const float w = wave_sum(v);
     __syncthreads();
     if ((threadIdx.x & 63) == 0) smr[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(dst, smr[0] + smr[1] + smr[2] + smr[3]);
+    if (threadIdx.x == 0)
+        atomicAdd(dst + ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7) & (SGV_DOT_SLOTS - 1)), smr[0] + smr[1] + smr[2] + smr[3]);
 }
 
 template <typename T>
@@ -180,16 +197,16 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
 }
 
 __device__ __forceinline__ float act_apply(int act, float z) {
-    return act == 1 ? gelu_f(z) : (act == 2 ? tanhf(z) : z);
+    return act == 1 ? gelu_f(z) : (act == 2 ? tanh_f(z) : z);
 }
 
 // out = [res + rscale *] act(gn(y))
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
-    if (!c.col_ok) return;
     float mean[8], rstd[8], ka[8], kb[8];
     gn_consts(p, c, mean, rstd);
+    if (!c.col_ok) return;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         const float g = p.gamma[c.c0 + e];
@@ -239,9 +256,10 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
     float lsel = 0.f, lsq = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) { col[0][e] = 0.f; col[1][e] = 0.f; col[2][e] = 0.f; }
+    float mean[8], rstd[8];
+    gn_consts(p, c, mean, rstd);
     if (c.col_ok) {
-        float mean[8], rstd[8], gam[8], bet[8];
-        gn_consts(p, c, mean, rstd);
+        float gam[8], bet[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c.c0 + e]; bet[e] = p.beta[c.c0 + e]; }
         const T* y = reinterpret_cast<const T*>(p.y);
@@ -258,7 +276,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
                 const float z = xh * gam[e] + bet[e];
                 float dz;
                 if constexpr (FROM_LOSS) {
-                    const float o = tanhf(z);
+                    const float o = tanh_f(z);
                     const float df = o - d[e];
                     lsel += loss_val(p.loss_type, df);
                     lsq += df * df;
@@ -298,14 +316,34 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, 
     const int g = blockIdx.x, b = blockIdx.y;
     const int c_lo = g * p.Cg, c_hi = c_lo + p.Cg;
     const float* part = p.part + ((long)b * RS * 3) * p.C;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
-        float A = 0.f, Bv = 0.f;
-        for (int r = 0; r < RS; ++r) { A += part[((long)r * 3 + 0) * p.C + c]; Bv += part[((long)r * 3 + 1) * p.C + c]; }
-        const float gm = p.gamma[c];
-        s1 += gm * A; s2 += gm * Bv;
-    }
+    // thread = (column lane cl, row lane rl): narrow groups use the spare threads to split the RS partial rows
+    int CP = 256;
+    while (CP >= 2 * p.Cg && CP > 1) CP >>= 1;
+    const int RLn = 256 / CP;
+    const int cl = threadIdx.x % CP, rl = threadIdx.x / CP;
+    const bool single = p.Cg <= CP;          // one column per thread: the sums stay in registers for the second half
+    __shared__ float smr[3][256];
     __shared__ float sm[8];
+    float A = 0.f, Bv = 0.f, X = 0.f;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c0 = c_lo; c0 < c_hi; c0 += CP) {
+        const int c = c0 + cl;
+        A = 0.f; Bv = 0.f; X = 0.f;
+        if (c < c_hi)
+            for (int r = rl; r < RS; r += RLn) {
+                A += part[((long)r * 3 + 0) * p.C + c];
+                Bv += part[((long)r * 3 + 1) * p.C + c];
+                X += part[((long)r * 3 + 2) * p.C + c];
+            }
+        if (RLn > 1) {
+            smr[0][threadIdx.x] = A; smr[1][threadIdx.x] = Bv; smr[2][threadIdx.x] = X;
+            __syncthreads();
+            if (rl == 0)
+                for (int k = 1; k < RLn; ++k) { A += smr[0][k * CP + cl]; Bv += smr[1][k * CP + cl]; X += smr[2][k * CP + cl]; }
+            __syncthreads();
+        }
+        if (rl == 0 && c < c_hi) { const float gm = p.gamma[c]; s1 += gm * A; s2 += gm * Bv; }
+    }
     const float w1 = wave_sum(s1), w2 = wave_sum(s2);
     if ((threadIdx.x & 63) == 0) { sm[(threadIdx.x >> 6) * 2] = w1; sm[(threadIdx.x >> 6) * 2 + 1] = w2; }
     __syncthreads();
@@ -315,6 +353,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, 
         p.sums2[((long)b * p.G + g) * 2 + 0] = (double)s1;
         p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
     }
+    if (rl != 0) return;
     const double n = (double)p.Cg * (double)p.T;
     const double sm_ = p.sums[((long)b * p.G + g) * 2 + 0], ss_ = p.sums[((long)b * p.G + g) * 2 + 1];
     const double mean = sm_ / n;
@@ -322,12 +361,14 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, 
     if (var < 0.0) var = 0.0;
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
     const float m1 = (float)((double)s1 / n), m2 = (float)((double)s2 / n);
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
-        float A = 0.f, Bv = 0.f, X = 0.f;
-        for (int r = 0; r < RS; ++r) {
-            A += part[((long)r * 3 + 0) * p.C + c];
-            Bv += part[((long)r * 3 + 1) * p.C + c];
-            X += part[((long)r * 3 + 2) * p.C + c];
+    for (int c = c_lo + cl; c < c_hi; c += CP) {
+        if (!single) {
+            A = 0.f; Bv = 0.f; X = 0.f;
+            for (int r = 0; r < RS; ++r) {
+                A += part[((long)r * 3 + 0) * p.C + c];
+                Bv += part[((long)r * 3 + 1) * p.C + c];
+                X += part[((long)r * 3 + 2) * p.C + c];
+            }
         }
         atomicAdd(p.dbeta + c, A);
         atomicAdd(p.dgamma + c, Bv);
@@ -335,17 +376,22 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, 
     }
 }
 
-// out[c] = sum over `rows` partial rows of part[row][c]; one block = 64 columns x 4 row-lanes
+// out[c] = sum over `rows` partial rows of part[row][c]; one block = 16 columns x 16 row-lanes
 __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part, int rows, int C, float* out) {
-    const int c = blockIdx.x * 64 + (threadIdx.x & 63);
-    const int rl = threadIdx.x >> 6;
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     float a = 0.f;
     if (c < C)
-        for (int r = rl; r < rows; r += 4) a += part[(long)r * C + c];
-    __shared__ float sm[4][64];
-    sm[rl][threadIdx.x & 63] = a;
+        for (int r = rl; r < rows; r += 16) a += part[(long)r * C + c];
+    __shared__ float sm[16][17];
+    sm[rl][cl] = a;
     __syncthreads();
-    if (rl == 0 && c < C) out[c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (rl == 0 && c < C) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cl];
+        out[c] = t;
+    }
 }
 
 // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]   (pure streaming pass: read y, dOut; write dY)
@@ -353,18 +399,15 @@ template <typename T, int ACT, bool FROM_LOSS>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
     float dotacc = 0.f;
+    float mean[8], rstd[8], m1[8], m2[8];
+    gn_consts<true>(p, c, mean, rstd, m1, m2);
     if (c.col_ok) {
-        float mean[8], rstd[8], gam[8], bet[8], m1[8], m2[8], cb[8];
-        gn_consts(p, c, mean, rstd);
-        const double n = (double)p.Cg * (double)p.T;
+        float gam[8], bet[8], cb[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             gam[e] = p.gamma[c.c0 + e];
             bet[e] = p.beta[c.c0 + e];
             cb[e] = p.cbias ? p.cbias[c.c0 + e] : 0.f;
-            const int g = (c.c0 + e) / p.Cg;
-            m1[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 0] / n);
-            m2[e] = (float)(p.sums2[((long)c.b * p.G + g) * 2 + 1] / n);
         }
         const T* y = reinterpret_cast<const T*>(p.y);
         const T* dout = reinterpret_cast<const T*>(p.dout);
@@ -380,7 +423,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
                 const float z = xh * gam[e] + bet[e];
                 float dz;
                 if constexpr (FROM_LOSS) {
-                    const float o = tanhf(z);
+                    const float o = tanh_f(z);
                     dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
                 } else {
                     dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
@@ -521,7 +564,7 @@ int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
         else { if (mode == 1) GN_LAUNCH_R((act_kernel<float, 1>), p, s); else GN_LAUNCH_R((act_kernel<float, 2>), p, s); }
         // combine the per-block column sums into the bias gradient
         GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 64)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
+        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 16)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
         return 0;
     }
     if (dtype == 1) {

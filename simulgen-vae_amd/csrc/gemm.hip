@@ -1538,7 +1538,8 @@ static inline int cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 // tests/test_kernels_gpu.py::test_gemm_nt_wide_stress.
 static bool gemm_nt_is_wide(int dtype, int N, long steps) {
     static const int use_wide = getenv("SGV_GEMM_WIDE") ? atoi(getenv("SGV_GEMM_WIDE")) : 1;
-    return use_wide && dtype == 1 && N >= 256 && steps >= 64;
+    static const int min_steps = getenv("SGV_WIDE_MIN_STEPS") ? atoi(getenv("SGV_WIDE_MIN_STEPS")) : 64;
+    return use_wide && dtype == 1 && N >= 256 && steps >= min_steps;
 }
 static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int min_steps, double slots = 768.0) {
     int best = 1;

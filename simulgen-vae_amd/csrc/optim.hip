@@ -155,7 +155,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
     if (a.sn >= 0) {
         const SNDesc d = sn[a.sn];
         inv_sigma = d.sigma[1];
-        cdot = d.dot[0];
+#pragma unroll
+        for (int k = 0; k < SGV_DOT_SLOTS; ++k) cdot += d.dot[k];
         u = d.u; v = d.v;
     }
     const long rc = (long)a.rows * a.cols;

@@ -57,6 +57,8 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 
 // exact-erf GELU (nn.GELU default) and derivative
 __device__ __forceinline__ float gelu_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752f)); }
+// tanh through one exp and one fast divide (absolute error ~1e-7; libm tanhf made the recon-head passes VALU-bound)
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - __fdividef(2.0f, __expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float gelu_grad_f(float x) {
     return 0.5f * (1.0f + erff(x * 0.70710678118654752f)) + x * __expf(-0.5f * x * x) * 0.39894228040143268f;
 }

@@ -68,7 +68,7 @@ struct SNDesc {
     float* tmp_t;      // [taps*cols] scratch: W^T u
     float* tmp_s;      // [rows]      scratch: W v
     float* sigma;      // [2]: sigma, 1/sigma
-    float* dot;        // <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
+    float* dot;        // [SGV_DOT_SLOTS] partial <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
     const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
     int taps, rows, cols;
     int active;        // participates in this forward
@@ -83,6 +83,9 @@ struct AdamDesc {
     int taps;
 };
 struct WorkItem { int desc; int chunk; };
+// <G,W_eff> is accumulated with float atomics from every block of the dY kernels: spread over this many slots
+// (summed by the AdamW pass) so the adds do not serialise on one address.
+constexpr int SGV_DOT_SLOTS = 32;
 
 int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,
                            int ndesc, int train, hipStream_t s);
