@@ -107,7 +107,9 @@ struct sgv_engine {
     char* copies = nullptr; size_t n_copies = 0;
     char* act = nullptr; size_t act_bytes = 0, act_used = 0;
     double* stats = nullptr; size_t n_stats = 0, n_stats_fwd = 0;  // [fwd sums | bwd sums2]
-    float* sn_tmp = nullptr; size_t n_sn_tmp = 0;
+    float* sn_tmp = nullptr; size_t n_sn_tmp = 0;   // [tmp_t of fused layers][tmp_t of the others][tmp_s of all]
+    size_t n_sn_tmp_fused = 0, sn_tmp_s_off = 0;
+    bool wtu_fresh = false;                          // tmp_t of the fused layers holds W^T u for the current weights
     float* sn_sigma = nullptr;
     float* sn_dot_dummy = nullptr;
     double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
@@ -118,7 +120,9 @@ struct sgv_engine {
     SNDesc* sn_dev = nullptr; std::vector<SNDesc> sn_host;
     AdamDesc* adam_dev = nullptr; std::vector<AdamDesc> adam_host;
     WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr, *items_copy = nullptr, *items_wct = nullptr;
+    WorkItem *items_sn_unf = nullptr, *items_adam_flat = nullptr, *items_adam_2d = nullptr;
     int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0, n_items_copy = 0, n_items_wct = 0;
+    int n_items_sn_unf = 0, n_items_adam_flat = 0, n_items_adam_2d = 0;
     // graph
     std::vector<Block> encA, encR, decU, decD, decP1, decP2, decX, decQ1, decQ2;
     Block decS, recon;
@@ -542,6 +546,9 @@ static void rebase_all(sgv_engine* e) {
 }
 
 // ---- descriptor tables --------------------------------------------------------------------------
+// conv weights that train go through the tiled AdamW (optim.hip adamw_sn_kernel), which also leaves W_new^T u
+// behind for the next forward's power iteration
+static bool layer_fused_adam(const Layer& l) { return l.used && l.has_grad && l.op != OP_LINEAR && l.cin % 4 == 0; }
 static int build_tables(sgv_engine* e) {
     // compute copies
     size_t nc = 0;
@@ -554,7 +561,11 @@ static int build_tables(sgv_engine* e) {
     // SN scratch
     size_t nt = 0;
     int si = 0;
-    for (auto& l : e->layers) { l.sn = si++; nt += align_up((size_t)l.cin * l.k, 4) + align_up((size_t)l.cout, 4); }
+    for (auto& l : e->layers) { l.sn = si++; if (layer_fused_adam(l)) nt += align_up((size_t)l.cin * l.k, 4); }
+    e->n_sn_tmp_fused = nt;
+    for (auto& l : e->layers) if (!layer_fused_adam(l)) nt += align_up((size_t)l.cin * l.k, 4);
+    e->sn_tmp_s_off = nt;
+    for (auto& l : e->layers) nt += align_up((size_t)l.cout, 4);
     e->n_sn_tmp = nt;
     return 0;
 }
@@ -562,14 +573,15 @@ static int build_tables(sgv_engine* e) {
 static int upload_tables(sgv_engine* e) {
     const int L = (int)e->layers.size();
     e->sn_host.resize(L);
-    size_t to = 0;
-    std::vector<WorkItem> i_sn, i_dot, i_adam, i_copy, i_wct;
+    size_t to_f = 0, to_u = e->n_sn_tmp_fused, to_s = e->sn_tmp_s_off;
+    std::vector<WorkItem> i_sn, i_sn_unf, i_dot, i_adam, i_adam_flat, i_adam_2d, i_copy, i_wct;
     for (int i = 0; i < L; ++i) {
         Layer& l = e->layers[i];
         SNDesc d;
         d.W = e->params + l.w; d.u = e->params + l.u; d.v = e->params + l.v;
-        d.tmp_t = e->sn_tmp + to; to += align_up((size_t)l.cin * l.k, 4);
-        d.tmp_s = e->sn_tmp + to; to += align_up((size_t)l.cout, 4);
+        size_t& to_t = layer_fused_adam(l) ? to_f : to_u;
+        d.tmp_t = e->sn_tmp + to_t; to_t += align_up((size_t)l.cin * l.k, 4);
+        d.tmp_s = e->sn_tmp + to_s; to_s += align_up((size_t)l.cout, 4);
         d.sigma = e->sn_sigma + 2 * i;
         d.dot = l.has_grad ? e->grads + l.gdot : e->sn_dot_dummy;
         d.G = l.has_grad ? e->grads + l.gw : nullptr;
@@ -577,7 +589,7 @@ static int upload_tables(sgv_engine* e) {
         e->sn_host[i] = d;
         if (l.used) {
             const int rb = (l.cout + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (l.cin + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
-            for (int c = 0; c < l.k * rb * cb; ++c) i_sn.push_back({i, c});
+            for (int c = 0; c < l.k * rb * cb; ++c) { i_sn.push_back({i, c}); if (!layer_fused_adam(l)) i_sn_unf.push_back({i, c}); }
         }
         if (l.has_grad && l.op == OP_LINEAR) {   // conv layers get <G,W_eff> from their dY kernels (ew.hip)
             const long nch = (l.nw() + OPT_CHUNK - 1) / OPT_CHUNK;
@@ -585,14 +597,18 @@ static int upload_tables(sgv_engine* e) {
         }
     }
     e->adam_host.clear();
-    auto add_adam = [&](size_t p, size_t g, long n, int sn, int rows, int cols, int taps, void* wc, void* wct) {
+    auto add_adam = [&](size_t p, size_t g, long n, int sn, int rows, int cols, int taps, void* wc, void* wct, bool tiled = false) {
         AdamDesc a;
         a.p = e->params + p; a.g = e->grads + g; a.m = e->adam_m + g; a.v = e->adam_v + g;
         a.n = n; a.sn = sn; a.rows = rows; a.cols = cols; a.taps = taps; a.wc = wc; a.wct = wct;
         const int id = (int)e->adam_host.size();
         e->adam_host.push_back(a);
         const long nch = (n + OPT_CHUNK - 1) / OPT_CHUNK;
-        for (long c = 0; c < nch; ++c) i_adam.push_back({id, (int)c});
+        for (long c = 0; c < nch; ++c) { i_adam.push_back({id, (int)c}); if (!tiled) i_adam_flat.push_back({id, (int)c}); }
+        if (tiled) {
+            const int rt6 = (rows + 63) / 64, ct6 = (cols + 63) / 64;
+            for (int c = 0; c < taps * rt6 * ct6; ++c) i_adam_2d.push_back({id, c});
+        }
         return id;
     };
     for (int i = 0; i < L; ++i) {
@@ -601,7 +617,7 @@ static int upload_tables(sgv_engine* e) {
         void* wct = l.wct != NPOS ? (void*)(e->copies + l.wct * e->esz) : nullptr;
         int id = -1;
         if (l.has_grad) {
-            id = add_adam(l.w, l.gw, l.nw(), i, l.cout, l.cin, l.k, wc, wct);
+            id = add_adam(l.w, l.gw, l.nw(), i, l.cout, l.cin, l.k, wc, wct, layer_fused_adam(l));
             add_adam(l.b, l.gb, l.cout, -1, 1, l.cout, 1, nullptr, nullptr);
         }
         if (wc || wct) {
@@ -637,6 +653,10 @@ static int upload_tables(sgv_engine* e) {
     if (up(i_adam.data(), sizeof(WorkItem) * i_adam.size(), (void**)&e->items_adam)) return fail(SGV_ERR_HIP, "table upload failed");
     if (up(i_copy.data(), sizeof(WorkItem) * i_copy.size(), (void**)&e->items_copy)) return fail(SGV_ERR_HIP, "table upload failed");
     if (up(i_wct.data(), sizeof(WorkItem) * i_wct.size(), (void**)&e->items_wct)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_sn_unf.data(), sizeof(WorkItem) * i_sn_unf.size(), (void**)&e->items_sn_unf)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_adam_flat.data(), sizeof(WorkItem) * i_adam_flat.size(), (void**)&e->items_adam_flat)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_adam_2d.data(), sizeof(WorkItem) * i_adam_2d.size(), (void**)&e->items_adam_2d)) return fail(SGV_ERR_HIP, "table upload failed");
+    e->n_items_sn_unf = (int)i_sn_unf.size(); e->n_items_adam_flat = (int)i_adam_flat.size(); e->n_items_adam_2d = (int)i_adam_2d.size();
     e->n_items_sn = (int)i_sn.size(); e->n_items_dot = (int)i_dot.size();
     e->n_items_adam = (int)i_adam.size(); e->n_items_copy = (int)i_copy.size(); e->n_items_wct = (int)i_wct.size();
     return 0;
@@ -916,7 +936,8 @@ int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot_dummy,
-                    e->scal, e->partial, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct};
+                    e->scal, e->partial, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
+                    e->items_sn_unf, e->items_adam_flat, e->items_adam_2d};
     for (void* p : ptrs) if (p) hipFree(p);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     delete e;
@@ -997,9 +1018,16 @@ static int refresh_copies(sgv_engine* e) {
 }
 
 static int run_sn(sgv_engine* e, int train) {
-    HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp * 4, e->stream));
-    if (opt_sn_power_iteration(e->sn_dev, e->items_sn, e->n_items_sn, e->items_sn, e->n_items_sn, (int)e->layers.size(), train, e->stream))
+    // tmp_t of the fused layers may already hold W^T u from the last AdamW pass (still valid: neither W nor u
+    // changed since); eval forwards never read or clobber it
+    const bool reuse = train && e->wtu_fresh;
+    const size_t z0 = !train ? e->sn_tmp_s_off : (reuse ? e->n_sn_tmp_fused : 0);
+    HIPCHK(hipMemsetAsync(e->sn_tmp + z0, 0, (e->n_sn_tmp - z0) * 4, e->stream));
+    const WorkItem* it1 = reuse ? e->items_sn_unf : e->items_sn;
+    const int n1 = reuse ? e->n_items_sn_unf : e->n_items_sn;
+    if (opt_sn_power_iteration(e->sn_dev, it1, n1, e->items_sn, e->n_items_sn, (int)e->layers.size(), train, e->stream))
         return fail(SGV_ERR_HIP, "spectral-norm launch failed");
+    if (train) e->wtu_fresh = false;     // u moved
     return 0;
 }
 
@@ -1024,6 +1052,7 @@ int sgv_load_state(sgv_engine* e, const char* name, const float* host, size_t co
     permute_entry(e, *s, host, tmp.data(), +1);
     HIPCHK(hipMemcpy(e->params + entry_param_offset(e, *s), tmp.data(), count * 4, hipMemcpyHostToDevice));
     e->copies_fresh = false;
+    e->wtu_fresh = false;
     return SGV_OK;
 }
 
@@ -1440,13 +1469,15 @@ int sgv_adamw_step(sgv_engine* e, float lr) {
     const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
     const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
     HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
-    if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+    // biases, GroupNorm affine and the Linear heads: flat pass.  Conv weights: tiled pass that also writes both
+    // compute copies and W_new^T u for the next forward's power iteration.
+    if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat, e->n_items_adam_flat, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    // bf16 mode: AdamW wrote the [tap][Cout][Cin] compute copy itself; only the transposed copy is left
-    if (e->dt == SGV_DTYPE_BF16 || true) {
-        if (opt_make_wct(e->adam_dev, e->items_wct, e->n_items_wct, e->dt, e->stream)) return fail(SGV_ERR_HIP, "make_wct launch failed");
-        e->copies_fresh = true;
-    }
+    if (e->n_sn_tmp_fused) HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp_fused * 4, e->stream));
+    if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d, e->n_items_adam_2d, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+        return fail(SGV_ERR_HIP, "adamw launch failed");
+    e->copies_fresh = true;
+    e->wtu_fresh = true;
     return SGV_OK;
 }
 

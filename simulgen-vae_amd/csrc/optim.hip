@@ -203,6 +203,104 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(gnorm_sq, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
 }
+// ---- AdamW over 64x64 tiles of the spectrally-normalised conv weights ------------------------------
+// Same update as adamw_kernel, plus everything else that needs the freshly updated weight while it is in
+// registers: the compute-dtype copy wc, the transposed/tap-flipped copy wct (through an LDS tile) and the
+// first half of the NEXT forward's power iteration, tmp_t[tap][c] += sum_r W_new[r][c] * u[r]  (u is only
+// modified by the forward itself).  Saves two full passes over the 1.6 GB of master weights per step.
+template <typename T>
+__global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
+                                                      float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
+                                                      double* gnorm_sq) {
+    constexpr int PITCH = 64 + (sizeof(T) == 2 ? 2 : 1);
+    __shared__ T tile[64 * PITCH];
+    __shared__ float tus[16][64];
+    __shared__ float sm[4];
+    const WorkItem it = items[blockIdx.x];
+    const AdamDesc a = adam[it.desc];
+    const SNDesc d = sn[a.sn];
+    const int ct = (a.cols + 63) >> 6, rt = (a.rows + 63) >> 6;
+    const int tap = it.chunk / (rt * ct);
+    const int rem = it.chunk - tap * rt * ct;
+    const int r0 = (rem / ct) << 6, c0 = (rem % ct) << 6;
+    const float inv_sigma = d.sigma[1];
+    float cdot = 0.f;
+#pragma unroll
+    for (int k = 0; k < SGV_DOT_SLOTS; ++k) cdot += d.dot[k];
+    const int cq = threadIdx.x & 15, rr = threadIdx.x >> 4;
+    const int col = c0 + cq * 4;
+    const bool cok = col < a.cols;          // cols % 4 == 0 (checked on the host)
+    float4 vv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (cok) vv = *reinterpret_cast<const float4*>(d.v + (long)tap * a.cols + col);
+    const long base = (long)tap * a.rows * a.cols;
+    T* wc = reinterpret_cast<T*>(a.wc);
+    const float step = lr / bc1, decay = 1.f - lr * wd;
+    float t0 = 0.f, t1 = 0.f, t2 = 0.f, t3 = 0.f, nacc = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int rl = k * 16 + rr, row = r0 + rl;
+        float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (cok && row < a.rows) {
+            const long i = base + (long)row * a.cols + col;
+            float4 g = *reinterpret_cast<const float4*>(a.g + i);
+            p = *reinterpret_cast<const float4*>(a.p + i);
+            float4 m = *reinterpret_cast<const float4*>(a.m + i);
+            float4 vs = *reinterpret_cast<const float4*>(a.v + i);
+            const float u_r = d.u[row];
+            const float ur = u_r * cdot;
+            g.x = (g.x - ur * vv.x) * inv_sigma; g.y = (g.y - ur * vv.y) * inv_sigma;
+            g.z = (g.z - ur * vv.z) * inv_sigma; g.w = (g.w - ur * vv.w) * inv_sigma;
+            nacc += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
+#define SGV_ADAM1(F)                                                    \
+            p.F *= decay;                                               \
+            m.F = m.F * b1 + (1.f - b1) * g.F;                          \
+            vs.F = vs.F * b2 + (1.f - b2) * g.F * g.F;                  \
+            p.F -= step * (m.F / (sqrtf(vs.F) / bc2sqrt + eps));
+            SGV_ADAM1(x) SGV_ADAM1(y) SGV_ADAM1(z) SGV_ADAM1(w)
+#undef SGV_ADAM1
+            *reinterpret_cast<float4*>(a.p + i) = p;
+            *reinterpret_cast<float4*>(a.m + i) = m;
+            *reinterpret_cast<float4*>(a.v + i) = vs;
+            if constexpr (sizeof(T) == 2) {
+                if (wc) {
+                    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+                    bf16x4_t o;
+                    o[0] = (__bf16)p.x; o[1] = (__bf16)p.y; o[2] = (__bf16)p.z; o[3] = (__bf16)p.w;
+                    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(a.wc) + i) = o;
+                }
+            }
+            t0 += p.x * u_r; t1 += p.y * u_r; t2 += p.z * u_r; t3 += p.w * u_r;
+        }
+        T* trow = tile + rl * PITCH + cq * 4;
+        trow[0] = from_f32<T>(p.x); trow[1] = from_f32<T>(p.y); trow[2] = from_f32<T>(p.z); trow[3] = from_f32<T>(p.w);
+    }
+    tus[rr][cq * 4 + 0] = t0; tus[rr][cq * 4 + 1] = t1; tus[rr][cq * 4 + 2] = t2; tus[rr][cq * 4 + 3] = t3;
+    const float w = wave_sum(nacc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(gnorm_sq, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+    if (threadIdx.x < 64 && c0 + (int)threadIdx.x < a.cols) {
+        float t = 0.f;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += tus[k][threadIdx.x];
+        atomicAdd(d.tmp_t + (long)tap * a.cols + c0 + threadIdx.x, t);
+    }
+    if (a.wct) {
+        T* dst = reinterpret_cast<T*>(a.wct) + (long)(a.taps - 1 - tap) * a.rows * a.cols;
+        const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+        for (int r = ty; r < 64; r += 4) {
+            const int cc = c0 + r, row = r0 + tx;
+            if (row < a.rows && cc < a.cols) dst[(long)cc * a.rows + row] = tile[tx * PITCH + r];
+        }
+    }
+}
+int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
+                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s) {
+    if (n <= 0) return 0;
+    if (compute_dtype == 1) hipLaunchKernelGGL((adamw_sn_kernel<bf16_t>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+    else hipLaunchKernelGGL((adamw_sn_kernel<float>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
               float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s) {
     if (n > 0 && compute_dtype == 1) hipLaunchKernelGGL((adamw_kernel<true, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
