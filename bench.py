@@ -55,6 +55,19 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+def load_traffic():
+    """HBM bytes per kernel from the newest committed PMC summary (profiles/rNN_traffic.json, written by
+    tools/summarize_profile.py traffic from separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this bench)."""
+    import glob
+    files = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r*_traffic.json")))
+    if not files:
+        return None
+    with open(files[-1]) as f:
+        t = json.load(f)
+    t["_source"] = "profiles/" + os.path.basename(files[-1])
+    return t
+
+
 def cpu_baseline(sample_batch, cores):
     """oracle/torch_port.py (PyTorch-CPU restatement of the reference step: same ATen conv/GroupNorm
     kernels the reference's CPU path runs) timed on this box's host cores on a bounded sample: full
@@ -88,6 +101,7 @@ def main():
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--layer-times", action="store_true", help="print a per-layer GEMM table (stderr) after the run")
     args = ap.parse_args()
 
     import torch
@@ -210,30 +224,61 @@ def main():
                              "parallelism": f"dp{world}", "losses_finite": finite},
                   "step_tflops": round((fwd + dx + dw) / (ms * 1e-3) / 1e12, 2),
                   "roofline": roof}
-    # per-kernel durations (hipEvents on the engine's stream), outside the timed region
+    # per-kernel durations (hipEvents on the engine's stream around each GEMM's main kernel), outside the timed region
     if not args.no_kernel_timing:
-        eng.kernel_time_reset(True)
+        eng.kernel_time_reset(2)
         nt = 2
         for i in range(nt):
             one_step(10_000 + i)
-        t_nt, c_nt = eng.kernel_time("gemm_nt")
-        t_tn, c_tn = eng.kernel_time("gemm_tn")
+        tags = eng.kernel_time_tags()
         eng.kernel_time_reset(False)
-        if rank == 0 and c_nt > 0:
-            fwd, dx, dw = gemm_flops(cfg, B)
-            ach = (fwd + dx) * nt / (t_nt * 1e-3) / 1e12
-            roof = result["roofline"]
-            roof["achieved"] = round(ach, 2)
-            roof["frac"] = round(ach / roof["peak"], 4)
-            roof["launches_per_step"] = c_nt // nt
-            roof["avg_launch_ms"] = round(t_nt / c_nt, 4)
-            roof["ms_per_step"] = round(t_nt / nt, 3)
-            ach_tn = dw * nt / (t_tn * 1e-3) / 1e12 if t_tn > 0 else None
-            result["roofline_gemm_tn"] = {"kernel": "gemm_tn_kernel (weight-gradient GEMM)", "bound": "mfma",
-                                          "achieved": round(ach_tn, 2) if ach_tn else None, "peak": roof["peak"],
-                                          "unit": "TFLOP/s", "frac": round(ach_tn / roof["peak"], 4) if ach_tn else None,
-                                          "ms_per_step": round(t_tn / nt, 3), "launches_per_step": c_tn // nt,
-                                          "flop_per_step": dw}
+        if rank == 0:
+            cls_stat = {}
+            for tag, tms, calls in tags:
+                if "|" not in tag:
+                    continue
+                cls, _layer, shape = tag.split("|")
+                d = dict(kv.split("=") for kv in shape.split())
+                fl = 2.0 * int(d["M"]) * int(d["N"]) * int(d["K"]) * int(d["taps"]) * calls
+                st = cls_stat.setdefault(cls, [0.0, 0.0, 0])
+                st[0] += fl; st[1] += tms; st[2] += calls
+            traffic = load_traffic()
+
+            def roof_obj(cls, kernel, note):
+                fl, tms, calls = cls_stat.get(cls, (0.0, 0.0, 0))
+                if calls == 0 or tms <= 0:
+                    return None
+                ach = fl / (tms * 1e-3) / 1e12
+                o = {"kernel": kernel, "bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s",
+                     "frac": round(ach / peak, 4), "traffic": None, "launches_per_step": calls // nt,
+                     "avg_launch_ms": round(tms / calls, 4), "ms_per_step": round(tms / nt, 3),
+                     "flop_per_launch": round(fl / calls), "note": note}
+                t = traffic.get(kernel.split(" ")[0]) if traffic else None
+                if t and t.get("launches"):
+                    o["traffic"] = round((t["fetch_bytes"] + t["write_bytes"]) / t["launches"])
+                    o["traffic_source"] = traffic.get("_source")
+                return o
+            result["roofline"] = roof_obj(
+                "gemm_nt_wide", "gemm_nt_wide64p_kernel (conv forward / input-gradient implicit GEMM, 128x256 tiles, LDS-DMA ring)",
+                "achieved = sum over its launches of 2*M*N*K*taps / sum of hipEvent durations of the main kernel; "
+                "traffic = (FETCH_SIZE x2 + WRITE_SIZE) per launch from the committed rocprofv3 --pmc passes") or result["roofline"]
+            result["roofline_gemm_nt_128"] = roof_obj("gemm_nt", "gemm_nt_kernel (128x128 tiles: N < 256 or short K)", "same accounting")
+            result["roofline_gemm_tn"] = roof_obj("gemm_tn", "gemm_tn_kernel (weight-gradient GEMM, 128x128 tiles)", "same accounting")
+    if args.layer_times and rank == 0:
+        eng.kernel_time_reset(2)
+        one_step(20_000)
+        rows = []
+        for tag, tms, calls in eng.kernel_time_tags():
+            if "|" not in tag:
+                continue
+            cls, layer, shape = tag.split("|")
+            d = dict(kv.split("=") for kv in shape.split())
+            fl = 2.0 * int(d["M"]) * int(d["N"]) * int(d["K"]) * int(d["taps"])
+            rows.append((tms / calls, cls, layer, shape, fl / (tms / calls * 1e-3) / 1e12))
+        eng.kernel_time_reset(False)
+        print("[bench] per-layer GEMM times (one step, hipEvents around the main kernel of each launch):", file=sys.stderr)
+        for tms, cls, layer, shape, tf in sorted(rows, reverse=True):
+            print(f"  {tms * 1e3:8.1f} us  {tf:7.1f} TF/s  {cls:8s} {layer:58s} {shape}", file=sys.stderr)
     if rank == 0:
         if world == 1 and args.cpu_baseline == "auto":
             eng.close()

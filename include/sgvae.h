@@ -159,7 +159,10 @@ size_t sgv_dataset_sample_bytes(const sgv_engine* e);
 /* Profiling aid for bench.py: hipEvent-timed duration (total ms and number of launches since the
  * last reset) of a kernel class ("gemm_nt", "gemm_tn"), measured on the engine's own stream. [sync] */
 int sgv_kernel_time(sgv_engine* e, const char* which, float* total_ms, int* calls);
-int sgv_kernel_time_reset(sgv_engine* e, int enable);
+int sgv_kernel_time_reset(sgv_engine* e, int enable);   /* 0 off, 1 per class, 2 per (class, layer, shape) */
+/* Walk the timer tags recorded since the engine was created: index 0.. until the return value is
+ * non-zero.  name receives "class" or "class|layer prefix|M=.. N=.. K=.. taps=.. splitk=..". [sync] */
+int sgv_kernel_time_tag(sgv_engine* e, int index, char* name, size_t cap, float* total_ms, int* calls);
 
 /* Low-level kernel entry points, exported for the unit parity tests (tests/test_kernels_gpu.py).
  * All pointers are device pointers; dtype is SGV_DTYPE_*.  [sync] */

@@ -141,7 +141,7 @@ struct sgv_engine {
     float scalars_host[SGV_MAX_SCALARS];
     sgv_bucket_cb cb = nullptr; void* cb_user = nullptr;
     std::vector<std::pair<size_t, size_t>> buckets;   // (offset, count) in grad arena, backward order
-    bool timing = false;
+    bool timing = false, timing_detail = false;
     std::vector<TimerRec> timers;
     std::map<std::string, int> tag_ids;
     std::vector<std::string> tag_names;
@@ -672,16 +672,27 @@ static int tag_id(sgv_engine* e, const std::string& name) {
     e->tag_ids[name] = id; e->tag_names.push_back(name);
     return id;
 }
+// Times the MAIN kernel of a GEMM launch (split-K combine passes are excluded so the numbers line up with the
+// rocprofv3 per-kernel averages in profiles/).
 struct ScopedTimer {
-    sgv_engine* e; TimerRec r; bool on;
-    ScopedTimer(sgv_engine* e_, const char* cls, const Layer* l) : e(e_), on(e_->timing) {
+    sgv_engine* e; TimerRec r; bool on; bool ended = false;
+    void end_now() { if (on && !ended) { hipEventRecord(r.b, e->stream); ended = true; } }
+    // detail (sgv_kernel_time_reset(e, 2)): one tag per (class, layer, shape) instead of one per class
+    ScopedTimer(sgv_engine* e_, const char* cls, const Layer* l, int M = 0, int N = 0, int K = 0, int taps = 0, int sk = 0)
+        : e(e_), on(e_->timing) {
         if (!on) return;
         hipEventCreate(&r.a); hipEventCreate(&r.b);
-        r.tag = tag_id(e, std::string(cls));
-        (void)l;
+        std::string name(cls);
+        if (e->timing_detail && l) {
+            char buf[160];
+            snprintf(buf, sizeof(buf), "|%s|M=%d N=%d K=%d taps=%d splitk=%d", l->prefix.c_str(), M, N, K, taps, sk);
+            name += buf;
+        }
+        r.tag = tag_id(e, name);
         hipEventRecord(r.a, e->stream);
+        if (!strncmp(cls, "gemm_nt", 7)) { gemm_nt_main_done_event(r.b); ended = true; }
     }
-    ~ScopedTimer() { if (on) { hipEventRecord(r.b, e->stream); e->timers.push_back(r); } }
+    ~ScopedTimer() { if (on) { end_now(); e->timers.push_back(r); } }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -705,7 +716,7 @@ static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor
     p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
     if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    ScopedTimer tm(e, "gemm_nt", &l);
+    ScopedTimer tm(e, gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
     int r = launch_gemm_nt(e->dt, p, e->stream);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d)", l.prefix.c_str(), p.M, p.N, p.K);
     return 0;
@@ -722,7 +733,7 @@ static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
     if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    ScopedTimer tm(e, "gemm_nt", &l);
+    ScopedTimer tm(e, gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
     int r = launch_gemm_nt(e->dt, p, e->stream);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt(dX) launch failed for %s", l.prefix.c_str());
     return 0;
@@ -745,7 +756,7 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     const long nw = l.nw();
     if ((size_t)sk * nw > e->partial_floats) sk = 1;
     float* G = e->grads + l.gw;
-    ScopedTimer tm(e, "gemm_tn", &l);
+    ScopedTimer tm(e, "gemm_tn", &l, p.M, p.N1, p.N2, p.taps, sk);
     if (sk == 1) {
         p.splitk = 1; p.out = G;
         if (launch_gemm_tn(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s", l.prefix.c_str());
@@ -753,6 +764,7 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
         // split-K over the batch*time rows: each slice writes its own fp32 slab (plain stores), then one sum pass
         p.splitk = sk; p.out = e->partial; p.out_slab_stride = nw;
         if (launch_gemm_tn(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s", l.prefix.c_str());
+        tm.end_now();
         int blocks = (int)((nw + 255) / 256); if (blocks > 4096) blocks = 4096;
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, e->stream, G, e->partial, sk, nw);
     }
@@ -1515,6 +1527,18 @@ int sgv_kernel_time_reset(sgv_engine* e, int enable) {
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     e->timers.clear();
     e->timing = enable != 0;
+    e->timing_detail = enable == 2;
+    return SGV_OK;
+}
+int sgv_kernel_time_tag(sgv_engine* e, int index, char* name, size_t cap, float* total_ms, int* calls) {
+    if (!e || !name || cap == 0) return fail(SGV_ERR_ARG, "null argument");
+    if (index < 0 || index >= (int)e->tag_names.size()) return SGV_ERR_ARG;   // end of the list: not an error message
+    HIPCHK(hipStreamSynchronize(e->stream));
+    snprintf(name, cap, "%s", e->tag_names[index].c_str());
+    float tot = 0.f; int n = 0;
+    for (auto& t : e->timers) if (t.tag == index) { float ms = 0.f; hipEventElapsedTime(&ms, t.a, t.b); tot += ms; ++n; }
+    if (total_ms) *total_ms = tot;
+    if (calls) *calls = n;
     return SGV_OK;
 }
 int sgv_kernel_time(sgv_engine* e, const char* which, float* total_ms, int* calls) {

@@ -1555,6 +1555,9 @@ static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int 
     return best;
 }
 
+bool gemm_nt_uses_wide(int dtype, int N, int K, int taps) {
+    return gemm_nt_is_wide(dtype, N, (long)taps * cdiv(K, dtype == 1 ? 32 : 16));
+}
 int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype) {
     const int bk = dtype == 1 ? 32 : 16;
     const long total = (long)taps * cdiv(K, bk);
@@ -1571,7 +1574,13 @@ int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype) {
     return pick_splitk(tiles, total, (double)taps * N1 * N2 * 4.0, 4);
 }
 
+// profiling hook: the next launch_gemm_nt records this event right after its main kernel (before a split-K combine)
+static thread_local hipEvent_t g_main_done = nullptr;
+void gemm_nt_main_done_event(hipEvent_t ev) { g_main_done = ev; }
+
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
+    const hipEvent_t main_done = g_main_done;
+    g_main_done = nullptr;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 0;
     const int epc = dtype == 1 ? 8 : 4;
     if (p.K % epc || p.lda % epc || p.ldw % epc || p.w_tap_stride % epc) return -1;
@@ -1603,6 +1612,7 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
             else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
         }
     }
+    if (main_done) hipEventRecord(main_done, s);
     if (p.splitk > 1) {
         long total = (long)p.M * p.N;
         int blocks = (int)((total + 255) / 256);

@@ -117,4 +117,6 @@ struct GemmTN {
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s);
 int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s);
 int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype);
+void gemm_nt_main_done_event(hipEvent_t ev);
+bool gemm_nt_uses_wide(int dtype, int N, int K, int taps);   // 128x256 software-pipelined kernel vs the 128x128 one
 int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype);

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
-    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
+    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
 ]
 
 
@@ -88,6 +88,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_dataset_sample_bytes.restype = C.c_size_t
     lib.sgv_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(f32), C.POINTER(i32)]
     lib.sgv_kernel_time_reset.argtypes = [vp, i32]
+    lib.sgv_kernel_time_tag.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(f32), C.POINTER(i32)]
     lib.sgv_test_gemm_nt.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sgv_test_gemm_tn.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     _lib = lib
@@ -303,6 +304,18 @@ class Engine:
     # ---- profiling ----
     def kernel_time_reset(self, enable: bool):
         _check(self.lib, self.lib.sgv_kernel_time_reset(self.h, int(enable)), "sgv_kernel_time_reset")
+
+    def kernel_time_tags(self):
+        """[(tag, total_ms, launches)] for every timer tag (per layer and shape after kernel_time_reset(2))."""
+        out, i = [], 0
+        buf = C.create_string_buffer(256)
+        while True:
+            ms, n = C.c_float(), C.c_int()
+            if self.lib.sgv_kernel_time_tag(self.h, i, buf, 256, C.byref(ms), C.byref(n)) != 0:
+                return out
+            if n.value:
+                out.append((buf.value.decode(), ms.value, n.value))
+            i += 1
 
     def kernel_time(self, which: str):
         ms, n = C.c_float(), C.c_int()

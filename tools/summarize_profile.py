@@ -3,6 +3,7 @@
 small per-step summaries committed under profiles/.
   python tools/summarize_profile.py stats  <kernel_stats.csv> <steps_in_run | 0 = count AdamW launches>
   python tools/summarize_profile.py pmc    <counter_collection.csv>      # FETCH_SIZE or WRITE_SIZE pass
+  python tools/summarize_profile.py traffic <fetch.csv> <write.csv>      # JSON read by bench.py (roofline.traffic)
 Counter units: rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts wide coalesced
 reads at half their bytes (MI355X_MICROARCH.md, HBM section) -> reads are multiplied by 2."""
 import collections
@@ -13,7 +14,7 @@ import sys
 def stats(path, steps):
     rows = list(csv.DictReader(open(path)))
     if steps <= 0:   # every training step launches the fused AdamW kernel exactly once
-        steps = sum(int(r["Calls"]) for r in rows if "adamw_kernel<true" in r["Name"])
+        steps = sum(int(r["Calls"]) for r in rows if "adamw_sn_kernel" in r["Name"])
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
     print(f"| kernel | launches/step | ms/step | avg us | % |\n|---|---|---|---|---|")
     for r in rows[:28]:
@@ -27,7 +28,7 @@ def pmc(path):
     rows = list(csv.DictReader(open(path)))
     name = rows[0]["Counter_Name"]
     corr = 2.0 if name == "FETCH_SIZE" else 1.0
-    idx = [i for i, x in enumerate(rows) if x["Kernel_Name"].startswith("void adamw_kernel")]
+    idx = [i for i, x in enumerate(rows) if "adamw_sn_kernel" in x["Kernel_Name"]]
     step = rows[idx[-2] + 1: idx[-1] + 1]
     agg, cnt, dur = collections.Counter(), collections.Counter(), collections.Counter()
     for x in step:
@@ -41,8 +42,39 @@ def pmc(path):
     print(f"\ntotal {sum(agg.values()) / 1e9:.1f} GB/step")
 
 
+def step_rows(path):
+    rows = list(csv.DictReader(open(path)))
+    idx = [i for i, x in enumerate(rows) if "adamw_sn_kernel" in x["Kernel_Name"]]
+    return rows[0]["Counter_Name"], rows[idx[-2] + 1: idx[-1] + 1]
+
+
+def traffic(fetch_csv, write_csv):
+    """JSON for bench.py's roofline.traffic: HBM bytes (reads x2 corrected, writes) and launches of each GEMM kernel
+    over one training step of the profiled run."""
+    import json
+    out = {}
+    for path in (fetch_csv, write_csv):
+        name, step = step_rows(path)
+        corr = 2.0 if name == "FETCH_SIZE" else 1.0
+        for x in step:
+            k = x["Kernel_Name"]
+            fam = next((n for n in ("gemm_nt_wide64p_kernel", "gemm_nt_reduce_kernel", "gemm_nt_kernel", "gemm_tn_kernel",
+                                    "sum_slabs_kernel", "adamw_sn_kernel") if n in k), None)
+            if fam is None:
+                continue
+            d = out.setdefault(fam, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
+            d["fetch_bytes" if name == "FETCH_SIZE" else "write_bytes"] += float(x["Counter_Value"]) * 1024 * corr
+            if name == "FETCH_SIZE":
+                d["launches"] += 1
+    out["note"] = ("one training step of bench.py (batch 16, bf16) under rocprofv3 --pmc; FETCH_SIZE x2 (gfx950 correction, "
+                   "MI355X_MICROARCH.md HBM section), WRITE_SIZE x1, counters in KiB")
+    print(json.dumps(out, indent=1))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "stats":
         stats(sys.argv[2], int(sys.argv[3]))
+    elif sys.argv[1] == "traffic":
+        traffic(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2])
