@@ -78,7 +78,7 @@ def cpu_baseline(sample_batch, cores):
     from simulgen_vae_amd.spec import VAEConfig
     from oracle.torch_port import TorchPortVAE
     torch.set_num_threads(cores)
-    cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", True)
+    cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", args.size == "small")
     m = TorchPortVAE(cfg, init_state(cfg, 7, reference_init=True))
     x = synthetic_samples(20251003, range(sample_batch), N_NODE, N_TIME)
     eps = synthetic_eps(1234, 0, cfg, sample_batch)
@@ -96,7 +96,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
-    ap.add_argument("--dataset", type=int, default=64, help="synthetic samples resident in HBM per rank")
+    ap.add_argument("--size", default="small", choices=["small", "large"],
+                    help="small = the headline config (BASELINE.json configs[1]); large = configs[3] (secondary; all "
+                         "activations stay resident in the 288 GB HBM, so no recompute is needed)")
+    ap.add_argument("--dataset", type=int, default=484, help="synthetic samples resident in HBM per rank")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
@@ -123,7 +126,7 @@ def main():
     from simulgen_vae_amd.init import init_state
     from simulgen_vae_amd.spec import VAEConfig
 
-    cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", True)
+    cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", args.size == "small")
     B = args.batch
     eng = E.Engine(cfg, max_batch=B, compute_dtype=args.dtype)
     t_init = time.time()
@@ -214,12 +217,12 @@ def main():
         roof = {"kernel": "gemm_nt_wide_kernel + gemm_nt_kernel (conv forward + input-gradient implicit GEMMs)", "bound": "mfma",
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "flop_per_step": fwd + dx}
-        result = {"metric": "simulation samples/sec/node (preset-1 small, batch 16)", "value": round(value, 3),
+        result = {"metric": f"simulation samples/sec/node (preset-1 {args.size}, batch 16)", "value": round(value, 3),
                   "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": args.dtype, "data": "synthetic U(-0.7,0.7) [P x 95008 x 200], random-init weights",
-                  "config": {"workload": "preset=1 --size=small, synthetic [P x 200 x 95008], batch 16 per GPU "
-                                         "(BASELINE.json configs[1])", "per_gpu_batch": B, "global_batch": B * world,
+                  "config": {"workload": f"preset=1 --size={args.size}, synthetic [P x 200 x 95008], batch 16 per GPU "
+                                         f"(BASELINE.json configs[{1 if args.size == 'small' else 3}])", "per_gpu_batch": B, "global_batch": B * world,
                              "num_node": N_NODE, "num_time": N_TIME, "filters": ENC, "dataset_samples_per_gpu": P,
                              "parallelism": f"dp{world}", "losses_finite": finite},
                   "step_tflops": round((fwd + dx + dw) / (ms * 1e-3) / 1e12, 2),
