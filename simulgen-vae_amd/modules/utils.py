@@ -138,3 +138,138 @@ def shard_indices(indices, rank, world, batch_size):
     trimmed so that every rank sees the same number of full-or-partial batches."""
     per = len(indices) // world
     return [indices[i * world + rank] for i in range(per)]
+
+
+# ------------------------------------------------------------------------------------------------
+# Post-training evaluation / latent export (reference modules/utils.py:428-596, called from
+# SimulGen-VAE.py:311-344).  Same arguments, prints, return tuples and quirks: one row per *batch* (only the
+# first sample of every batch is stored, exactly as the reference indexes `[0]`), `loss_total` is the sum of
+# the per-batch MSEs, reconstruction PNGs for the first ten batches when matplotlib is importable.
+# ------------------------------------------------------------------------------------------------
+def reparameterize(mu, std, eps=None):
+    """modules/decoder.py:218-223: z = mu + eps * clamp(std, 1e-8, 10); eps ~ N(0,1) unless injected."""
+    std = torch.clamp(std, min=1e-8, max=10.0)
+    if eps is None:
+        eps = torch.randn_like(std)
+    return mu + eps * std
+
+
+def _mse(a, b):
+    return torch.mean((a.float() - b.float()) ** 2)
+
+
+def _dataset_shape(dataloader):
+    ds = dataloader.dataset
+    if hasattr(ds, "dataset"):
+        ds = ds.dataset
+    for attr in ("x_data", "data"):
+        if hasattr(ds, attr):
+            return tuple(getattr(ds, attr).shape)
+    first = next(iter(dataloader))
+    return tuple(first.shape)
+
+
+def evaluate_vae_reconstruction(VAE, dataloader, device, num_param, num_filter_enc, latent_dim, latent_dim_end,
+                                recon_iter=1, dataset_name="Dataset", save_images=True, eps_fn=None):
+    """Encoder -> reparameterise -> `mode='fix'` decoder -> per-batch MSE, keeping the best of `recon_iter` draws.
+    Returns (latent_vectors [num_param, latent_dim_end], hierarchical_latent_vectors [num_param, L-1, latent_dim],
+    reconstruction_loss [num_param], reconstructed [num_param, num_node, num_time], loss_total).
+    `eps_fn(j, i, like)` (not in the reference) injects the reparameterisation noise for parity tests."""
+    save_dir = None
+    if save_images:
+        os.makedirs("checkpoints", exist_ok=True)
+        save_dir = "checkpoints/" + dataset_name.replace(" ", "_").replace("(", "").replace(")", "").lower()
+        os.makedirs(save_dir, exist_ok=True)
+    latent_vectors = np.zeros([num_param, latent_dim_end])
+    hierarchical_latent_vectors = np.zeros([num_param, len(num_filter_enc) - 1, latent_dim])
+    reconstruction_loss = np.zeros([num_param])
+    data_shape = _dataset_shape(dataloader)
+    reconstructed = np.empty([num_param, data_shape[1], data_shape[2]])
+    loss_total = 0
+    print(f"Evaluating {dataset_name}...")
+    j = -1
+    for j, image in enumerate(dataloader):
+        best = 100.0
+        x = VAE._prep(image) if hasattr(VAE, "_prep") else image.to(device)
+        mu, log_var, xs = VAE.encoder(x)
+        loss = None
+        for i in range(recon_iter):
+            std = torch.exp(0.5 * log_var)
+            latent_vector = reparameterize(mu, std, None if eps_fn is None else eps_fn(j, i, std))
+            gen_x, _ = VAE.decoder(latent_vector, xs, mode="fix")
+            loss = _mse(gen_x, x)
+            if float(loss) < best:
+                best = float(loss)
+                latent_vectors[j, :] = latent_vector[0, :].detach().cpu().numpy()
+                for k in range(len(xs)):
+                    hierarchical_latent_vectors[j, k, :] = xs[k].detach().cpu().numpy()[0]
+                reconstruction_loss[j] = best
+                reconstructed[j, :, :] = gen_x[0].detach().float().cpu().numpy()
+        print(f"Parameter {j + 1} finished - MSE: {float(loss):.4E}")
+        loss_total = loss_total + float(loss)
+        if save_images and j < 10:
+            try:
+                import matplotlib
+                matplotlib.use("Agg")
+                import matplotlib.pyplot as plt
+                original = x[0].detach().float().cpu().numpy()
+                recon = reconstructed[j]
+                plt.figure(figsize=(12, 6))
+                nplot = min(3, original.shape[0])
+                for ch in range(nplot):
+                    plt.subplot(nplot, 1, ch + 1)
+                    plt.plot(original[ch], label="Original", alpha=0.7)
+                    plt.plot(recon[ch], label="Reconstructed", alpha=0.7, linestyle="--")
+                    plt.title(f"Channel {ch + 1} - Sample {j + 1} - MSE: {float(loss):.4E}")
+                    plt.legend()
+                    plt.grid(True, alpha=0.3)
+                plt.tight_layout()
+                plt.savefig(f"{save_dir}/reconstruction_sample_{j + 1:03d}.png", dpi=300, bbox_inches="tight")
+                plt.close()
+            except Exception as e:  # same degradation as the reference
+                print(f"Warning: Could not save reconstruction image for sample {j + 1}: {e}")
+    print("")
+    average_loss = loss_total / (j + 1) if j >= 0 else 0
+    print(f"Total {dataset_name} MSE loss: {average_loss:.3e}")
+    if save_images:
+        print(f"Saved {min(10, j + 1) if j >= 0 else 0} reconstruction images to: {save_dir}/")
+    print("--------------------------------")
+    print("")
+    return latent_vectors, hierarchical_latent_vectors, reconstruction_loss, reconstructed, loss_total
+
+
+def evaluate_vae_simple(VAE, dataloader, device, dataset_name="Dataset", eps_fn=None):
+    """utils.py:563-596: sum of per-batch reconstruction MSEs, nothing stored."""
+    loss_total = 0
+    print(f"Evaluating {dataset_name}...")
+    j = -1
+    for j, image in enumerate(dataloader):
+        x = VAE._prep(image) if hasattr(VAE, "_prep") else image.to(device)
+        mu, log_var, xs = VAE.encoder(x)
+        std = torch.exp(0.5 * log_var)
+        z = reparameterize(mu, std, None if eps_fn is None else eps_fn(j, 0, std))
+        gen_x, _ = VAE.decoder(z, xs, mode="fix")
+        loss = _mse(gen_x, x)
+        print(f"Parameter {j + 1} finished - MSE: {float(loss):.4E}")
+        loss_total = loss_total + float(loss)
+    print("")
+    average_loss = loss_total / (j + 1) if j >= 0 else 0
+    print(f"Total {dataset_name} MSE loss: {average_loss:.3e}")
+    print("--------------------------------")
+    print("")
+    return loss_total
+
+
+def export_latents(VAE, x_all, num_filter_enc, latent_dim, latent_dim_end, recon_iter=1, out_dir="model_save",
+                   loss_file="./SimulGen-VAE_L2_loss.txt", save_images=False, eps_fn=None):
+    """The "whole dataset" leg of SimulGen-VAE.py:325-344: batch-1 pass over every sample, then
+    `model_save/latent_vectors.npy`, `model_save/xs.npy` and `SimulGen-VAE_L2_loss.txt` in the reference's formats
+    (what `--lc_only=1` later loads, SimulGen-VAE.py:348-350)."""
+    loader = torch.utils.data.DataLoader(Dataset(x_all, False), batch_size=1, shuffle=False, num_workers=0)
+    lat, hier, rl, _, _ = evaluate_vae_reconstruction(VAE, loader, "cuda", len(x_all), num_filter_enc, latent_dim,
+                                                      latent_dim_end, recon_iter, "Whole Dataset", save_images, eps_fn)
+    os.makedirs(out_dir, exist_ok=True)
+    np.save(os.path.join(out_dir, "latent_vectors"), lat)
+    np.save(os.path.join(out_dir, "xs"), hier)
+    np.savetxt(loss_file, rl, fmt="%e")
+    return lat, hier, rl

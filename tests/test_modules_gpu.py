@@ -76,3 +76,69 @@ def test_train_plumbing_run(tmp_path, monkeypatch):
     np.testing.assert_allclose(mu1, mu2, rtol=1e-4, atol=1e-5)   # split-K heads use float atomics: order varies
     with pytest.raises(ValueError):
         tr.train(2, B, tl, vl, 1e-3, enc, enc[::-1], N, 32, 8, T, 1e6, "MSE", True, True)   # epochs < 4
+
+
+def test_evaluate_vae_reconstruction_matches_oracle(tmp_path, monkeypatch):
+    """evaluate_vae_reconstruction / export_latents against the CPU oracle (eval-mode encoder ->
+    z = mu (+ injected eps) -> mode='fix' decoder -> per-batch MSE), including the reference's first-sample-of-
+    each-batch bookkeeping and the on-disk formats of model_save/latent_vectors.npy, xs.npy and the L2 loss file."""
+    from modules import utils as U
+    from oracle.vae_oracle import OracleVAE
+    monkeypatch.chdir(tmp_path)
+    g = np.load(os.path.join(GOLD, "g0_small_MSE.npz"))
+    cfg = make_cfg(G0)
+    state = {e.name: g["s3." + e.name] for e in param_spec(cfg)}
+    P = 6
+    x = synthetic_samples(77, range(P), cfg.num_node, cfg.num_time)
+    m = VAE(cfg.latent_dim, cfg.hierarchical_dim, cfg.num_filter_enc, cfg.num_filter_dec, cfg.num_node, cfg.num_time,
+            lossfun="MSE", batch_size=2, small=True, compute_dtype="f32")
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in state.items()})
+    m.eval()
+    rng = np.random.RandomState(3)
+    eps_tab = rng.standard_normal((P, 2, cfg.latent_dim)).astype(np.float32)
+
+    def eps_fn(j, i, like):
+        return torch.from_numpy(np.repeat(eps_tab[j, i][None], like.shape[0], 0)).to(like.device)
+
+    orc = OracleVAE(cfg, state)
+    orc.training = False
+    orc._W, orc._sigma, orc.acts = {}, {}, {}     # eval mode: effective weights are constant, cache them once
+    zero_maps = [np.zeros((1, c, cfg.num_time), np.float32) for c in cfg.num_filter_dec[1:-1]]
+
+    def oracle_row(sample, eps):
+        mu, lv, xs = orc.encoder(sample[None])
+        z = mu + eps[None] * np.clip(np.exp(0.5 * lv), 1e-8, 10.0)
+        xh, _ = orc.decoder(z.astype(np.float32), xs, zero_maps, mode="fix")
+        return z[0], [v[0] for v in xs], xh[0], float(np.mean((xh[0] - sample) ** 2))
+
+    # batch-2 loader, two draws per batch: row j describes the FIRST sample of batch j, best of the two draws
+    loader = torch.utils.data.DataLoader(U.Dataset(x, False), batch_size=2, shuffle=False)
+    lat, hier, rl, rec, tot = U.evaluate_vae_reconstruction(m, loader, "cuda", P, cfg.num_filter_enc, cfg.hierarchical_dim,
+                                                            cfg.latent_dim, recon_iter=2, dataset_name="Unit (test)",
+                                                            save_images=False, eps_fn=eps_fn)
+    assert lat.shape == (P, cfg.latent_dim) and hier.shape == (P, 3, cfg.hierarchical_dim) and rec.shape == (P, cfg.num_node, cfg.num_time)
+    assert np.all(lat[3:] == 0) and np.all(rl[3:] == 0)            # only len(loader) rows are ever written
+    for j in range(3):
+        mu, lv, xs = orc.encoder(x[2 * j:2 * j + 2])
+        best = None
+        for i in range(2):
+            z = (mu + eps_tab[j, i][None] * np.clip(np.exp(0.5 * lv), 1e-8, 10.0)).astype(np.float32)
+            xh, _ = orc.decoder(z, xs, [np.zeros((2, c, cfg.num_time), np.float32) for c in cfg.num_filter_dec[1:-1]], mode="fix")
+            mse = float(np.mean((xh - x[2 * j:2 * j + 2]) ** 2))
+            if best is None or mse < best[0]:
+                best = (mse, z[0], xh[0])
+        assert abs(rl[j] - best[0]) < 2e-4 * best[0]
+        assert relerr(lat[j], best[1]) < 3e-4 and relerr(rec[j], best[2]) < 3e-4
+        for k in range(3):
+            assert relerr(hier[j, k], xs[k][0]) < 3e-4
+    # whole-dataset export (batch 1): files in the reference's formats
+    lat1, hier1, rl1 = U.export_latents(m, x, cfg.num_filter_enc, cfg.hierarchical_dim, cfg.latent_dim, recon_iter=1,
+                                        eps_fn=lambda j, i, like: torch.zeros_like(like))
+    z0, xs0, xh0, mse0 = oracle_row(x[4], np.zeros(cfg.latent_dim, np.float32))
+    assert relerr(lat1[4], z0) < 3e-4 and abs(rl1[4] - mse0) < 2e-4 * mse0
+    a = np.load("model_save/latent_vectors.npy")
+    b = np.load("model_save/xs.npy")
+    c = np.loadtxt("SimulGen-VAE_L2_loss.txt")
+    assert a.dtype == np.float64 and a.shape == (P, cfg.latent_dim) and b.shape == (P, 3, cfg.hierarchical_dim)
+    np.testing.assert_allclose(c, rl1, rtol=1e-6)
+    assert abs(U.evaluate_vae_simple(m, loader, "cuda", "Unit", eps_fn=eps_fn) - tot) < 1e-6 + 0.5 * tot   # same loop, last draw vs best
