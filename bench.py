@@ -48,13 +48,6 @@ def gemm_flops(cfg, batch):
     return fwd, dx, dw
 
 
-class DevArray:
-    """__cuda_array_interface__ view of the engine's gradient arena for torch.distributed."""
-
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
-
-
 def load_traffic():
     """HBM bytes per kernel from the newest committed PMC summary (profiles/rNN_traffic.json, written by
     tools/summarize_profile.py traffic from separate FETCH_SIZE / WRITE_SIZE rocprofv3 passes of this bench)."""
@@ -125,6 +118,7 @@ def main():
     from simulgen_vae_amd import engine as E
     from simulgen_vae_amd.init import init_state
     from simulgen_vae_amd.spec import VAEConfig
+    from simulgen_vae_amd.modules.train import GradAllReduce
 
     cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", args.size == "small")
     B = args.batch
@@ -149,14 +143,9 @@ def main():
         print(f"[bench] init {time.time() - t_init:.1f}s, dataset {P} samples resident "
               f"({data.numel() / 1e9:.1f} GB), dtype {args.dtype}", file=sys.stderr)
 
-    gptr, gcount = eng.grad_buffer()
     ddp = world > 1 or (os.environ.get("SGV_FORCE_DDP") == "1" and dist.is_initialized())   # forced: plumbing test at N=1
-    gflat = torch.as_tensor(DevArray(gptr, gcount), device="cuda") if ddp else None
-    pending = []
-    if ddp:
-        def on_bucket(b, off, cnt):
-            pending.append(dist.all_reduce(gflat[off:off + cnt], op=dist.ReduceOp.AVG, async_op=True))
-        eng.set_bucket_callback(on_bucket)
+    # bucketed mean all-reduce over RCCL, overlapped with backward and with AdamW (modules/train.py GradAllReduce)
+    allreduce = GradAllReduce(eng) if ddp else None
 
     rng = random.Random(99 + rank)
     nprng = np.random.RandomState(5 + rank)
@@ -182,10 +171,9 @@ def main():
         eng.forward(train=True, sync=False)
         eng.backward(ALPHA, epochs_beta)
         if ddp:
-            for w in pending:
-                w.wait()
-            pending.clear()
-        eng.adamw_step(LR)
+            allreduce.step(eng, LR)
+        else:
+            eng.adamw_step(LR)
 
     for i in range(args.warmup):
         one_step(i)

@@ -127,8 +127,9 @@ int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t coun
 int sgv_backward(sgv_engine* e, float alpha, float beta);
 /* Callback invoked from inside sgv_backward (host side, after the kernels producing a gradient
  * bucket have been enqueued) so the caller can overlap its all-reduce of
- * [sgv_grad_buffer + offset, +count) with the rest of backward.  Buckets arrive in
- * reverse-autograd order. */
+ * [sgv_grad_buffer + offset, +count) with the rest of backward.  Weight buckets arrive in
+ * reverse-autograd order; the small last-numbered bucket (biases, GroupNorm affine, <G,W> scalars) is released
+ * just before the first encoder layer's weight bucket, which is always the final callback. */
 typedef void (*sgv_bucket_cb)(void* user, int bucket, size_t offset_elems, size_t count_elems);
 int sgv_set_bucket_callback(sgv_engine* e, sgv_bucket_cb cb, void* user);
 /* The flat fp32 gradient arena (device) of all parameters that receive gradients; what the
@@ -142,6 +143,16 @@ int sgv_grad_norm(sgv_engine* e, double* out);
  * eps 1e-8, weight_decay 0.01; skips parameters without gradient.  Also refreshes the
  * compute-dtype weight copies. */
 int sgv_adamw_step(sgv_engine* e, float lr);
+/* The same step restricted to the parameters whose gradients live in buckets [bucket_lo, bucket_hi) (bucket
+ * numbering of sgv_set_bucket_callback; the last bucket holds biases, GroupNorm affine and the spectral-norm
+ * <G,W> scalars, which every conv weight's update needs).  Lets a data-parallel caller update the layers whose
+ * all-reduce has finished while the last, largest bucket is still in flight.  first=1 on the first call of an
+ * optimisation step, last=1 on the final one; every bucket must be covered exactly once per step. */
+int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last);
+int sgv_bucket_count(const sgv_engine* e);
+/* Gradient 2-norm accumulated by the AdamW pass(es) of the current step (same value sgv_grad_norm computes in a
+ * separate pass).  [sync] */
+int sgv_last_grad_norm(sgv_engine* e, double* out);
 
 /* AugmentedDataset.__getitem__ x batch + default collate (augmentation.py:43-124) on a dataset
  * resident in HBM in the engine's internal layout: builds the input batch directly.

@@ -123,6 +123,7 @@ struct sgv_engine {
     WorkItem *items_sn_unf = nullptr, *items_adam_flat = nullptr, *items_adam_2d = nullptr;
     int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0, n_items_copy = 0, n_items_wct = 0;
     int n_items_sn_unf = 0, n_items_adam_flat = 0, n_items_adam_2d = 0;
+    std::vector<int> flat_off, tile_off;             // AdamW work items are sorted by gradient bucket: [bucket] -> first item
     // graph
     std::vector<Block> encA, encR, decU, decD, decP1, decP2, decX, decQ1, decQ2;
     Block decS, recon;
@@ -575,6 +576,12 @@ static int upload_tables(sgv_engine* e) {
     e->sn_host.resize(L);
     size_t to_f = 0, to_u = e->n_sn_tmp_fused, to_s = e->sn_tmp_s_off;
     std::vector<WorkItem> i_sn, i_sn_unf, i_dot, i_adam, i_adam_flat, i_adam_2d, i_copy, i_wct;
+    const int nbk = (int)e->buckets.size();
+    std::vector<std::vector<WorkItem>> flat_b(nbk), tile_b(nbk);
+    auto bucket_of = [&](size_t goff) {
+        for (int b = 0; b < nbk; ++b) if (goff >= e->buckets[b].first && goff < e->buckets[b].first + e->buckets[b].second) return b;
+        return nbk - 1;
+    };
     for (int i = 0; i < L; ++i) {
         Layer& l = e->layers[i];
         SNDesc d;
@@ -604,10 +611,11 @@ static int upload_tables(sgv_engine* e) {
         const int id = (int)e->adam_host.size();
         e->adam_host.push_back(a);
         const long nch = (n + OPT_CHUNK - 1) / OPT_CHUNK;
-        for (long c = 0; c < nch; ++c) { i_adam.push_back({id, (int)c}); if (!tiled) i_adam_flat.push_back({id, (int)c}); }
+        const int bk = bucket_of(g);
+        for (long c = 0; c < nch; ++c) { i_adam.push_back({id, (int)c}); if (!tiled) flat_b[bk].push_back({id, (int)c}); }
         if (tiled) {
             const int rt6 = (rows + 63) / 64, ct6 = (cols + 63) / 64;
-            for (int c = 0; c < taps * rt6 * ct6; ++c) i_adam_2d.push_back({id, c});
+            for (int c = 0; c < taps * rt6 * ct6; ++c) tile_b[bk].push_back({id, c});
         }
         return id;
     };
@@ -639,6 +647,12 @@ static int upload_tables(sgv_engine* e) {
         if (!g.has_grad) continue;
         add_adam(g.gamma, g.ggamma, g.C, -1, 1, g.C, 1, nullptr, nullptr);
         add_adam(g.beta, g.gbeta, g.C, -1, 1, g.C, 1, nullptr, nullptr);
+    }
+    e->flat_off.assign(nbk + 1, 0); e->tile_off.assign(nbk + 1, 0);
+    for (int b = 0; b < nbk; ++b) {
+        i_adam_flat.insert(i_adam_flat.end(), flat_b[b].begin(), flat_b[b].end());
+        i_adam_2d.insert(i_adam_2d.end(), tile_b[b].begin(), tile_b[b].end());
+        e->flat_off[b + 1] = (int)i_adam_flat.size(); e->tile_off[b + 1] = (int)i_adam_2d.size();
     }
     auto up = [&](const void* src, size_t bytes, void** dst) -> int {
         if (bytes == 0) { *dst = nullptr; return 0; }
@@ -809,7 +823,10 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
 }
 
 // dOut: gradient wrt the block output; dIn (nullable): gradient wrt the block input (overwritten).
-static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dOut, const Tensor* dIn, int B) {
+// before_first_dw (optional) runs after the last dY of the block exists, right before the weight-gradient GEMM of
+// the block's first conv (sgv_backward uses it to release the small-gradient bucket early).
+static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dOut, const Tensor* dIn, int B,
+                     const std::function<void()>* before_first_dw = nullptr) {
     const long M = (long)B * e->T;
     Tensor dA = dOut;
     float sc = b.residual ? 0.1f : 1.0f;
@@ -845,6 +862,7 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
             dY = dA;
         }
         sc = 1.0f;
+        if (s == 0 && before_first_dw) (*before_first_dw)();
         CHK(conv_bwd_dw(e, L, dY, x_conv, M));
         const bool need = (s > 0) || (dIn != nullptr);
         if (need) {
@@ -1379,7 +1397,9 @@ int sgv_backward(sgv_engine* e, float alpha, float beta) {
     const long M = (long)B * e->T;
     const float coefB = beta / (float)B;
     int bucket = 0;
-    auto fire = [&]() { if (e->cb && bucket < (int)e->buckets.size()) e->cb(e->cb_user, bucket, e->buckets[bucket].first, e->buckets[bucket].second); ++bucket; };
+    auto fire_at = [&](int b) { if (e->cb && b >= 0 && b < (int)e->buckets.size()) e->cb(e->cb_user, b, e->buckets[b].first, e->buckets[b].second); };
+    auto fire = [&]() { fire_at(bucket); ++bucket; };
+    const int small_bucket = (int)e->buckets.size() - 1;
     // zero the small-gradient zone (biases / GroupNorm affine use atomics) and the backward group sums
     HIPCHK(hipMemsetAsync(e->grads + e->n_grads_w, 0, (e->n_grads - e->n_grads_w) * 4, e->stream));
     {
@@ -1452,14 +1472,21 @@ int sgv_backward(sgv_engine* e, float alpha, float beta) {
                                e->grads + xl.gw, e->grads + xl.gb, B, xl.cin, xl.cout, e->stream);
         }
         CHK(block_bwd(e, e->encR[i], e->encA[i].st.back().a, e->d_h[i], &e->enc_a_dummy[i], B));
-        if (i == 0) fire();   // everything but the first-layer weight gradient is now enqueued
         const Tensor x_prev = i == 0 ? e->x_in : e->enc_h[i - 1];
-        CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], i > 0 ? &e->d_h[i - 1] : nullptr, B));
+        if (i == 0) {
+            fire();   // everything but the first block's weight gradients is now enqueued
+            // <G,W_eff> of the (small) Linear layers from their weights; conv layers accumulated theirs in the dY kernels
+            if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
+            // the small zone (biases, GroupNorm affine, <G,W_eff> scalars) is complete once the first conv's dY exists:
+            // release it BEFORE the first-layer weight-gradient GEMM so that its all-reduce (and, with it, the AdamW
+            // of every other layer) does not queue behind the 390 MB first-layer bucket
+            const std::function<void()> early = [&]() { fire_at(small_bucket); };
+            CHK(block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early));
+        } else {
+            CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], &e->d_h[i - 1], B));
+        }
     }
-    // <G,W_eff> of the (small) Linear layers from their weights; conv layers accumulated theirs above
-    if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
-    fire();
-    fire();   // small zone (biases, GroupNorm affine, <G,W_eff> scalars)
+    fire();   // first encoder block's weights
     return SGV_OK;
 }
 
@@ -1474,22 +1501,45 @@ int sgv_grad_norm(sgv_engine* e, double* out) {
     return SGV_OK;
 }
 
-int sgv_adamw_step(sgv_engine* e, float lr) {
+int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
-    e->step += 1;
+    const int nbk = (int)e->buckets.size();
+    if (bucket_lo < 0 || bucket_hi > nbk || bucket_lo > bucket_hi) return fail(SGV_ERR_ARG, "bucket range [%d,%d) outside [0,%d)", bucket_lo, bucket_hi, nbk);
     const double b1 = 0.9, b2 = 0.999;
+    if (first) {
+        e->step += 1;
+        HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
+        if (e->n_sn_tmp_fused) HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp_fused * 4, e->stream));
+        e->copies_fresh = false;
+        e->wtu_fresh = false;
+    }
+    if (e->step < 1) return fail(SGV_ERR_STATE, "sgv_adamw_step_range: the first call of a step must pass first=1");
     const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
     const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
-    HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
     // biases, GroupNorm affine and the Linear heads: flat pass.  Conv weights: tiled pass that also writes both
     // compute copies and W_new^T u for the next forward's power iteration.
-    if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat, e->n_items_adam_flat, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+    const int f0 = e->flat_off[bucket_lo], f1 = e->flat_off[bucket_hi], t0 = e->tile_off[bucket_lo], t1 = e->tile_off[bucket_hi];
+    if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    if (e->n_sn_tmp_fused) HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp_fused * 4, e->stream));
-    if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d, e->n_items_adam_2d, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+    if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    e->copies_fresh = true;
-    e->wtu_fresh = true;
+    if (last) {
+        e->copies_fresh = true;
+        e->wtu_fresh = true;
+    }
+    return SGV_OK;
+}
+int sgv_adamw_step(sgv_engine* e, float lr) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    return sgv_adamw_step_range(e, lr, 0, (int)e->buckets.size(), 1, 1);
+}
+int sgv_bucket_count(const sgv_engine* e) { return e ? (int)e->buckets.size() : 0; }
+int sgv_last_grad_norm(sgv_engine* e, double* out) {
+    if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
+    double h = 0.0;
+    HIPCHK(hipMemcpyAsync(&h, e->scal + 15, 8, hipMemcpyDeviceToHost, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *out = sqrt(h);
     return SGV_OK;
 }
 

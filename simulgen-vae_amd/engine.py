@@ -27,6 +27,7 @@ ABI_SYMBOLS = [
     "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
+    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_last_grad_norm",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
 ]
 
@@ -82,6 +83,9 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_scale_grads.argtypes = [vp, f32]
     lib.sgv_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
     lib.sgv_adamw_step.argtypes = [vp, f32]
+    lib.sgv_adamw_step_range.argtypes = [vp, f32, i32, i32, i32, i32]
+    lib.sgv_bucket_count.argtypes = [vp]
+    lib.sgv_last_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
     lib.sgv_augment_collate.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     lib.sgv_dataset_convert.argtypes = [vp, vp, vp, i32]
     lib.sgv_dataset_sample_bytes.argtypes = [vp]
@@ -262,6 +266,18 @@ class Engine:
 
     def adamw_step(self, lr: float):
         _check(self.lib, self.lib.sgv_adamw_step(self.h, float(lr)), "sgv_adamw_step")
+
+    def adamw_step_range(self, lr: float, bucket_lo: int, bucket_hi: int, first: bool, last: bool):
+        _check(self.lib, self.lib.sgv_adamw_step_range(self.h, float(lr), int(bucket_lo), int(bucket_hi), int(first), int(last)),
+               "sgv_adamw_step_range")
+
+    def bucket_count(self) -> int:
+        return int(self.lib.sgv_bucket_count(self.h))
+
+    def last_grad_norm(self) -> float:
+        d = C.c_double()
+        _check(self.lib, self.lib.sgv_last_grad_norm(self.h, C.byref(d)), "sgv_last_grad_norm")
+        return d.value
 
     def grad_buffer(self):
         """(device pointer, element count) of the flat fp32 gradient arena."""

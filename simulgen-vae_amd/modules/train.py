@@ -60,20 +60,45 @@ class _DevArray:
 
 
 class GradAllReduce:
-    """Bucketed, overlapped mean all-reduce of the engine's flat gradient arena over RCCL."""
+    """Bucketed mean all-reduce of the engine's flat gradient arena over RCCL, overlapped with backward (the
+    engine calls `_on_bucket` as soon as the kernels producing a bucket are enqueued) and with AdamW (`step`
+    updates every layer whose bucket has arrived while the last, first-encoder-layer bucket is still in flight)."""
 
-    def __init__(self, engine):
+    def __init__(self, engine, group=None):
         ptr, n = engine.grad_buffer()
         self.flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
-        self.pending = []
+        self.group = group
+        self.pending = []          # (bucket, work) in issue order == completion order on the RCCL stream
+        self.nb = engine.bucket_count()
         engine.set_bucket_callback(self._on_bucket)
 
     def _on_bucket(self, b, off, cnt):
-        self.pending.append(dist.all_reduce(self.flat[off:off + cnt], op=dist.ReduceOp.AVG, async_op=True))
+        w = dist.all_reduce(self.flat[off:off + cnt], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        self.pending.append((b, w))
 
     def __call__(self, engine):
-        for w in self.pending:
+        """Wait for every bucket (use when something needs all gradients before the optimiser, e.g. sgv_grad_norm)."""
+        for _, w in self.pending:
             w.wait()
+        self.pending.clear()
+
+    def step(self, engine, lr):
+        """wait(all but the final bucket) -> AdamW on those -> wait(final) -> AdamW on it.  The waits are
+        stream-side (no host block), so the first AdamW call runs under the final bucket's all-reduce."""
+        if not self.pending:
+            engine.adamw_step(lr)
+            return
+        last_b, last_w = self.pending[-1]
+        if len(self.pending) != self.nb or last_b != self.nb - 2:
+            self(engine)                      # unexpected callback pattern: plain path
+            engine.adamw_step(lr)
+            return
+        for _, w in self.pending[:-1]:
+            w.wait()
+        engine.adamw_step_range(lr, 0, last_b, True, False)
+        engine.adamw_step_range(lr, last_b + 1, self.nb, False, False)
+        last_w.wait()
+        engine.adamw_step_range(lr, last_b, last_b + 1, False, True)
         self.pending.clear()
 
 
@@ -125,9 +150,10 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
             sc = eng.forward(train=True)
             eng.backward(alpha, beta)
             if allreduce is not None:
-                allreduce(eng)
-            grad_sum += eng.grad_norm()
-            eng.adamw_step(lr)
+                allreduce.step(eng, lr)
+            else:
+                eng.adamw_step(lr)
+            grad_sum += eng.last_grad_norm()     # accumulated inside the AdamW pass (train.py:156-161 value)
             l, r, k = run_forward_losses(sc, beta)
             loss_save += l
             recon_save += r

@@ -142,3 +142,63 @@ def test_evaluate_vae_reconstruction_matches_oracle(tmp_path, monkeypatch):
     assert a.dtype == np.float64 and a.shape == (P, cfg.latent_dim) and b.shape == (P, 3, cfg.hierarchical_dim)
     np.testing.assert_allclose(c, rl1, rtol=1e-6)
     assert abs(U.evaluate_vae_simple(m, loader, "cuda", "Unit", eps_fn=eps_fn) - tot) < 1e-6 + 0.5 * tot   # same loop, last draw vs best
+
+
+def test_overlapped_allreduce_step_equals_plain_step():
+    """the data-parallel step (bucket callbacks -> RCCL mean all-reduce -> bucket-ranged AdamW with the
+    first-encoder-layer bucket updated last) must leave exactly the state of the plain single-GPU step.  One-rank
+    RCCL group: AVG over one rank is the identity, so every parameter, u/v vector and Adam moment has to match
+    (up to float-atomic ordering); the bucket order contract (small bucket released before the last weight bucket) is checked too."""
+    import torch.distributed as dist
+    from modules.train import GradAllReduce
+    from simulgen_vae_amd.engine import Engine
+    from simulgen_vae_amd.init import init_state
+    from tests.gpu_common import G1
+    cfg = make_cfg(G1)
+    B = 4
+    x = torch.from_numpy(synthetic_samples(5, range(B), cfg.num_node, cfg.num_time)).cuda()
+    state = init_state(cfg, 11, reference_init=True)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        outs = []
+        for mode in ("plain", "ddp"):
+            eng = Engine(cfg, max_batch=B, compute_dtype="f32")
+            eng.load_state(state)
+            eng.seed(99)
+            ar = GradAllReduce(eng) if mode == "ddp" else None
+            order = []
+            if ar is not None:
+                inner = ar._on_bucket
+                ar._on_bucket = lambda b, off, cnt: (order.append(b), inner(b, off, cnt))
+                eng.set_bucket_callback(ar._on_bucket)
+            norms = []
+            for step in range(3):
+                eng.set_input(x)
+                eng.forward(train=True)
+                eng.backward(1e6, 1e-4)
+                if ar is not None:
+                    ar.step(eng, 1e-3)
+                else:
+                    eng.adamw_step(1e-3)
+                norms.append(eng.last_grad_norm())
+            torch.cuda.synchronize()
+            if ar is not None:
+                nb = eng.bucket_count()
+                assert order[-nb:] == list(range(nb - 2)) + [nb - 1, nb - 2]
+            outs.append((eng.state_dict(), norms))
+            eng.close()
+        (sa, na), (sb, nb_) = outs
+        # float atomics (bias / <G,W> / power-iteration accumulation) make two runs of the SAME path differ in the
+        # last bits, and Adam's first steps turn a sign flip of a near-zero gradient into a 2*lr difference on that
+        # element: compare in the mean, not element by element
+        np.testing.assert_allclose(na, nb_, rtol=1e-4)
+        for k in sa:
+            a, b = sa[k].astype(np.float64), sb[k].astype(np.float64)
+            assert np.mean(np.abs(a - b)) <= 1e-4 * np.mean(np.abs(a)) + 1e-9, k
+    finally:
+        if created:
+            dist.destroy_process_group()
