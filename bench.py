@@ -61,7 +61,7 @@ def load_traffic():
     return t
 
 
-def cpu_baseline(sample_batch, cores):
+def cpu_baseline(sample_batch, cores, small=True):
     """oracle/torch_port.py (PyTorch-CPU restatement of the reference step: same ATen conv/GroupNorm
     kernels the reference's CPU path runs) timed on this box's host cores on a bounded sample: full
     node/time/filter sizes, reduced batch; 1 untimed step (lazy optimizer state), then 1 timed full
@@ -71,7 +71,7 @@ def cpu_baseline(sample_batch, cores):
     from simulgen_vae_amd.spec import VAEConfig
     from oracle.torch_port import TorchPortVAE
     torch.set_num_threads(cores)
-    cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", args.size == "small")
+    cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", small)
     m = TorchPortVAE(cfg, init_state(cfg, 7, reference_init=True))
     x = synthetic_samples(20251003, range(sample_batch), N_NODE, N_TIME)
     eps = synthetic_eps(1234, 0, cfg, sample_batch)
@@ -281,7 +281,7 @@ def main():
             except Exception:
                 pass
             cores = min(cores, args.cpu_threads)   # a 1-GPU box's CPU share is 16 cores; 256 torch threads thrash
-            v, dt, r = cpu_baseline(args.cpu_sample_batch, cores)
+            v, dt, r = cpu_baseline(args.cpu_sample_batch, cores, args.size == "small")
             result["cpu_baseline"] = {"value": round(v, 4), "unit": "samples/s", "cores": cores, "kind": "port",
                                       "sample": f"oracle/torch_port.py (PyTorch-CPU fp32 port of the reference step), 1 timed "
                                                 f"full training step (fwd+bwd+grad-norm+AdamW) at full N=95008/T=200/filters "
