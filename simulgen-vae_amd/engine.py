@@ -160,8 +160,12 @@ class Engine:
             out.append((name.value.decode(), tuple(shape[j] for j in range(nd.value)), kind.value, bool(hg.value)))
         return out
 
-    def load_state(self, state: Dict[str, np.ndarray]):
+    def load_state(self, state: Dict[str, np.ndarray], partial: bool = False):
+        """nn.Module.load_state_dict: every key of the reference state_dict (partial=True: only the keys given,
+        e.g. to restore the spectral-norm u/v vectors)."""
         for e in self.spec:
+            if partial and e.name not in state:
+                continue
             a = np.ascontiguousarray(state[e.name], dtype=np.float32)
             if a.shape != tuple(e.shape):
                 raise SgvError(f"shape mismatch for {e.name}: {a.shape} vs {e.shape}")

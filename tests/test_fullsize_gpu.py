@@ -1,0 +1,112 @@
+"""BASELINE.json configs[1] at full size (95 008 nodes x 200 steps, filters 1024-512-256-128, bf16) on the GPU.
+The CPU oracle cannot run here, so parity is carried by size-independent properties of the path (task statement
+section 3): determinism, loss identities, linearity of backward in (alpha, beta), the data-parallel identity
+"mean of the shard gradients == gradient of the concatenated batch" (SURVEY 8(e)), agreement of the two grad-norm
+code paths, and the encoder -> mode='fix' decoder round trip against the eval forward."""
+import numpy as np
+import pytest
+import torch
+
+import simulgen_vae_amd  # noqa: F401
+from simulgen_vae_amd import engine as E
+from simulgen_vae_amd.init import init_state
+from simulgen_vae_amd.spec import VAEConfig
+from tests.gpu_common import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+ENC = [1024, 512, 256, 128]
+N, T, B = 95008, 200, 8
+ALPHA, BETA = 1e6, 1e-4
+BIG = ["encoder.encoder_blocks.0.module_list.0._seq.0.weight_orig", "decoder.recon.0.weight_orig",
+       "decoder.decoder_residual_blocks.2.seq.3.weight_orig", "decoder.decoder_residual_blocks.1.seq.0.weight_orig",
+       "decoder.condition_xz.1.2.weight_orig", "encoder.last_x_linear.weight_orig", "decoder.recon.1.weight",
+       "decoder.recon.0.bias"]
+
+
+# Stated tolerances (rel-L2 on whole gradient tensors).  fp32 compute: run-to-run differences come only from float
+# atomic ordering (~1e-6).  bf16 compute (the bench dtype): a 1e-7 perturbation of a spectral norm flips bf16
+# roundings of stored maps and decorrelates two runs at the bf16 noise floor of this 40-layer net (measured 1.1e-2
+# on the first-layer gradient for two IDENTICAL runs), so bf16 can only be held to 3e-2.
+TOL = {"f32": 1e-3, "bf16": 3e-2}
+
+
+@pytest.fixture(scope="module", params=["f32", "bf16"])
+def full(request):
+    cfg = VAEConfig(32, 8, ENC, ENC[::-1], N, T, "MSE", True)
+    state = init_state(cfg, 7, reference_init=True)
+    eng = E.Engine(cfg, max_batch=B, compute_dtype=request.param)
+    eng.tol = TOL[request.param]
+    eng.load_state(state)
+    uv = {k: v for k, v in state.items() if k.endswith("weight_u") or k.endswith("weight_v")}
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand((B, N, T), generator=g, device="cuda") * 1.4 - 0.7
+    dec = cfg.num_filter_dec
+    eps = [torch.randn((B, cfg.latent_dim), generator=g, device="cuda")] + \
+          [torch.randn((B, dec[i + 1], T), generator=g, device="cuda") for i in range(len(dec) - 2)]
+    yield cfg, eng, uv, x, eps
+    eng.close()
+
+
+def _grads(eng, uv, x, eps, alpha, beta, names):
+    eng.load_state(uv, partial=True)            # every train forward advances the power iteration: restart it
+    eng.set_input(x.contiguous())
+    eng.set_eps([e.contiguous() for e in eps])
+    sc = eng.forward(train=True)
+    eng.backward(alpha, beta)
+    return sc, {k: eng.grad(k) for k in names}, eng.grad_norm()
+
+
+def test_fullsize_step_properties(full):
+    cfg, eng, uv, x, eps = full
+    sc1, g1, n1 = _grads(eng, uv, x, eps, ALPHA, BETA, BIG)
+    assert np.isfinite(sc1["recon"]) and all(np.isfinite(k) for k in sc1["kls"]) and np.isfinite(n1) and n1 > 0
+    assert sc1["recon"] == sc1["mse"]                       # lossfun == MSE: both reductions are the same number
+    # same inputs, same eps, same u/v -> same scalars (reductions use fp64 atomics: order-insensitive to ~1e-12)
+    sc1b, g1b, n1b = _grads(eng, uv, x, eps, ALPHA, BETA, BIG[:2])
+    assert abs(sc1b["recon"] - sc1["recon"]) <= eng.tol * 1e-2 * abs(sc1["recon"])
+    for k in BIG[:2]:
+        assert rel_l2(g1b[k], g1[k]) < eng.tol, k
+    # backward is linear in (alpha, beta); a factor 2 is exact in floating point up to atomic ordering
+    _, g2, n2 = _grads(eng, uv, x, eps, 2 * ALPHA, 2 * BETA, BIG)
+    assert abs(n2 - 2 * n1) <= eng.tol * n2
+    for k in BIG:
+        assert rel_l2(g2[k], 2.0 * g1[k]) < eng.tol, k
+    # the fused grad-norm of the AdamW pass == the stand-alone pass (train.py:156-161)
+    eng.adamw_step(1e-3)
+    assert abs(eng.last_grad_norm() - n2) <= 1e-4 * n2
+    sc3 = eng.forward(train=False)
+    assert np.isfinite(sc3["recon"])
+
+
+def test_fullsize_shard_mean_gradient_equals_full_batch(full):
+    """Data-parallel identity at full size: gradients of the batch-8 step == mean of the gradients of its two
+    batch-4 shards (every loss term is a batch mean, GroupNorm is per sample).  Tolerances: TOL above."""
+    cfg, eng, uv, x, eps = full
+    names = BIG
+    _, gf, nf = _grads(eng, uv, x, eps, ALPHA, BETA, names)
+    h = B // 2
+    _, ga, _ = _grads(eng, uv, x[:h], [e[:h] for e in eps], ALPHA, BETA, names)
+    _, gb, _ = _grads(eng, uv, x[h:], [e[h:] for e in eps], ALPHA, BETA, names)
+    for k in names:
+        assert rel_l2(0.5 * (ga[k] + gb[k]), gf[k]) < eng.tol, (k, rel_l2(0.5 * (ga[k] + gb[k]), gf[k]))
+
+
+def test_fullsize_fix_roundtrip_matches_eval_forward(full):
+    """encoder -> decoder(z = mu, xs, mode='fix') reproduces the eval forward run with eps = 0."""
+    cfg, eng, uv, x, eps = full
+    xb = x[:4].contiguous()
+    eng.set_input(xb)
+    eng.set_eps([torch.zeros_like(e[:4]).contiguous() for e in eps])
+    eng.set_option("write_xhat", 1)
+    sc = eng.forward(train=False, fix=True)
+    xh_fwd = eng.xhat().clone()
+    mu, lv, xs = eng.encode()
+    eng.set_eps([torch.zeros_like(e[:4]).contiguous() for e in eps])
+    eng.decode(torch.from_numpy(mu).cuda(), [torch.from_numpy(v).cuda() for v in xs], fix=True)
+    xh_dec = eng.xhat()
+    err = float((xh_dec - xh_fwd).abs().max())
+    assert err < 2e-2, err                                   # bf16 maps; identical code path -> typically 0
+    mse = float(torch.mean((xh_dec - xb) ** 2))
+    assert abs(mse - sc["mse"]) <= 2e-3 * abs(sc["mse"])
+    assert float(xh_dec.abs().max()) <= 1.0                  # tanh head
