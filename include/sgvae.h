@@ -167,6 +167,20 @@ int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const
 int sgv_dataset_convert(sgv_engine* e, const float* src_dev, void* dst_dev, int count);
 size_t sgv_dataset_sample_bytes(const sgv_engine* e);
 
+/* Input pipeline, stateless.  data_preprocess.data_scaler (data_preprocess.py:65-165) fits
+ * sklearn.preprocessing.MinMaxScaler(feature_range=(-0.7, 0.7)) per node on a sample of [num_time x num_param]
+ * rows and transforms the whole [P][T][N] array; SimulGen-VAE.py:282 then transposes it for Conv1d.
+ * sgv_minmax_fit: per-node min / max (NaNs ignored) over n_rows device rows of n_node floats (accumulate=1 merges
+ * into existing values, for chunked feeding) [sync]; sgv_minmax_coeffs: MinMaxScaler's scale_ / min_ (zero ranges
+ * handled as sklearn does); sgv_scale_convert: x*scale_+min_ of raw rows written in the engine's resident
+ * dataset layout [P][T][N] and compute dtype (raw [P][T][N] rows are already in that order). */
+int sgv_minmax_fit(const float* rows_dev, long n_rows, int n_node, float* min_dev, float* max_dev, int accumulate,
+                   void* stream);
+int sgv_minmax_coeffs(const float* min_dev, const float* max_dev, int n_node, float lo, float hi, float* scale_dev,
+                      float* offset_dev, void* stream);
+int sgv_scale_convert(int dst_dtype, const float* src_dev, const float* scale_dev, const float* offset_dev,
+                      void* dst_dev, long n_rows, int n_node, void* stream);
+
 /* Profiling aid for bench.py: hipEvent-timed duration (total ms and number of launches since the
  * last reset) of a kernel class ("gemm_nt", "gemm_tn"), measured on the engine's own stream. [sync] */
 int sgv_kernel_time(sgv_engine* e, const char* which, float* total_ms, int* calls);

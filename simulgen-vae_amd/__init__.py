@@ -17,6 +17,6 @@ def install_reference_api():
     import sys
     pkg = importlib.import_module(__name__ + ".modules")
     sys.modules["modules"] = pkg
-    for sub in ("VAE_network", "train", "utils", "augmentation", "losses"):
+    for sub in ("VAE_network", "train", "utils", "augmentation", "losses", "data_preprocess"):
         sys.modules["modules." + sub] = importlib.import_module(__name__ + ".modules." + sub)
     return pkg

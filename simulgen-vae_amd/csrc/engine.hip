@@ -1596,6 +1596,33 @@ int sgv_last_grad_norm(sgv_engine* e, double* out) {
     return SGV_OK;
 }
 
+// ---- input pipeline (stateless: no engine needed) ----------------------------------------------------
+int sgv_minmax_fit(const float* rows_dev, long n_rows, int n_node, float* min_dev, float* max_dev, int accumulate, void* stream) {
+    if (!rows_dev || !min_dev || !max_dev) return fail(SGV_ERR_ARG, "null argument");
+    if (n_rows <= 0 || n_node <= 0 || n_node % 4) return fail(SGV_ERR_ARG, "sgv_minmax_fit: n_rows > 0 and n_node %% 4 == 0 required");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return fail(SGV_ERR_NOGPU, "no HIP device visible: libsgvae has no CPU fallback");
+    float* partial = nullptr;
+    HIPCHK(hipMalloc((void**)&partial, sizeof(float) * 2 * (size_t)n_node * SGV_MINMAX_ROWSPLIT));
+    int r = ew_minmax_fit(rows_dev, n_rows, n_node, min_dev, max_dev, partial, SGV_MINMAX_ROWSPLIT, accumulate, (hipStream_t)stream);
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(partial);
+    if (r || se != hipSuccess) return fail(SGV_ERR_HIP, "minmax_fit failed");
+    return SGV_OK;
+}
+int sgv_minmax_coeffs(const float* min_dev, const float* max_dev, int n_node, float lo, float hi, float* scale_dev, float* offset_dev, void* stream) {
+    if (!min_dev || !max_dev || !scale_dev || !offset_dev || n_node <= 0) return fail(SGV_ERR_ARG, "bad argument");
+    if (ew_minmax_coeffs(min_dev, max_dev, n_node, lo, hi, scale_dev, offset_dev, (hipStream_t)stream)) return fail(SGV_ERR_HIP, "minmax_coeffs launch failed");
+    return SGV_OK;
+}
+int sgv_scale_convert(int dst_dtype, const float* src_dev, const float* scale_dev, const float* offset_dev, void* dst_dev, long n_rows, int n_node, void* stream) {
+    if (!src_dev || !scale_dev || !offset_dev || !dst_dev) return fail(SGV_ERR_ARG, "null argument");
+    if (n_node <= 0 || n_node % 8) return fail(SGV_ERR_ARG, "sgv_scale_convert: n_node %% 8 == 0 required");
+    if (dst_dtype != SGV_DTYPE_F32 && dst_dtype != SGV_DTYPE_BF16) return fail(SGV_ERR_ARG, "bad dtype");
+    if (ew_scale_convert(dst_dtype, src_dev, scale_dev, offset_dev, dst_dev, n_rows, n_node, (hipStream_t)stream)) return fail(SGV_ERR_HIP, "scale_convert launch failed");
+    return SGV_OK;
+}
+
 size_t sgv_dataset_sample_bytes(const sgv_engine* e) { return e ? (size_t)e->N * e->T * e->esz : 0; }
 
 int sgv_dataset_convert(sgv_engine* e, const float* src_dev, void* dst_dev, int count) {

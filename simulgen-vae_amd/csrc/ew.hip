@@ -1072,3 +1072,77 @@ int ew_cast_rows(int dtype, const float* src, long lds_, void* dst, long ldd, in
     else hipLaunchKernelGGL((cast_rows_kernel<float>), dim3(blocks), dim3(256), 0, s, src, lds_, (float*)dst, ldd, rows, C);
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------
+// Input pipeline: per-node MinMaxScaler(-0.7, 0.7) as the reference fits it on a row sample
+// (modules/data_preprocess.py:65-165 -> sklearn.preprocessing.MinMaxScaler) and the scaled copy of the raw
+// [P][T][N] array straight into the engine's resident layout [P][T][N] (the reference's transpose to [P,N,T],
+// SimulGen-VAE.py:282, and ours back cancel).  All HBM-bound streaming passes.
+// ------------------------------------------------------------------------------------------
+// partial[rs][2][N]: min / max over rows rs, rs+RS, ... of the column; NaNs are ignored like np.nanmin/nanmax
+__global__ __launch_bounds__(256) void minmax_partial_kernel(const float* rows, long n_rows, int N, float* partial) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (c >= N) return;
+    float4 lo = make_float4(INFINITY, INFINITY, INFINITY, INFINITY), hi = make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+    for (long r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        const float4 v = *reinterpret_cast<const float4*>(rows + r * N + c);
+        lo.x = fminf(lo.x, v.x); lo.y = fminf(lo.y, v.y); lo.z = fminf(lo.z, v.z); lo.w = fminf(lo.w, v.w);
+        hi.x = fmaxf(hi.x, v.x); hi.y = fmaxf(hi.y, v.y); hi.z = fmaxf(hi.z, v.z); hi.w = fmaxf(hi.w, v.w);
+    }
+    float* p = partial + (long)blockIdx.y * 2 * N;
+    *reinterpret_cast<float4*>(p + c) = lo;
+    *reinterpret_cast<float4*>(p + N + c) = hi;
+}
+__global__ __launch_bounds__(256) void minmax_final_kernel(const float* partial, int RS, int N, float* mn, float* mx, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float lo = accumulate ? mn[c] : INFINITY, hi = accumulate ? mx[c] : -INFINITY;
+    for (int r = 0; r < RS; ++r) { lo = fminf(lo, partial[(long)r * 2 * N + c]); hi = fmaxf(hi, partial[(long)r * 2 * N + N + c]); }
+    mn[c] = lo; mx[c] = hi;
+}
+// sklearn MinMaxScaler._partial_fit: scale_ = (hi-lo)/handle_zeros(data_max-data_min), min_ = lo - data_min*scale_
+__global__ __launch_bounds__(256) void minmax_coeffs_kernel(const float* mn, const float* mx, int N, float lo, float hi, float* scale, float* offset) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= N) return;
+    float range = mx[c] - mn[c];
+    if (range < 10.f * 1.1920929e-07f) range = 1.f;          // _handle_zeros_in_scale (10 * eps of the dtype)
+    const float s = (hi - lo) / range;
+    scale[c] = s;
+    offset[c] = lo - mn[c] * s;
+}
+template <typename T>
+__global__ __launch_bounds__(256) void scale_convert_kernel(const float* src, const float* scale, const float* offset, T* dst,
+                                                           long n_rows, int N) {
+    const int c = (blockIdx.x * 256 + threadIdx.x) * 8;
+    if (c >= N) return;
+    float s[8], o[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { s[e] = scale[c + e]; o[e] = offset[c + e]; }
+    for (long r = blockIdx.y; r < n_rows; r += gridDim.y) {
+        float v[8];
+        load8(src + r * N + c, v);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = v[e] * s[e] + o[e];     // sklearn: X *= scale_; X += min_
+        store8(dst + r * N + c, v);
+    }
+}
+int ew_minmax_fit(const float* rows, long n_rows, int N, float* mn, float* mx, float* partial, int RS, int accumulate, hipStream_t s) {
+    if (n_rows <= 0 || N % 4) return -1;
+    if (RS > n_rows) RS = (int)n_rows;
+    hipLaunchKernelGGL(minmax_partial_kernel, dim3(cdiv_i(N / 4, 256), RS), dim3(256), 0, s, rows, n_rows, N, partial);
+    hipLaunchKernelGGL(minmax_final_kernel, dim3(cdiv_i(N, 256)), dim3(256), 0, s, partial, RS, N, mn, mx, accumulate);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int ew_minmax_coeffs(const float* mn, const float* mx, int N, float lo, float hi, float* scale, float* offset, hipStream_t s) {
+    hipLaunchKernelGGL(minmax_coeffs_kernel, dim3(cdiv_i(N, 256)), dim3(256), 0, s, mn, mx, N, lo, hi, scale, offset);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+int ew_scale_convert(int dtype, const float* src, const float* scale, const float* offset, void* dst, long n_rows, int N, hipStream_t s) {
+    if (n_rows <= 0) return 0;
+    if (N % 8) return -1;
+    int ry = (int)(n_rows < 2048 ? n_rows : 2048);
+    dim3 grid(cdiv_i(N / 8, 256), ry);
+    if (dtype == 1) hipLaunchKernelGGL((scale_convert_kernel<bf16_t>), grid, dim3(256), 0, s, src, scale, offset, (bf16_t*)dst, n_rows, N);
+    else hipLaunchKernelGGL((scale_convert_kernel<float>), grid, dim3(256), 0, s, src, scale, offset, (float*)dst, n_rows, N);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}

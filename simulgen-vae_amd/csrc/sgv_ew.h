@@ -57,6 +57,11 @@ int ew_augment(int dtype, const void* data, void* out, long sample_elems, int ba
                const unsigned long long* noise_seed, const float* scale, const int* mix_idx, const float* lam, hipStream_t s);
 int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s);
 int ew_scale(float* y, float a, long n, hipStream_t s);
+// input pipeline
+constexpr int SGV_MINMAX_ROWSPLIT = 64;
+int ew_minmax_fit(const float* rows, long n_rows, int N, float* mn, float* mx, float* partial, int RS, int accumulate, hipStream_t s);
+int ew_minmax_coeffs(const float* mn, const float* mx, int N, float lo, float hi, float* scale, float* offset, hipStream_t s);
+int ew_scale_convert(int dtype, const float* src, const float* scale, const float* offset, void* dst, long n_rows, int N, hipStream_t s);
 int ew_cast_rows(int dtype, const float* src, long lds_, void* dst, long ldd, int rows, int C, hipStream_t s);
 
 // ---------------- optimizer / spectral norm (optim.hip) ----------------

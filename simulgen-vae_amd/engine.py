@@ -28,6 +28,7 @@ ABI_SYMBOLS = [
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
     "sgv_adamw_step_range", "sgv_bucket_count", "sgv_last_grad_norm",
+    "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
 ]
 
@@ -92,6 +93,9 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_dataset_sample_bytes.restype = C.c_size_t
     lib.sgv_kernel_time.argtypes = [vp, C.c_char_p, C.POINTER(f32), C.POINTER(i32)]
     lib.sgv_kernel_time_reset.argtypes = [vp, i32]
+    lib.sgv_minmax_fit.argtypes = [vp, C.c_long, i32, vp, vp, i32, vp]
+    lib.sgv_minmax_coeffs.argtypes = [vp, vp, i32, f32, f32, vp, vp, vp]
+    lib.sgv_scale_convert.argtypes = [i32, vp, vp, vp, vp, C.c_long, i32, vp]
     lib.sgv_kernel_time_tag.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(f32), C.POINTER(i32)]
     lib.sgv_test_gemm_nt.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sgv_test_gemm_tn.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

@@ -99,6 +99,12 @@ class ResidentLoader:
 
     def resident(self, engine):
         """Dataset converted once to the engine's layout/dtype and kept in HBM (utils.Dataset load_all)."""
+        x = self.dataset.x_data
+        if hasattr(x, "buf") and hasattr(x, "num_node"):     # data_preprocess.DeviceDataset: written in this layout already
+            from ..engine import DTYPES
+            if DTYPES[x.dtype] != DTYPES[engine.compute_dtype] or x.buf.numel() != len(x) * engine.sample_bytes():
+                raise ValueError(f"device dataset is {x.dtype} {x.shape}, engine computes in {engine.compute_dtype}")
+            return x.buf
         if self._resident is None or self._resident[0] is not engine:
             P = len(self.dataset)
             buf = torch.empty(P * engine.sample_bytes(), dtype=torch.uint8, device="cuda")

@@ -119,13 +119,15 @@ class Dataset(torch.utils.data.Dataset):
 
     def __init__(self, x_data, load_all):
         self.load_all = bool(load_all)
-        if self.load_all and torch.cuda.is_available():
+        if hasattr(x_data, "buf") and hasattr(x_data, "num_node"):      # data_preprocess.DeviceDataset: already in HBM
+            self.x_data = x_data
+        elif self.load_all and torch.cuda.is_available():
             self.x_data = torch.as_tensor(np.asarray(x_data), dtype=torch.float32).cuda()
         else:
             self.x_data = np.ascontiguousarray(x_data)
 
     def __getitem__(self, index):
-        if torch.is_tensor(self.x_data):
+        if torch.is_tensor(self.x_data) or hasattr(self.x_data, "buf"):
             return self.x_data[index]
         return torch.from_numpy(self.x_data[index].copy()).float()
 

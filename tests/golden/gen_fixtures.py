@@ -259,7 +259,37 @@ def augmentation():
     print("augment seed", seed, "counts:", counts, "beta", log["beta"])
 
 
+def scaler():
+    """Reference data_scaler / reduce_dataset (modules/data_preprocess.py:13-41,65-165) on a small synthetic raw array
+    [P, T, N] with a constant node, a NaN-free heavy-tailed node and values outside the sampled range.
+    P*T = 12000 rows > 10x the 1000-row sample floor, so the np.random.seed(42) row sampling really subsamples."""
+    import modules.data_preprocess as dp
+    rng = np.random.default_rng(123)
+    P, T, N = 60, 200, 16
+    raw = (rng.standard_normal((P, T, N)) * rng.uniform(0.1, 30.0, N) + rng.uniform(-5, 5, N)).astype(np.float32)
+    raw[:, :, 3] = 2.5                      # zero range -> sklearn's _handle_zeros_in_scale
+    raw[7, 11, 5] = 1e4                     # outlier that the row sample may or may not contain
+    cwd = os.getcwd()
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        os.chdir(d)
+        os.makedirs("model_save")
+        try:
+            work = raw.copy()
+            out, shape, sc = dp.data_scaler(work, work, T, N, 1)
+        finally:
+            os.chdir(cwd)
+    nt, red, nn = dp.reduce_dataset(raw.copy(), 150, 8, P, T, 4, 12)
+    np.savez_compressed(os.path.join(HERE, "scaler.npz"), raw=raw, scaled=np.asarray(out, np.float32), data_min=sc.data_min_,
+                        data_max=sc.data_max_, scale=sc.scale_, offset=sc.min_, shape=np.array(shape),
+                        reduced=np.asarray(red, np.float32), reduced_meta=np.array([nt, nn]))
+    print("scaler.npz", out.shape, float(np.min(out)), float(np.max(out)))
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "scaler":
+        scaler()
+        sys.exit(0)
     run_case("g0_small_MSE", CONFIGS["g0"], True, "MSE", full=True)
     run_case("g0_large_MSE", CONFIGS["g0"], False, "MSE", full=True)
     for lf in ("MAE", "smoothL1", "Huber"):
@@ -267,3 +297,4 @@ if __name__ == "__main__":
     run_case("g1_small_MSE", CONFIGS["g1"], True, "MSE", full=False)
     schedules()
     augmentation()
+    scaler()

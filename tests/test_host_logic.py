@@ -181,3 +181,23 @@ def test_two_rank_mean_gradient_equals_full_batch(tmp_path):
     grads = m.backward(1e6, 1e-4)
     ref = np.concatenate([grads[e.name].ravel() for e in param_spec(cfg) if grads.get(e.name) is not None])
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-5
+
+
+def test_input_pipeline_host_side_matches_reference_fixture():
+    """SURVEY 8(f) N3, host half: reduce_dataset and the seeded row sampling of data_scaler against the fixture
+    recorded from the reference (tests/golden/gen_fixtures.py scaler)."""
+    import os
+    from simulgen_vae_amd.modules import data_preprocess as dp
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "scaler.npz"))
+    raw = g["raw"]
+    P, T, N = raw.shape
+    nt, red, nn = dp.reduce_dataset(raw.copy(), 150, 8, P, T, 4, 12)
+    assert (nt, nn) == tuple(g["reduced_meta"]) and red.dtype == np.float64
+    np.testing.assert_array_equal(red.astype(np.float32), g["reduced"])
+    same = dp.reduce_dataset(raw, T, N, P, T, 0, N)
+    assert same[1] is raw
+    idx, max_samples, stride = dp._sample_rows(P * T)
+    assert max_samples == 1200 and stride == 10 and len(set(idx.tolist())) == 1200
+    rows = raw.reshape(-1, N)[idx]
+    np.testing.assert_allclose(rows.min(0), g["data_min"], rtol=0, atol=0)     # the reference saw exactly these rows
+    np.testing.assert_allclose(rows.max(0), g["data_max"], rtol=0, atol=0)

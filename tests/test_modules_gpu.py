@@ -202,3 +202,44 @@ def test_overlapped_allreduce_step_equals_plain_step():
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_data_scaler_matches_reference_fixture(tmp_path, monkeypatch):
+    """GPU data_scaler (per-node MinMaxScaler(-0.7, 0.7) fitted on the reference's seeded row sample,
+    transform of the whole array) against the outputs recorded from the reference; then the HBM-resident variant
+    feeding create_augmented_dataloaders without another conversion.  fp32 tolerance: 2e-6 absolute on values in
+    [-0.7, 0.7] (the reference multiplies then adds in two roundings, the kernel uses one FMA)."""
+    from modules import data_preprocess as dp
+    monkeypatch.chdir(tmp_path)
+    g = np.load(os.path.join(GOLD, "scaler.npz"))
+    raw = g["raw"]
+    P, T, N = raw.shape
+    out, shape, sc = dp.data_scaler(raw.copy(), raw, T, N, 1)
+    assert tuple(shape) == tuple(g["shape"]) and out.shape == raw.shape and out.dtype == np.float32
+    np.testing.assert_array_equal(sc.data_min_, g["data_min"])
+    np.testing.assert_array_equal(sc.data_max_, g["data_max"])
+    np.testing.assert_allclose(sc.scale_, g["scale"], rtol=1e-6)
+    np.testing.assert_allclose(sc.min_, g["offset"], rtol=1e-5, atol=1e-6)
+    assert sc.scale_[3] == np.float32(1.4)                       # zero-range node: scale = range of the target / 1
+    ref = g["scaled"]
+    assert np.abs(out - ref).max() <= 2e-6 * max(1.0, np.abs(ref).max())
+    assert ref.max() > 100                                      # the outlier outside the sampled range is NOT clipped
+    import pickle
+    sk = pickle.load(open("model_save/scaler.pkl", "rb"))        # our own file, written a few lines above
+    np.testing.assert_allclose(sk.transform(raw[0]), out[0], atol=5e-6)
+    # resident variant: engine layout [P][T][N] bf16, consumed by the loaders as is
+    N2 = 64
+    raw2 = np.tile(raw, (1, 1, N2 // N))[:8, :12]
+    dev, _, sc2 = dp.data_scaler(raw2.copy(), raw2, 12, N2, 1, device_dataset=True, compute_dtype="bf16")
+    host, _, _ = dp.data_scaler(raw2.copy(), raw2, 12, N2, 1)
+    want = torch.from_numpy(host).to(torch.bfloat16)
+    got = dev.buf.view(torch.bfloat16).view(8, 12, N2).cpu()
+    assert torch.equal(got, want)
+    assert dev.shape == (8, N2, 12) and torch.equal(dev[3].cpu(), want[3].T.float())
+    tl, vl = aug.create_augmented_dataloaders(dev, 2, load_all=True)
+    from simulgen_vae_amd.engine import Engine
+    from tests.gpu_common import make_cfg as mk
+    cfg = mk(dict(latent_dim=32, hierarchical_dim=8, enc=[32, 16, 8, 8], num_node=N2, num_time=12))
+    eng = Engine(cfg, max_batch=2, compute_dtype="bf16")
+    assert tl.resident(eng).data_ptr() == dev.buf.data_ptr()
+    eng.close()
