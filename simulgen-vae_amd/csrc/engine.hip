@@ -792,7 +792,7 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     p.M = (int)M; p.N1 = l.cout; p.N2 = l.cin; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
     p.use_tr = e->use_tr;
     p.ldo = l.cin; p.out_tap_stride = (long)l.cout * l.cin;
-    int sk = gemm_tn_pick_splitk(p.M, p.N1, p.N2, p.taps, e->dt);
+    int sk = e->use_tr ? gemm_tn_pick_splitk(p.M, p.N1, p.N2, p.taps, e->dt, e->T) : gemm_tn_pick_splitk(p.M, p.N1, p.N2, p.taps, e->dt);
     const long nw = l.nw();
     if ((size_t)sk * nw > e->partial_tn_floats) sk = 1;
     float* G = e->grads + l.gw;
@@ -961,7 +961,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
         if (sk > 1) pf = std::max(pf, (size_t)sk * M * l.cout);
         sk = gemm_nt_pick_splitk((int)M, l.cin, l.cout, l.k, e->dt);
         if (sk > 1 && l.need_wct) pf = std::max(pf, (size_t)sk * M * l.cin);
-        sk = gemm_tn_pick_splitk((int)M, l.cout, l.cin, l.k, e->dt);
+        sk = std::max(gemm_tn_pick_splitk((int)M, l.cout, l.cin, l.k, e->dt, e->T), gemm_tn_pick_splitk((int)M, l.cout, l.cin, l.k, e->dt));
         if (sk > 1) pf_tn = std::max(pf_tn, (size_t)sk * l.nw());
     }
     if (pf < ((size_t)32 << 20)) pf = (size_t)32 << 20;   // batch < max_batch can pick deeper splits
@@ -1705,7 +1705,7 @@ int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M,
                      int use_tr, void* stream) {
     GemmTN p; memset(&p, 0, sizeof(p));
     p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
-    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_wide = use_tr == 2;
     float* partial = nullptr;
     const long nw = (long)taps * N1 * N2;
     if (p.splitk > 1) {

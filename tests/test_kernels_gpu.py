@@ -53,7 +53,7 @@ def ref_conv_tn(dY, X, taps, Tlen):
     for j in range(taps):
         dt = j - pad
         src = np.arange(M) + dt
-        ok = (t + dt >= 0) & (t + dt < Tlen)
+        ok = (t + dt >= 0) & (t + dt < Tlen) & (src < M)      # a partial last sample: rows past M read as zeros
         Xs = np.zeros_like(X, dtype=np.float64)
         Xs[ok] = X[src[ok]]
         out[j] = dY.astype(np.float64).T @ Xs
@@ -137,6 +137,41 @@ def test_gemm_tn(dtype, use_tr, case):
     assert np.isfinite(got).all()
     err = np.abs(got - ref).max() / np.abs(ref).max()
     assert err < 2e-5, err
+
+
+TN_WIDE_CASES = [
+    # M, N1, N2, taps, Tlen, splitk  -- all eligible for the (opt-in) 128x256 LDS-DMA weight-gradient kernel (bf16, N2 >= 256, Tlen >= 64)
+    (1600, 192, 520, 5, 200, 1),      # ragged N1/N2 tiles, taps across sample boundaries
+    (1000, 136, 256, 3, 100, 3),      # M not a multiple of 64, split-K slabs
+    (3200, 1024, 768, 1, 200, 2),
+    (777, 64, 264, 5, 64, 1),         # M not a multiple of Tlen, smallest allowed Tlen
+    (4000, 320, 1280, 3, 200, 5),
+    (512, 128, 256, 1, 512, 1),       # 8 stages: the shortest loop the launcher selects it for
+]
+
+
+@pytest.mark.parametrize("case", TN_WIDE_CASES)
+def test_gemm_tn_wide(case):
+    """gemm_tn_wide_kernel vs numpy on bf16-exact inputs, each shape repeated 8x (the counted-vmcnt ring must give
+    the same answer every time)."""
+    import torch
+    lib = E.load_library()
+    M, N1, N2, taps, Tlen, splitk = case
+    rng = np.random.default_rng(11)
+    dY = _bf16_round(rng.standard_normal((M, N1)).astype(np.float32))
+    X = _bf16_round(rng.standard_normal((M, N2)).astype(np.float32))
+    ddY, dX = _dev(dY, 1), _dev(X, 1)
+    ref = ref_conv_tn(dY, X, taps, Tlen)
+    scale = np.abs(ref).max()
+    for rep in range(8):
+        out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+        # use_tr = 2: force the (opt-in) wide kernel for every eligible shape
+        rc = lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk, 2, None)
+        assert rc == 0, lib.sgv_last_error()
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), (case, rep)
+        err = np.abs(got - ref).max() / scale
+        assert err < 2e-5, (case, rep, err)
 
 
 @pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1)])
