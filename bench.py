@@ -202,7 +202,7 @@ def main():
         value = B * world * args.steps / elapsed
         fwd, dx, dw = gemm_flops(cfg, B)
         peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
-        roof = {"kernel": "gemm_nt_wide_kernel + gemm_nt_kernel (conv forward + input-gradient implicit GEMMs)", "bound": "mfma",
+        roof = {"kernel": "gemm_nt_wide64p_kernel + gemm_nt_kernel (conv forward + input-gradient implicit GEMMs)", "bound": "mfma",
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "flop_per_step": fwd + dx}
         result = {"metric": f"simulation samples/sec/node (preset-1 {args.size}, batch 16)", "value": round(value, 3),

@@ -309,736 +309,26 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     }
 }
 
-// =========================================================================================
-// NT, LDS-DMA version: operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds), 3-stage ring,
-// prefetch distance 2, one raw s_barrier per K step, no ds_write / staging VGPRs.
-//   * LDS image per stage: A[128 rows][64 B] | W[128 rows][64 B], unpadded (an LDS-DMA wave-instruction writes
-//     M0-base + lane*16, i.e. 16 consecutive rows).  Bank conflicts are avoided by an XOR swizzle applied on the
-//     SOURCE side: LDS slot p of row r holds source chunk p ^ ((r>>2)&3); readers use the same involution.
-//   * masked taps / K tails / tile edges: the lane's buffer offset is pointed out of range and the hardware
-//     writes zeros into LDS (verified on MI355X: tests/micro/lds_dma_probe.hip).
-//   * each wave counts only its own DMA ops: 4 per tile, so `s_waitcnt vmcnt(4)` = "my part of tile s landed,
-//     tile s+1 may still be in flight"; the barrier after it publishes all four waves' parts.
-// =========================================================================================
 typedef __attribute__((address_space(3))) void lds_void;
-// timing-only ablations for tests/micro (results are wrong when any is set): 1 = no MFMA, 2 = no DMA loads,
-// 4 = no LDS fragment reads
-#ifndef SGV_ABLATE
-#define SGV_ABLATE 0
-#endif
-template <typename T>
-__global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_dma_kernel(const GemmNT p) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = 4 * EPC;
-    constexpr bool IS_BF16 = sizeof(T) == 2;
-    constexpr int ESZ = (int)sizeof(T);
-    constexpr int TILEB = 128 * 64;
-    constexpr int STAGEB = 2 * TILEB;
-    constexpr int NS = 3;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
-    const int ntiles = tiles_n * tiles_m;
-    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
-    const int z = logical / ntiles;
-    const int tile = logical - z * ntiles;
-    int tm, tn;
-    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm << 7, n0 = tn << 7;
-    const int kchunks = (p.K + BK - 1) / BK;
-    const int total = p.taps * kchunks;
-    const int s_begin = (int)((long)total * z / p.splitk);
-    const int s_end = (int)((long)total * (z + 1) / p.splitk);
-
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
-    // DMA roles: wave w fills tile rows [32w, 32w+32) of each operand with two 1-KiB instructions (16 rows each)
-    const int dr0 = wave * 32 + (lane >> 2), dr1 = dr0 + 16;
-    const int dp = lane & 3;
-    const int dc0 = dp ^ ((dr0 >> 2) & 3), dc1 = dp ^ ((dr1 >> 2) & 3);   // source chunk for this LDS slot
-    const int am0 = m0 + dr0, am1 = m0 + dr1, wn0 = n0 + dr0, wn1 = n0 + dr1;
-    const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
-    const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
-    const uint32_t abase0 = (uint32_t)(((long)am0 * p.lda + dc0 * EPC) * ESZ), abase1 = (uint32_t)(((long)am1 * p.lda + dc1 * EPC) * ESZ);
-    const uint32_t wbase0 = wn0 < p.N ? (uint32_t)(((long)wn0 * p.ldw + dc0 * EPC) * ESZ) : OOB_OFF;
-    const uint32_t wbase1 = wn1 < p.N ? (uint32_t)(((long)wn1 * p.ldw + dc1 * EPC) * ESZ) : OOB_OFF;
-    unsigned char* const dmaA = smem + wave * 2048;          // wave-uniform LDS bases (stage 0)
-    unsigned char* const dmaW = smem + TILEB + wave * 2048;
-
-    const int lda_b = (int)(p.lda * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
-    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;     // incremental state of the next tile to issue
-    {
-        const int kci0 = s_begin / p.taps;
-        ld_j = s_begin - kci0 * p.taps;
-        ld_kcb = kci0 * BK * ESZ;
-        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
-        ld_woff = ld_j * wts_b + ld_kcb;
-    }
-    const int klim0_b = (p.K - dc0 * EPC) * ESZ, klim1_b = (p.K - dc1 * EPC) * ESZ;
-    uint32_t am0_mask = 0u, am1_mask = 0u;
-    for (int j = 0; j < p.taps; ++j) {
-        if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
-        if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
-    }
-#define SGV_DMA_ISSUE(STAGE, S)                                                                               \
-    {                                                                                                         \
-        const bool k0_ = ld_kcb < klim0_b, k1_ = ld_kcb < klim1_b;                                            \
-        const bool pa0 = k0_ && ((am0_mask >> ld_j) & 1u);                                                    \
-        const bool pa1 = k1_ && ((am1_mask >> ld_j) & 1u);                                                    \
-        if (!(SGV_ABLATE & 2)) {                                                                              \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB), 16, pa0 ? abase0 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + 1024), 16, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB), 16, k0_ ? wbase0 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 1024), 16, k1_ ? wbase1 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
-        } else { asm volatile("" :: "v"(pa0), "v"(pa1), "v"(ld_aoff), "v"(ld_woff)); }                        \
-        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
-        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
-    }
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int lr = lane & 31, lh = lane >> 5;
-    const int swz = (lr >> 2) & 3;                           // rows wm*64 + i*32 + lr: bits 2..3 come from lr
-    const int a_frag_off = (wm * 64 + lr) * 64;
-    const int w_frag_off = TILEB + (wn * 64 + lr) * 64;
-#define SGV_DMA_COMPUTE(STAGE)                                                                                \
-    {                                                                                                         \
-        const unsigned char* sa_ = smem + (STAGE) * STAGEB + a_frag_off;                                      \
-        const unsigned char* sw_ = smem + (STAGE) * STAGEB + w_frag_off;                                      \
-        if constexpr (IS_BF16) {                                                                              \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-                const int po_ = ((ks * 2 + lh) ^ swz) * 16;                                                   \
-                bf16x8 a0_, a1_, b0_, b1_;                                                                    \
-                if (!(SGV_ABLATE & 4)) {                                                                      \
-                a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                                            \
-                a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 64 + po_);                                  \
-                b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                                            \
-                b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 64 + po_);                                  \
-                } else { a0_ = a1_ = b0_ = b1_ = __builtin_bit_cast(bf16x8, make_uint4(po_, lane, ks, 7)); } \
-                if (!(SGV_ABLATE & 1)) {                                                                      \
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
-                } else { asm volatile("" :: "v"(a0_), "v"(a1_), "v"(b0_), "v"(b1_)); }                        \
-            }                                                                                                 \
-        } else {                                                                                              \
-            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
-                const int k_ = ks * 2 + lh;                                                                   \
-                const int po_ = (((k_ >> 2) ^ swz) * 16) + (k_ & 3) * 4;                                      \
-                const float a0_ = *reinterpret_cast<const float*>(sa_ + po_);                                 \
-                const float a1_ = *reinterpret_cast<const float*>(sa_ + 32 * 64 + po_);                       \
-                const float b0_ = *reinterpret_cast<const float*>(sw_ + po_);                                 \
-                const float b1_ = *reinterpret_cast<const float*>(sw_ + 32 * 64 + po_);                       \
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b0_, acc[0][0], 0, 0, 0);               \
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0_, b1_, acc[0][1], 0, 0, 0);               \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b0_, acc[1][0], 0, 0, 0);               \
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1_, b1_, acc[1][1], 0, 0, 0);               \
-            }                                                                                                 \
-        }                                                                                                     \
-    }
-
-    const int nst = s_end - s_begin;
-    if (nst > 0) {
-        SGV_DMA_ISSUE(0, s_begin);
-        if (nst > 1) SGV_DMA_ISSUE(1, s_begin + 1);
-        int st = 0;                                   // stage holding tile i
-        int i = 0;
-        for (; i + 2 < nst; ++i) {
-            // my 4 DMA ops of tile i have landed, then all waves'; ONE asm statement so hipcc cannot hoist the
-            // refill below above the barrier (seen as an intermittent WAR race in the fp32 build)
-            asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            const int st2 = st >= 1 ? st - 1 : st + 2;             // (st + 2) % 3: last read in step i-1
-            if (st2 == 0) { SGV_DMA_ISSUE(0, s_begin + i + 2); }
-            else if (st2 == 1) { SGV_DMA_ISSUE(1, s_begin + i + 2); }
-            else { SGV_DMA_ISSUE(2, s_begin + i + 2); }
-            asm volatile("" ::: "memory");
-            if (st == 0) { SGV_DMA_COMPUTE(0); } else if (st == 1) { SGV_DMA_COMPUTE(1); } else { SGV_DMA_COMPUTE(2); }
-            st = st == 2 ? 0 : st + 1;
-        }
-        for (; i < nst; ++i) {                                     // last two tiles: nothing left to issue
-            if (i + 1 < nst) asm volatile("s_waitcnt vmcnt(4)\n\ts_barrier" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-            if (st == 0) { SGV_DMA_COMPUTE(0); } else if (st == 1) { SGV_DMA_COMPUTE(1); } else { SGV_DMA_COMPUTE(2); }
-            st = st == 2 ? 0 : st + 1;
-        }
-    }
-#undef SGV_DMA_ISSUE
-#undef SGV_DMA_COMPUTE
-
-    // ---- epilogue (same as gemm_nt_kernel) ----
-    const float sc = p.scale ? *p.scale : 1.0f;
-    const bool full = (m0 + 128 <= p.M) && (n0 + 128 <= p.N);
-    const T* addp = reinterpret_cast<const T*>(p.addend);
-    if constexpr (IS_BF16) {
-        if (p.splitk == 1 && !p.out_f32) {
-            constexpr int CP = 272;
-            static_assert(128 * CP <= NS * STAGEB, "C tile must fit in the ring");
-            __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 2; ++a) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int lcol = wn * 64 + b * 32 + lr;
-                    const int gcol = n0 + lcol;
-                    const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lrow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
-                    }
-                }
-            }
-            __syncthreads();
-            bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = tid + i * 256;
-                const int lrow = c >> 4, lc8 = (c & 15) * 8;
-                const int grow = m0 + lrow, gcol = n0 + lc8;
-                if (grow < p.M && gcol < p.N) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
-                    if (addp) {
-                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
-                    }
-                    *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wn * 64 + b * 32 + lr;
-            const bool cok = full || (col < p.N);
-            const int colc = cok ? col : 0;
-            const int rbase = m0 + wm * 64 + a * 32 + 4 * lh;
-            if (p.splitk > 1) {
-                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && (full || row < p.M)) dst[(long)row * p.N] = acc[a][b][r];
-                }
-            } else {
-                const float bv = p.bias ? p.bias[colc] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && (full || row < p.M)) {
-                        float v = acc[a][b][r] * sc + bv;
-                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
-                        if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
-                        else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = from_f32<T>(v);
-                    }
-                }
-            }
-        }
-    }
-}
 
 // =========================================================================================
-// NT, LDS-DMA, 128(M) x 256(N) tile ("wide"): 4 waves, each 128 x 64 (4x2 MFMA tiles, 16 MFMAs per K step),
-// 3-stage ring of 24 KiB (A 128 rows | W 256 rows, 64-B rows, source-side XOR swizzle), 2 blocks per CU.
-// Versus the 128x128 kernels: twice the MFMA work per barrier / per step of loop overhead (measured: the step
-// skeleton cost as much as the 8 MFMAs it wrapped), 0.75 instead of 1 ds_read_b128 per MFMA, 25 % fewer operand
-// bytes per FLOP, and for M = 3200 the grid (25 x N/256 tiles) fills the 512 block slots in whole rounds.
-// =========================================================================================
-template <typename T>
-__global__ __launch_bounds__(256, 1) void gemm_nt_wide_kernel(const GemmNT p) {
-    constexpr int EPC = ElemTraits<T>::EPC;
-    constexpr int BK = 4 * EPC;
-    constexpr bool IS_BF16 = sizeof(T) == 2;
-    constexpr int ESZ = (int)sizeof(T);
-    constexpr int TILEA = 128 * 64, TILEW = 256 * 64;
-    constexpr int STAGEB = TILEA + TILEW;
-    constexpr int NS = 3;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 127) >> 7;
-    const int ntiles = tiles_n * tiles_m;
-    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
-    const int z = logical / ntiles;
-    const int tile = logical - z * ntiles;
-    int tm, tn;
-    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm << 7, n0 = tn << 8;
-    const int kchunks = (p.K + BK - 1) / BK;
-    const int total = p.taps * kchunks;
-    const int s_begin = (int)((long)total * z / p.splitk);
-    const int s_end = (int)((long)total * (z + 1) / p.splitk);
-
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
-    // DMA roles per wave and stage: A rows [32w, 32w+32) (2 ops), W rows [64w, 64w+64) (4 ops); 16 rows per op
-    const int rl = lane >> 2, dp = lane & 3;
-    const int ar0 = wave * 32 + rl, ar1 = ar0 + 16;
-    const int wr0 = wave * 64 + rl, wr1 = wr0 + 16, wr2 = wr0 + 32, wr3 = wr0 + 48;
-    // rows r and r+16 share (r>>2)&3 parity pattern: swizzle term uses the tile-local row
-    const int dca0 = dp ^ ((ar0 >> 2) & 3), dca1 = dp ^ ((ar1 >> 2) & 3);
-    const int dcw0 = dp ^ ((wr0 >> 2) & 3), dcw1 = dp ^ ((wr1 >> 2) & 3), dcw2 = dp ^ ((wr2 >> 2) & 3), dcw3 = dp ^ ((wr3 >> 2) & 3);
-    const int am0 = m0 + ar0, am1 = m0 + ar1;
-    const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
-    const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
-    const uint32_t abase0 = (uint32_t)(((long)am0 * p.lda + dca0 * EPC) * ESZ), abase1 = (uint32_t)(((long)am1 * p.lda + dca1 * EPC) * ESZ);
-#define SGV_WBASE(R, DC) ((n0 + (R)) < p.N ? (uint32_t)(((long)(n0 + (R)) * p.ldw + (DC) * EPC) * ESZ) : OOB_OFF)
-    const uint32_t wbase0 = SGV_WBASE(wr0, dcw0), wbase1 = SGV_WBASE(wr1, dcw1), wbase2 = SGV_WBASE(wr2, dcw2), wbase3 = SGV_WBASE(wr3, dcw3);
-#undef SGV_WBASE
-    unsigned char* const dmaA = smem + wave * 2048;
-    unsigned char* const dmaW = smem + TILEA + wave * 4096;
-
-    const int lda_b = (int)(p.lda * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
-    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;
-    {
-        const int kci0 = s_begin / p.taps;
-        ld_j = s_begin - kci0 * p.taps;
-        ld_kcb = kci0 * BK * ESZ;
-        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
-        ld_woff = ld_j * wts_b + ld_kcb;
-    }
-    // chunk validity along K depends on the lane's source chunk; all dc* are in 0..3
-    const int kK_b = p.K * ESZ;
-    uint32_t am0_mask = 0u, am1_mask = 0u;
-    for (int j = 0; j < p.taps; ++j) {
-        if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
-        if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
-    }
-#define SGV_KOK(DC) ((ld_kcb + (DC) * 16) < kK_b)
-#define SGV_WIDE_ISSUE(STAGE)                                                                                 \
-    {                                                                                                         \
-        const bool pa0 = SGV_KOK(dca0) && ((am0_mask >> ld_j) & 1u);                                          \
-        const bool pa1 = SGV_KOK(dca1) && ((am1_mask >> ld_j) & 1u);                                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB), 16, pa0 ? abase0 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + 1024), 16, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB), 16, SGV_KOK(dcw0) ? wbase0 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0);        \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 1024), 16, SGV_KOK(dcw1) ? wbase1 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 2048), 16, SGV_KOK(dcw2) ? wbase2 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + 3072), 16, SGV_KOK(dcw3) ? wbase3 + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0); \
-        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
-        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
-    }
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int lr = lane & 31, lh = lane >> 5;
-    const int swz = (lr >> 2) & 3;
-    const int a_frag_off = lr * 64;
-    const int w_frag_off = TILEA + (wave * 64 + lr) * 64;
-#define SGV_WIDE_COMPUTE(STAGE)                                                                               \
-    {                                                                                                         \
-        const unsigned char* sa_ = smem + (STAGE) * STAGEB + a_frag_off;                                      \
-        const unsigned char* sw_ = smem + (STAGE) * STAGEB + w_frag_off;                                      \
-        if constexpr (IS_BF16) {                                                                              \
-            _Pragma("unroll") for (int ks = 0; ks < 2; ++ks) {                                                \
-                const int po_ = ((ks * 2 + lh) ^ swz) * 16;                                                   \
-                const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                               \
-                const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 64 + po_);                     \
-                const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                               \
-                const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 64 + po_);                     \
-                const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(sa_ + 64 * 64 + po_);                     \
-                const bf16x8 a3_ = *reinterpret_cast<const bf16x8*>(sa_ + 96 * 64 + po_);                     \
-                acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
-                acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
-                acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b0_, acc[2][0], 0, 0, 0);            \
-                acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b1_, acc[2][1], 0, 0, 0);            \
-                acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b0_, acc[3][0], 0, 0, 0);            \
-                acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b1_, acc[3][1], 0, 0, 0);            \
-            }                                                                                                 \
-        } else {                                                                                              \
-            _Pragma("unroll") for (int ks = 0; ks < 8; ++ks) {                                                \
-                const int k_ = ks * 2 + lh;                                                                   \
-                const int po_ = (((k_ >> 2) ^ swz) * 16) + (k_ & 3) * 4;                                      \
-                const float b0_ = *reinterpret_cast<const float*>(sw_ + po_);                                 \
-                const float b1_ = *reinterpret_cast<const float*>(sw_ + 32 * 64 + po_);                       \
-                _Pragma("unroll") for (int a = 0; a < 4; ++a) {                                               \
-                    const float av_ = *reinterpret_cast<const float*>(sa_ + a * 32 * 64 + po_);               \
-                    acc[a][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, b0_, acc[a][0], 0, 0, 0);           \
-                    acc[a][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(av_, b1_, acc[a][1], 0, 0, 0);           \
-                }                                                                                             \
-            }                                                                                                 \
-        }                                                                                                     \
-    }
-    // one pipeline step: my 6 DMA ops of the tile in stage CUR have landed (tile+1 may be in flight), publish,
-    // refill the stage that was read in the previous step, multiply
-#define SGV_WIDE_STEP(CUR, REFILL)                                                                            \
-    {                                                                                                         \
-        /* one asm statement: neither the DMA issue below nor the LDS reads can be moved across it */         \
-        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");                                         \
-        SGV_WIDE_ISSUE(REFILL);                                                                               \
-        asm volatile("" ::: "memory");                                                                        \
-        SGV_WIDE_COMPUTE(CUR);                                                                                \
-    }
-#define SGV_WIDE_TAIL(CUR, WAIT)                                                                              \
-    {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(" #WAIT ")\n\ts_barrier" ::: "memory");                                 \
-        SGV_WIDE_COMPUTE(CUR);                                                                                \
-    }
-    const int nst = s_end - s_begin;
-    if (nst > 0) {
-        SGV_WIDE_ISSUE(0);
-        if (nst > 1) SGV_WIDE_ISSUE(1);
-        int i = 0;
-        // steady state, unrolled over the 3-stage ring: tile i in stage i%3, refill stage (i+2)%3
-        while (i + 5 <= nst) {          // all three steps still have a tile i+2 to issue
-            SGV_WIDE_STEP(0, 2)
-            SGV_WIDE_STEP(1, 0)
-            SGV_WIDE_STEP(2, 1)
-            i += 3;
-        }
-        // 1..4 tiles left: tile i sits in stage 0 (i is a multiple of 3)
-        const int rem = nst - i;
-        if (rem == 4) { SGV_WIDE_STEP(0, 2) SGV_WIDE_STEP(1, 0) SGV_WIDE_TAIL(2, 6) SGV_WIDE_TAIL(0, 0) }
-        else if (rem == 3) { SGV_WIDE_STEP(0, 2) SGV_WIDE_TAIL(1, 6) SGV_WIDE_TAIL(2, 0) }
-        else if (rem == 2) { SGV_WIDE_TAIL(0, 6) SGV_WIDE_TAIL(1, 0) }
-        else { SGV_WIDE_TAIL(0, 0) }
-    }
-#undef SGV_WIDE_ISSUE
-#undef SGV_WIDE_COMPUTE
-#undef SGV_WIDE_STEP
-#undef SGV_WIDE_TAIL
-#undef SGV_KOK
-
-    // ---- epilogue ----
-    const float sc = p.scale ? *p.scale : 1.0f;
-    const T* addp = reinterpret_cast<const T*>(p.addend);
-    if constexpr (IS_BF16) {
-        if (p.splitk == 1 && !p.out_f32) {
-            constexpr int CP = 528;   // 512 B + 16 B pad
-            static_assert(128 * CP <= NS * STAGEB, "C tile must fit in the ring");
-            __syncthreads();
-#pragma unroll
-            for (int a = 0; a < 4; ++a) {
-#pragma unroll
-                for (int b = 0; b < 2; ++b) {
-                    const int lcol = wave * 64 + b * 32 + lr;
-                    const int gcol = n0 + lcol;
-                    const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int lrow = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
-                    }
-                }
-            }
-            __syncthreads();
-            bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = tid + i * 256;          // 4096 chunks of 8 bf16
-                const int lrow = c >> 5, lc8 = (c & 31) * 8;
-                const int grow = m0 + lrow, gcol = n0 + lc8;
-                if (grow < p.M && gcol < p.N) {
-                    bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
-                    if (addp) {
-                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
-                    }
-                    *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
-                }
-            }
-            return;
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wave * 64 + b * 32 + lr;
-            const bool cok = col < p.N;
-            const int colc = cok ? col : 0;
-            const int rbase = m0 + a * 32 + 4 * lh;
-            if (p.splitk > 1) {
-                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < p.M) dst[(long)row * p.N] = acc[a][b][r];
-                }
-            } else {
-                const float bv = p.bias ? p.bias[colc] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < p.M) {
-                        float v = acc[a][b][r] * sc + bv;
-                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
-                        if (p.out_f32) reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
-                        else reinterpret_cast<T*>(p.C)[(long)row * p.ldc + col] = from_f32<T>(v);
-                    }
-                }
-            }
-        }
-    }
-}
-
-// =========================================================================================
-// NT, LDS-DMA, 128 x 256 tile, K-step 64 ("wide64", bf16 only): like gemm_nt_wide_kernel but each stage holds
-// 64 K elements (128-byte rows; 3 stages x 48 KiB = 144 KiB of the 160 KiB LDS, one block per CU): 32 MFMAs per
-// wave per barrier, 12 DMA ops per wave per stage (vmcnt(12)), 96 KiB of operand bytes in flight per CU.
-// LDS slot p (16 B) of row r holds source chunk p ^ ((r>>1)&7): two 128-B rows share a 256-B bank row, so the 8
-// chunk slots x 2 row parities of a ds_read_b128 lane group are all distinct.
-// =========================================================================================
-__global__ __launch_bounds__(256, 1) void gemm_nt_wide64_kernel(const GemmNT p) {
-    typedef bf16_t T;
-    constexpr int EPC = 8, BK = 64, ESZ = 2;
-    constexpr int TILEA = 128 * 128, TILEW = 256 * 128;
-    constexpr int STAGEB = TILEA + TILEW;       // 48 KiB
-    constexpr int NS = 3;
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 127) >> 7;
-    const int ntiles = tiles_n * tiles_m;
-    const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
-    const int z = logical / ntiles;
-    const int tile = logical - z * ntiles;
-    int tm, tn;
-    grouped_raster(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm << 7, n0 = tn << 8;
-    const int kchunks = (p.K + BK - 1) / BK;
-    const int total = p.taps * kchunks;
-    const int s_begin = (int)((long)total * z / p.splitk);
-    const int s_end = (int)((long)total * (z + 1) / p.splitk);
-
-    const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
-    // DMA roles: one op = 8 rows x 128 B.  Wave w: A rows [32w, 32w+32) (4 ops), W rows [64w, 64w+64) (8 ops).
-    const int rl = lane >> 3, dp = lane & 7;
-    // tile-local rows of op q: base + 8q + rl; (row>>1)&7 = ((8q + rl)>>1)&7 since bases are multiples of 32
-    // -> the swizzle term only depends on (8q + rl): ((rl>>1) + 4q) & 7
-    const int lda_b = (int)(p.lda * ESZ), ldw_b = (int)(p.ldw * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
-    uint32_t aoffs[4], woffs[8];
-    uint32_t amask[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const int row = wave * 32 + q * 8 + rl;
-        const int dc = dp ^ ((row >> 1) & 7);
-        const int am = m0 + row;
-        aoffs[q] = (uint32_t)((long)am * lda_b + dc * 16);
-        uint32_t mk = 0u;
-        const int at = am % p.Tlen;
-        for (int j = 0; j < p.taps; ++j)
-            if (am < p.M && (unsigned)(at + j - p.pad) < (unsigned)p.Tlen) mk |= 1u << j;
-        amask[q] = mk | ((uint32_t)dc << 8);      // bits 8..10: source chunk (for the K-tail test)
-    }
-#pragma unroll
-    for (int q = 0; q < 8; ++q) {
-        const int row = wave * 64 + q * 8 + rl;
-        const int dc = dp ^ ((row >> 1) & 7);
-        const int wn = n0 + row;
-        woffs[q] = wn < p.N ? (uint32_t)((long)wn * ldw_b + dc * 16) : OOB_OFF;
-    }
-    // all 12 ops of a lane use source chunks dp ^ s with s in 0..7; K-tail validity is per chunk:
-    // chunk c of the current step is valid iff ld_kcb + 16*c < K bytes
-    unsigned char* const dmaA = smem + wave * 4096;
-    unsigned char* const dmaW = smem + TILEA + wave * 8192;
-    int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;
-    {
-        const int kci0 = s_begin / p.taps;
-        ld_j = s_begin - kci0 * p.taps;
-        ld_kcb = kci0 * BK * ESZ;
-        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
-        ld_woff = ld_j * wts_b + ld_kcb;
-    }
-    const int kK_b = p.K * ESZ;
-#define SGV_W64_A(Q, STAGE)                                                                                   \
-    {                                                                                                         \
-        const bool ok_ = ((amask[Q] >> ld_j) & 1u) && ((ld_kcb + (int)((amask[Q] >> 8) & 7u) * 16) < kK_b);   \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + (Q) * 1024), 16,  \
-                                                 ok_ ? aoffs[Q] + (uint32_t)ld_aoff : OOB_OFF, 0, 0, 0);      \
-    }
-#define SGV_W64_W(Q, STAGE)                                                                                   \
-    {                                                                                                         \
-        const int dc_ = dp ^ ((((Q) * 8 + rl) >> 1) & 7);                                                     \
-        const bool ok_ = (ld_kcb + dc_ * 16) < kK_b;                                                          \
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (lds_void*)(dmaW + (STAGE) * STAGEB + (Q) * 1024), 16,  \
-                                                 ok_ ? woffs[Q] + (uint32_t)ld_woff : OOB_OFF, 0, 0, 0);      \
-    }
-#define SGV_W64_ISSUE(STAGE)                                                                                  \
-    {                                                                                                         \
-        SGV_W64_A(0, STAGE) SGV_W64_A(1, STAGE) SGV_W64_A(2, STAGE) SGV_W64_A(3, STAGE)                       \
-        SGV_W64_W(0, STAGE) SGV_W64_W(1, STAGE) SGV_W64_W(2, STAGE) SGV_W64_W(3, STAGE)                       \
-        SGV_W64_W(4, STAGE) SGV_W64_W(5, STAGE) SGV_W64_W(6, STAGE) SGV_W64_W(7, STAGE)                       \
-        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
-        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
-    }
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int lr = lane & 31, lh = lane >> 5;
-    const int swz = (lr >> 1) & 7;                 // rows a*32 + lr / wave*64 + b*32 + lr: bits 1..3 come from lr
-    const int a_frag_off = lr * 128;
-    const int w_frag_off = TILEA + (wave * 64 + lr) * 128;
-#define SGV_W64_COMPUTE(STAGE)                                                                                \
-    {                                                                                                         \
-        const unsigned char* sa_ = smem + (STAGE) * STAGEB + a_frag_off;                                      \
-        const unsigned char* sw_ = smem + (STAGE) * STAGEB + w_frag_off;                                      \
-        _Pragma("unroll") for (int ks = 0; ks < 4; ++ks) {                                                    \
-            const int po_ = ((ks * 2 + lh) ^ swz) * 16;                                                       \
-            const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + po_);                                   \
-            const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * 128 + po_);                        \
-            const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + po_);                                   \
-            const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * 128 + po_);                        \
-            const bf16x8 a2_ = *reinterpret_cast<const bf16x8*>(sa_ + 64 * 128 + po_);                        \
-            const bf16x8 a3_ = *reinterpret_cast<const bf16x8*>(sa_ + 96 * 128 + po_);                        \
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);                \
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);                \
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);                \
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);                \
-            acc[2][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b0_, acc[2][0], 0, 0, 0);                \
-            acc[2][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a2_, b1_, acc[2][1], 0, 0, 0);                \
-            acc[3][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b0_, acc[3][0], 0, 0, 0);                \
-            acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3_, b1_, acc[3][1], 0, 0, 0);                \
-        }                                                                                                     \
-    }
-#define SGV_W64_STEP(CUR, REFILL)                                                                             \
-    {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");                                        \
-        SGV_W64_ISSUE(REFILL);                                                                                \
-        asm volatile("" ::: "memory");                                                                        \
-        SGV_W64_COMPUTE(CUR);                                                                                 \
-    }
-#define SGV_W64_TAIL(CUR, WAIT)                                                                               \
-    {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(" #WAIT ")\n\ts_barrier" ::: "memory");                                 \
-        SGV_W64_COMPUTE(CUR);                                                                                 \
-    }
-    const int nst = s_end - s_begin;
-    if (nst > 0) {
-        SGV_W64_ISSUE(0);
-        if (nst > 1) SGV_W64_ISSUE(1);
-        int i = 0;
-        while (i + 5 <= nst) {
-            SGV_W64_STEP(0, 2)
-            SGV_W64_STEP(1, 0)
-            SGV_W64_STEP(2, 1)
-            i += 3;
-        }
-        const int rem = nst - i;
-        if (rem == 4) { SGV_W64_STEP(0, 2) SGV_W64_STEP(1, 0) SGV_W64_TAIL(2, 12) SGV_W64_TAIL(0, 0) }
-        else if (rem == 3) { SGV_W64_STEP(0, 2) SGV_W64_TAIL(1, 12) SGV_W64_TAIL(2, 0) }
-        else if (rem == 2) { SGV_W64_TAIL(0, 12) SGV_W64_TAIL(1, 0) }
-        else { SGV_W64_TAIL(0, 0) }
-    }
-#undef SGV_W64_A
-#undef SGV_W64_W
-#undef SGV_W64_ISSUE
-#undef SGV_W64_COMPUTE
-#undef SGV_W64_STEP
-#undef SGV_W64_TAIL
-
-    // ---- epilogue (as gemm_nt_wide_kernel) ----
-    const float sc = p.scale ? *p.scale : 1.0f;
-    const T* addp = reinterpret_cast<const T*>(p.addend);
-    if (p.splitk == 1 && !p.out_f32) {
-        constexpr int CP = 528;
-        __syncthreads();
-#pragma unroll
-        for (int a = 0; a < 4; ++a) {
-#pragma unroll
-            for (int b = 0; b < 2; ++b) {
-                const int lcol = wave * 64 + b * 32 + lr;
-                const int gcol = n0 + lcol;
-                const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int lrow = a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
-                }
-            }
-        }
-        __syncthreads();
-        bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
-#pragma unroll
-        for (int i = 0; i < 16; ++i) {
-            const int c = tid + i * 256;
-            const int lrow = c >> 5, lc8 = (c & 31) * 8;
-            const int grow = m0 + lrow, gcol = n0 + lc8;
-            if (grow < p.M && gcol < p.N) {
-                bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
-                if (addp) {
-                    const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
-                }
-                *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
-            }
-        }
-        return;
-    }
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = n0 + wave * 64 + b * 32 + lr;
-            const bool cok = col < p.N;
-            const int colc = cok ? col : 0;
-            const int rbase = m0 + a * 32 + 4 * lh;
-            if (p.splitk > 1) {
-                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < p.M) dst[(long)row * p.N] = acc[a][b][r];
-                }
-            } else {
-                const float bv = p.bias ? p.bias[colc] : 0.f;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int row = rbase + (r & 3) + 8 * (r >> 2);
-                    if (cok && row < p.M) {
-                        float v = acc[a][b][r] * sc + bv;
-                        if (addp) v += to_f32(addp[(long)row * p.ldadd + col]);
-                        reinterpret_cast<float*>(p.C)[(long)row * p.ldc + col] = v;
-                    }
-                }
-            }
-        }
-    }
-}
-
-// =========================================================================================
-// NT, LDS-DMA, 128 x 256 tile, K-step 64, SOFTWARE-PIPELINED ("wide64p", bf16 only).  Same tiles/ring as wide64, but
-// with one wave per SIMD every exposed LDS latency stalls the MFMA pipe, so fragments are double-buffered:
-//   L(k1) M(k0) | L(k2) M(k1) | L(k3) M(k2) | wait lgkm+vmcnt, barrier, refill THIS stage, L(k0 of next tile) | M(k3)
-// i.e. the reads of sub-step k+1 are issued before the MFMAs of k, and the stage hand-off sits in front of the last
-// MFMA group.  The refill targets the stage just read (all waves have retired their reads: lgkmcnt(0) + barrier).
-// wide64 itself: each stage holds
-// 64 K elements (128-byte rows; 3 stages x 48 KiB = 144 KiB of the 160 KiB LDS, one block per CU): 32 MFMAs per
-// wave per barrier, 12 DMA ops per wave per stage (vmcnt(12)), 96 KiB of operand bytes in flight per CU.
-// LDS slot p (16 B) of row r holds source chunk p ^ ((r>>1)&7): two 128-B rows share a 256-B bank row, so the 8
-// chunk slots x 2 row parities of a ds_read_b128 lane group are all distinct.
+// NT, LDS-DMA, 128(M) x 256(N) tile, K-step 64, SOFTWARE-PIPELINED ("wide64p", bf16 only).
+//   * operand tiles go global -> LDS directly (buffer_load_dwordx4 ... lds): no staging VGPRs, no ds_write.  An LDS-DMA
+//     wave-instruction writes M0-base + lane*16, i.e. 8 consecutive 128-byte rows; bank conflicts are avoided by an XOR
+//     swizzle applied on the SOURCE side: LDS slot p (16 B) of row r holds source chunk p ^ ((r>>1)&7) (two 128-B rows
+//     share a 256-B bank row, so the 8 chunk slots x 2 row parities of a ds_read_b128 lane group are all distinct).
+//   * masked taps / K tails / tile edges: the lane's buffer offset is pointed out of range and the hardware writes zeros
+//     into LDS (verified on MI355X: tests/micro/lds_dma_probe.hip).
+//   * 3 stages x 48 KiB = 144 KiB of the 160 KiB LDS, one block (4 waves, 128 fp32 accumulators each in AGPRs) per CU:
+//     32 MFMAs per wave per barrier, 12 DMA ops per wave per stage; each wave counts only its own DMA ops, so
+//     `s_waitcnt vmcnt(12)` = "my part of the next stage landed, the one after may still be in flight" (96 KiB of operand
+//     bytes in flight per CU); the barrier after it publishes all four waves' parts.
+//   * with one wave per SIMD every exposed LDS latency stalls the MFMA pipe, so fragments are double-buffered:
+//       L(k1) M(k0) | L(k2) M(k1) | L(k3) M(k2) | wait lgkm+vmcnt, barrier, refill THIS stage, L(k0 of next tile) | M(k3)
+//     i.e. the reads of sub-step k+1 are issued before the MFMAs of k, and the stage hand-off sits in front of the last
+//     MFMA group.  The refill targets the stage just read (all waves have retired their reads: lgkmcnt(0) + barrier).
+// History (profiles/r01_summary.md): 128x128 register-staged 520 TFLOP/s on 5120^2 k5 -> 128x128 LDS-DMA 620 -> 128x256
+// K-step 32 760 -> K-step 64 930 -> software-pipelined 1030.  The intermediate kernels were removed.
 // =========================================================================================
 __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p) {
     typedef bf16_t T;
@@ -1231,7 +521,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p)
 #undef SGV_W64_W
 #undef SGV_W64_ISSUE
 
-    // ---- epilogue (as gemm_nt_wide_kernel) ----
+    // ---- epilogue: bf16 tiles go through LDS for 16-byte coalesced stores; split-K / fp32 outputs store directly ----
     const float sc = p.scale ? *p.scale : 1.0f;
     const T* addp = reinterpret_cast<const T*>(p.addend);
     if (p.splitk == 1 && !p.out_f32) {
@@ -1862,26 +1152,14 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     q.a_bytes = ((long)(p.M - 1) * p.lda + p.K) * esz;
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
-    static const int use_dma = getenv("SGV_GEMM_DMA") ? atoi(getenv("SGV_GEMM_DMA")) : 0;   // 128x128 LDS-DMA variant: opt-in
-    static const int use_wide = getenv("SGV_GEMM_WIDE") ? atoi(getenv("SGV_GEMM_WIDE")) : 1;
     const long total_steps = (long)p.taps * cdiv(p.K, dtype == 1 ? 32 : 16);
-    if (use_wide && gemm_nt_is_wide(dtype, p.N, total_steps)) {
+    if (gemm_nt_is_wide(dtype, p.N, total_steps)) {
         dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 256) * p.splitk);
-        static const int use_w64 = getenv("SGV_GEMM_W64") ? atoi(getenv("SGV_GEMM_W64")) : 1;
-        static const int use_w64p = getenv("SGV_GEMM_W64P") ? atoi(getenv("SGV_GEMM_W64P")) : 1;
-        if (dtype == 1 && use_w64 && use_w64p) hipLaunchKernelGGL(gemm_nt_wide64p_kernel, grid, dim3(256), 0, s, q);
-        else if (dtype == 1 && use_w64) hipLaunchKernelGGL(gemm_nt_wide64_kernel, grid, dim3(256), 0, s, q);
-        else if (dtype == 1) hipLaunchKernelGGL((gemm_nt_wide_kernel<bf16_t>), grid, dim3(256), 0, s, q);
-        else hipLaunchKernelGGL((gemm_nt_wide_kernel<float>), grid, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gemm_nt_wide64p_kernel, grid, dim3(256), 0, s, q);
     } else {
         dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk);
-        if (use_dma) {
-            if (dtype == 1) hipLaunchKernelGGL((gemm_nt_dma_kernel<bf16_t>), grid, dim3(256), 0, s, q);
-            else hipLaunchKernelGGL((gemm_nt_dma_kernel<float>), grid, dim3(256), 0, s, q);
-        } else {
-            if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
-            else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
-        }
+        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
     }
     if (main_done) hipEventRecord(main_done, s);
     if (p.splitk > 1) {
