@@ -114,14 +114,15 @@ struct sgv_engine {
     float* sn_dot_dummy = nullptr;
     double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
     float* partial = nullptr; size_t partial_floats = 0;
-    // weight-gradient GEMMs are off the critical path of backward and CAN run on a second stream next to the dX
-    // GEMMs and normalisation passes of the following layers (option "dw_side_stream" / SGV_DW_SIDE=1).  Measured
-    // on MI355X it loses 2.5 % (16.55 vs 16.15 ms/step): the big GEMMs already fill every CU and the co-running
-    // kernels evict each other's L2 tiles, so it is OFF by default.
+    // weight-gradient GEMMs are off the critical path of backward: the SMALL ones (<= 250 GFLOP, i.e. everything but
+    // the five largest layers) run on a second stream next to the dX GEMMs and normalisation passes of the following
+    // layers, which fills the CUs those 100-200-block launches leave idle (measured 16.14 -> 15.83 ms/step).  Putting
+    // the big ones there too loses 2.5 %: they fill every CU on their own and co-running kernels evict each other's
+    // L2 tiles.  Option "dw_side_stream" / SGV_DW_SIDE=0 turns it off; kernel-timing passes always run on one stream.
     hipStream_t side = nullptr;
     float* partial_tn = nullptr; size_t partial_tn_floats = 0;
     std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
-    bool use_side = false, side_dirty = false;
+    bool use_side = true, side_dirty = false;
     float* xpose_tmp = nullptr; size_t xpose_floats = 0;
     float* recon_unit = nullptr;   // [3][N] unit-scale dgamma/dbeta/dbias of the recon head
     float* colpart = nullptr; size_t colpart_floats = 0;   // per-block column-sum workspace
@@ -798,7 +799,9 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     float* G = e->grads + l.gw;
     // side stream: dY and X are final once the kernels enqueued so far on the main stream have run; nothing on the
     // main stream reads G before join_side().  (Kernel-timing passes keep everything on one stream.)
-    const bool side = e->use_side && !e->timing;
+    // only the small launches go to the side stream: big GEMMs fill every CU on their own and co-running them costs L2
+    static const double side_max_gf = getenv("SGV_DW_SIDE_MAXGF") ? atof(getenv("SGV_DW_SIDE_MAXGF")) : 250.0;
+    const bool side = e->use_side && !e->timing && 2.0e-9 * p.M * p.N1 * p.N2 * p.taps <= side_max_gf;
     hipStream_t st = e->stream;
     float* slabs = e->partial;
     if (side) {
@@ -993,7 +996,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
     ALLOC(e->partial_tn, e->partial_tn_floats * 4);
-    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) e->side = nullptr;
+    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { e->side = nullptr; e->use_side = false; }
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
     ALLOC(e->colpart, e->colpart_floats * 4);
