@@ -169,11 +169,11 @@ def main():
                 lam.append(1.0)
         eng.augment_collate(data, idx, seeds, scale, mix, lam)
         eng.forward(train=True, sync=False)
-        eng.backward(ALPHA, epochs_beta)
         if ddp:
+            eng.backward(ALPHA, epochs_beta)
             allreduce.step(eng, LR)
         else:
-            eng.adamw_step(LR)
+            eng.backward_step(ALPHA, epochs_beta, LR)     # backward + AdamW, optimizer overlapped under backward
 
     for i in range(args.warmup):
         one_step(i)

@@ -125,6 +125,12 @@ int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t coun
 
 /* loss = alpha*recon + beta*sum(kl); loss.backward() (train.py:144-153). */
 int sgv_backward(sgv_engine* e, float alpha, float beta);
+/* sgv_backward followed by sgv_adamw_step(lr) (train.py:153-168 without the logging in between), single-GPU path:
+ * the AdamW pass of each conv-weight bucket is started on a second stream as soon as that bucket's gradients are
+ * final and runs under the remaining backward kernels (HBM-bound optimizer next to MFMA-bound GEMMs).  Same
+ * results as the two separate calls; gradients stay readable (sgv_export_grad) afterwards.  Not valid while a
+ * bucket callback is registered. */
+int sgv_backward_step(sgv_engine* e, float alpha, float beta, float lr);
 /* Callback invoked from inside sgv_backward (host side, after the kernels producing a gradient
  * bucket have been enqueued) so the caller can overlap its all-reduce of
  * [sgv_grad_buffer + offset, +count) with the rest of backward.  Weight buckets arrive in

@@ -1439,18 +1439,36 @@ int sgv_scale_grads(sgv_engine* e, float factor) {
     return SGV_OK;
 }
 
-int sgv_backward(sgv_engine* e, float alpha, float beta) {
+static int adamw_begin(sgv_engine* e);
+static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int which, hipStream_t st);
+int sgv_adamw_step(sgv_engine* e, float lr);
+// fuse_lr >= 0: also run the optimizer, and start the AdamW of every conv-weight bucket on the side stream as soon as
+// that bucket's gradients are final, under the rest of backward (single-GPU path: no bucket callback registered)
+static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
     if (!e->have_fwd || !e->fwd_train) return fail(SGV_ERR_STATE, "sgv_backward needs a preceding sgv_forward(train=1)");
+    const bool fuse = fuse_lr >= 0.f;
+    static const int early_on = getenv("SGV_EARLY_ADAM") ? atoi(getenv("SGV_EARLY_ADAM")) : 1;
+    const bool early = early_on && fuse && !e->cb && e->side && e->use_side && !e->timing;
+    if (early) CHK(adamw_begin(e));
     const int B = e->batch, n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
     const float coefB = beta / (float)B;
     int bucket = 0;
     e->ev_next = 0;
+    int early_err = 0;
     auto fire_at = [&](int b) {
-        if (e->cb && b >= 0 && b < (int)e->buckets.size()) {
+        if (b < 0 || b >= (int)e->buckets.size()) return;
+        if (e->cb) {
             join_side(e);     // the bucket's weight gradients come from the side stream
             e->cb(e->cb_user, b, e->buckets[b].first, e->buckets[b].second);
+        } else if (early && b < (int)e->buckets.size() - 2) {
+            // the bucket's weight gradients (and the <G,W> slots of its conv layers) are final once everything enqueued
+            // so far has run: AdamW of its conv weights goes to the side stream, under the remaining backward
+            hipEvent_t ev = next_event(e);
+            if (!ev || hipEventRecord(ev, e->stream) != hipSuccess || hipStreamWaitEvent(e->side, ev, 0) != hipSuccess) { early_err = 1; return; }
+            if (adamw_range(e, fuse_lr, b, b + 1, 1, e->side)) early_err = 1;
+            e->side_dirty = true;
         }
     };
     auto fire = [&]() { fire_at(bucket); ++bucket; };
@@ -1542,8 +1560,31 @@ int sgv_backward(sgv_engine* e, float alpha, float beta) {
         }
     }
     fire();   // first encoder block's weights
+    if (early_err) return fail(SGV_ERR_HIP, "early AdamW launch failed");
+    if (fuse) {
+        const int nbk = (int)e->buckets.size();
+        if (early) {
+            CHK(join_side(e));                                            // side-stream dW GEMMs of the last bucket
+            CHK(adamw_range(e, fuse_lr, nbk - 2, nbk - 1, 1, e->stream)); // first encoder block's conv weights
+            CHK(adamw_range(e, fuse_lr, 0, nbk, 2, e->stream));           // every flat item
+            e->side_dirty = true;                                          // AdamW launches may still run on the side stream
+            CHK(join_side(e));
+            e->copies_fresh = true;
+            e->wtu_fresh = true;
+        } else {
+            CHK(join_side(e));
+            if (!e->cb) CHK(sgv_adamw_step(e, fuse_lr));
+        }
+        return SGV_OK;
+    }
     CHK(join_side(e));
     return SGV_OK;
+}
+int sgv_backward(sgv_engine* e, float alpha, float beta) { return backward_impl(e, alpha, beta, -1.f); }
+int sgv_backward_step(sgv_engine* e, float alpha, float beta, float lr) {
+    if (lr < 0.f) return fail(SGV_ERR_ARG, "negative learning rate");
+    if (e && e->cb) return fail(SGV_ERR_STATE, "sgv_backward_step is the single-GPU path: with a bucket callback use sgv_backward + sgv_adamw_step_range");
+    return backward_impl(e, alpha, beta, lr);
 }
 
 int sgv_grad_norm(sgv_engine* e, double* out) {
@@ -1557,28 +1598,35 @@ int sgv_grad_norm(sgv_engine* e, double* out) {
     return SGV_OK;
 }
 
-int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last) {
-    if (!e) return fail(SGV_ERR_ARG, "null engine");
-    const int nbk = (int)e->buckets.size();
-    if (bucket_lo < 0 || bucket_hi > nbk || bucket_lo > bucket_hi) return fail(SGV_ERR_ARG, "bucket range [%d,%d) outside [0,%d)", bucket_lo, bucket_hi, nbk);
+// which: 1 = conv-weight tiles, 2 = flat items (biases, GroupNorm affine, Linear heads), 3 = both
+static int adamw_begin(sgv_engine* e) {
+    e->step += 1;
+    HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
+    if (e->n_sn_tmp_fused) HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp_fused * 4, e->stream));
+    e->copies_fresh = false;
+    e->wtu_fresh = false;
+    return 0;
+}
+static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int which, hipStream_t st) {
     const double b1 = 0.9, b2 = 0.999;
-    if (first) {
-        e->step += 1;
-        HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
-        if (e->n_sn_tmp_fused) HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp_fused * 4, e->stream));
-        e->copies_fresh = false;
-        e->wtu_fresh = false;
-    }
-    if (e->step < 1) return fail(SGV_ERR_STATE, "sgv_adamw_step_range: the first call of a step must pass first=1");
     const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
     const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
     // biases, GroupNorm affine and the Linear heads: flat pass.  Conv weights: tiled pass that also writes both
     // compute copies and W_new^T u for the next forward's power iteration.
     const int f0 = e->flat_off[bucket_lo], f1 = e->flat_off[bucket_hi], t0 = e->tile_off[bucket_lo], t1 = e->tile_off[bucket_hi];
-    if (opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+    if ((which & 2) && opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, st))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, e->stream))
+    if ((which & 1) && opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, st))
         return fail(SGV_ERR_HIP, "adamw launch failed");
+    return 0;
+}
+int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    const int nbk = (int)e->buckets.size();
+    if (bucket_lo < 0 || bucket_hi > nbk || bucket_lo > bucket_hi) return fail(SGV_ERR_ARG, "bucket range [%d,%d) outside [0,%d)", bucket_lo, bucket_hi, nbk);
+    if (first) CHK(adamw_begin(e));
+    if (e->step < 1) return fail(SGV_ERR_STATE, "sgv_adamw_step_range: the first call of a step must pass first=1");
+    CHK(adamw_range(e, lr, bucket_lo, bucket_hi, 3, e->stream));
     if (last) {
         e->copies_fresh = true;
         e->wtu_fresh = true;

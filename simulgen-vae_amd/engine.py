@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
-    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_last_grad_norm",
+    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_last_grad_norm", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
 ]
@@ -84,6 +84,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_scale_grads.argtypes = [vp, f32]
     lib.sgv_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
     lib.sgv_adamw_step.argtypes = [vp, f32]
+    lib.sgv_backward_step.argtypes = [vp, f32, f32, f32]
     lib.sgv_adamw_step_range.argtypes = [vp, f32, i32, i32, i32, i32]
     lib.sgv_bucket_count.argtypes = [vp]
     lib.sgv_last_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
@@ -266,6 +267,10 @@ class Engine:
 
     def backward(self, alpha: float, beta: float):
         _check(self.lib, self.lib.sgv_backward(self.h, float(alpha), float(beta)), "sgv_backward")
+
+    def backward_step(self, alpha: float, beta: float, lr: float):
+        """backward + AdamW with the optimizer of finished buckets overlapped under the rest of backward."""
+        _check(self.lib, self.lib.sgv_backward_step(self.h, float(alpha), float(beta), float(lr)), "sgv_backward_step")
 
     def grad_norm(self) -> float:
         d = C.c_double()

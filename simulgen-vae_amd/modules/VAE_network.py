@@ -147,8 +147,9 @@ class VAE:
         eng = self._eng(x.shape[0])
         eng.set_input(x)
         sc = eng.forward(train=True, sync=sync)
-        eng.backward(alpha, beta)
         if allreduce is not None:
-            allreduce(eng)
-        eng.adamw_step(lr)
+            eng.backward(alpha, beta)
+            allreduce.step(eng, lr)
+        else:
+            eng.backward_step(alpha, beta, lr)
         return sc

@@ -148,11 +148,11 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
             else:
                 eng.set_input(model._prep(item))
             sc = eng.forward(train=True)
-            eng.backward(alpha, beta)
             if allreduce is not None:
+                eng.backward(alpha, beta)
                 allreduce.step(eng, lr)
             else:
-                eng.adamw_step(lr)
+                eng.backward_step(alpha, beta, lr)
             grad_sum += eng.last_grad_norm()     # accumulated inside the AdamW pass (train.py:156-161 value)
             l, r, k = run_forward_losses(sc, beta)
             loss_save += l

@@ -243,3 +243,41 @@ def test_data_scaler_matches_reference_fixture(tmp_path, monkeypatch):
     eng = Engine(cfg, max_batch=2, compute_dtype="bf16")
     assert tl.resident(eng).data_ptr() == dev.buf.data_ptr()
     eng.close()
+
+
+def test_fused_backward_step_equals_separate_calls():
+    """sgv_backward_step (AdamW of finished buckets started on the side stream under the rest of backward) leaves the
+    state of sgv_backward + sgv_adamw_step; gradients stay exportable afterwards.  fp32 compute, compared in the mean
+    (float-atomic ordering differs between any two runs)."""
+    from simulgen_vae_amd.engine import Engine
+    from simulgen_vae_amd.init import init_state
+    from tests.gpu_common import G2
+    cfg = make_cfg(G2)
+    B = 2
+    x = torch.from_numpy(synthetic_samples(5, range(B), cfg.num_node, cfg.num_time)).cuda()
+    state = init_state(cfg, 11, reference_init=True)
+    outs = []
+    for mode in ("separate", "fused"):
+        eng = Engine(cfg, max_batch=B, compute_dtype="f32")
+        eng.load_state(state)
+        eng.seed(99)
+        norms = []
+        for step in range(3):
+            eng.set_input(x)
+            eng.forward(train=True)
+            if mode == "fused":
+                eng.backward_step(1e6, 1e-4, 1e-3)
+            else:
+                eng.backward(1e6, 1e-4)
+                eng.adamw_step(1e-3)
+            norms.append(eng.last_grad_norm())
+        g = eng.grad("decoder.decoder_residual_blocks.2.seq.3.weight_orig")
+        torch.cuda.synchronize()
+        outs.append((eng.state_dict(), norms, g))
+        eng.close()
+    (sa, na, ga), (sb, nb_, gb) = outs
+    np.testing.assert_allclose(na, nb_, rtol=1e-4)
+    assert relerr(gb, ga) < 1e-3
+    for k in sa:
+        a, b = sa[k].astype(np.float64), sb[k].astype(np.float64)
+        assert np.mean(np.abs(a - b)) <= 1e-4 * np.mean(np.abs(a)) + 1e-9, k
