@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSV output (kernel stats / kernel trace / PMC counter collection) of a bench.py run into the
 small per-step summaries committed under profiles/.
-  python tools/summarize_profile.py stats  <kernel_stats.csv> <steps_in_run | 0 = count AdamW launches>
+  python tools/summarize_profile.py stats  <kernel_stats.csv> <steps_in_run | 0 = count augment launches>
   python tools/summarize_profile.py pmc    <counter_collection.csv>      # FETCH_SIZE or WRITE_SIZE pass
   python tools/summarize_profile.py traffic <fetch.csv> <write.csv>      # JSON read by bench.py (roofline.traffic)
 Counter units: rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts wide coalesced
@@ -11,25 +11,31 @@ import csv
 import sys
 
 
+SETUP = ("transpose_kernelIf", "at::native", "make_copies_kernel")     # dataset generation / conversion, first weight copies
+
+
 def stats(path, steps):
     rows = list(csv.DictReader(open(path)))
-    if steps <= 0:   # every training step launches the fused AdamW kernel exactly once
-        steps = sum(int(r["Calls"]) for r in rows if "adamw_sn_kernel" in r["Name"])
+    if steps <= 0:   # every training step launches the augment+collate kernel exactly once
+        steps = sum(int(r["Calls"]) for r in rows if "augment_kernel" in r["Name"])
+    setup = [r for r in rows if any(k in r["Name"] for k in SETUP)]
+    rows = [r for r in rows if r not in setup]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
-    print(f"| kernel | launches/step | ms/step | avg us | % |\n|---|---|---|---|---|")
+    print(f"| kernel | launches/step | ms/step | avg us | % of step kernels |\n|---|---|---|---|---|")
     for r in rows[:28]:
         print(f"| `{r['Name'][:80]}` | {int(r['Calls']) / steps:.1f} | {float(r['TotalDurationNs']) / 1e6 / steps:.3f} | "
-              f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['Percentage']):.1f} |")
+              f"{float(r['AverageNs']) / 1e3:.1f} | {float(r['TotalDurationNs']) / tot * 100:.1f} |")
     print(f"\ntotal kernel time {tot / 1e6 / steps:.2f} ms/step over {sum(int(r['Calls']) for r in rows) / steps:.0f} launches/step "
-          f"(run of {steps} steps incl. warm-up and the kernel-timing pass)")
+          f"(run of {steps} steps incl. warm-up and the kernel-timing pass); one-off set-up kernels (synthetic dataset generation and "
+          f"layout conversion, first weight copies) excluded: {sum(float(r['TotalDurationNs']) for r in setup) / 1e6:.1f} ms in total")
 
 
 def pmc(path):
     rows = list(csv.DictReader(open(path)))
     name = rows[0]["Counter_Name"]
     corr = 2.0 if name == "FETCH_SIZE" else 1.0
-    idx = [i for i, x in enumerate(rows) if "adamw_sn_kernel" in x["Kernel_Name"]]
-    step = rows[idx[-2] + 1: idx[-1] + 1]
+    idx = [i for i, x in enumerate(rows) if "augment_kernel" in x["Kernel_Name"]]     # one per training step, first kernel of it
+    step = rows[idx[-2]: idx[-1]]
     agg, cnt, dur = collections.Counter(), collections.Counter(), collections.Counter()
     for x in step:
         k = x["Kernel_Name"].split("(")[0][:60]
@@ -44,8 +50,8 @@ def pmc(path):
 
 def step_rows(path):
     rows = list(csv.DictReader(open(path)))
-    idx = [i for i, x in enumerate(rows) if "adamw_sn_kernel" in x["Kernel_Name"]]
-    return rows[0]["Counter_Name"], rows[idx[-2] + 1: idx[-1] + 1]
+    idx = [i for i, x in enumerate(rows) if "augment_kernel" in x["Kernel_Name"]]
+    return rows[0]["Counter_Name"], rows[idx[-2]: idx[-1]]
 
 
 def traffic(fetch_csv, write_csv):

@@ -6,7 +6,7 @@ import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "augment_kernel" in r["Kernel_Name"]]
-lo, hi = marks[-3], marks[-2]
+lo, hi = marks[len(marks) // 2], marks[len(marks) // 2 + 1]     # a step from the middle of the timed region
 step = rows[lo:hi]
 t0 = int(step[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in step)
 print(f"step wall {(t1 - t0) / 1e6:.3f} ms, kernels {len(step)}, summed kernel time {sum(int(r['End_Timestamp']) - int(r['Start_Timestamp']) for r in step) / 1e6:.3f} ms")
