@@ -120,7 +120,8 @@ int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host
 /* Reconstruction of the last forward, reference layout [B, num_node, num_time] fp32 on device. */
 int sgv_get_xhat(sgv_engine* e, float* xhat_dev);
 /* Named intermediate of the last forward as fp32 reference layout on host (parity tests):
- * "enc_h<i>", "dec_out<i>", "zmap<i>", "mu", "log_var", "z", "xs<i>".  [sync] */
+ * "enc_h<i>", "dec_out<i>", "zmap<i>", "mu", "log_var", "z", "xs<i>", "x_hat"; "x_in" = the input batch as
+ * held by the engine after sgv_set_input / sgv_augment_collate (readable before any forward).  [sync] */
 int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t count);
 
 /* loss = alpha*recon + beta*sum(kl); loss.backward() (train.py:144-153). */

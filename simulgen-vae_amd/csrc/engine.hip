@@ -1393,9 +1393,14 @@ int sgv_get_xhat(sgv_engine* e, float* xhat_dev) {
 
 int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t count) {
     if (!e || !name || !host) return fail(SGV_ERR_ARG, "null argument");
-    if (!e->have_fwd) return fail(SGV_ERR_STATE, "no forward pass to read from");
     const int B = e->batch;
     std::string s(name);
+    if (s == "x_in") {     // the input batch as the engine holds it (after sgv_set_input / sgv_augment_collate)
+        if (B < 1) return fail(SGV_ERR_STATE, "no input batch");
+        if ((long)count != (long)B * e->T * e->N) return fail(SGV_ERR_ARG, "size mismatch for activation 'x_in'");
+        return export_act(e, e->x_in, B, host);
+    }
+    if (!e->have_fwd) return fail(SGV_ERR_STATE, "no forward pass to read from");
     auto chk = [&](long want) { return (long)count == want ? 0 : fail(SGV_ERR_ARG, "size mismatch for activation '%s': got %zu expected %ld", name, count, want); };
     auto idx = [&](const char* pre) { return atoi(s.c_str() + strlen(pre)); };
     HIPCHK(hipStreamSynchronize(e->stream));

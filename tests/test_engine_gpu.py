@@ -157,3 +157,72 @@ def test_philox_eps_statistics():
     assert np.isfinite(a["recon"]) and np.isfinite(b["recon"])
     assert np.abs(z1 - z2).max() > 1e-3
     eng.close()
+
+
+def test_augment_collate_matches_oracle():
+    """A13: the fused noise/scale/mixup + collate kernel on the HBM-resident dataset vs oracle.augment_sample
+    (augmentation.py:86-124).  Scale and mixup are exact arithmetic on the stored sample; the Gaussian noise comes from
+    the engine's own Philox stream (the reference uses torch.randn_like), so it is checked through its statistics,
+    its determinism per seed and its independence across seeds."""
+    import torch
+    cfg = make_cfg(G1)
+    P, B = 6, 5
+    x = synthetic_samples(31, range(P), cfg.num_node, cfg.num_time)
+    eng = E.Engine(cfg, max_batch=B, compute_dtype="f32")
+    eng.load_state(init_state(cfg, 3))
+    data = torch.empty(P * eng.sample_bytes(), dtype=torch.uint8, device="cuda")
+    eng.dataset_convert(torch.from_numpy(x).cuda(), data, P)
+    idx = [4, 0, 5, 2, 2]
+    seeds = [0, 0, 0, 12345, 777]
+    scale = [1.0, 0.93, 1.07, 1.0, 1.0]
+    mix = [-1, 3, 1, -1, -1]
+    lam = [1.0, 0.37, 0.9, 1.0, 1.0]
+    eng.augment_collate(data, idx, seeds, scale, mix, lam)
+    got = eng.activation("x_in", (B, cfg.num_node, cfg.num_time))
+    for b in range(3):       # no noise: exact up to one fp32 rounding per operation
+        dec = dict(noise=False, scale=None if scale[b] == 1.0 else np.float32(scale[b]), lam=None if mix[b] < 0 else lam[b])
+        want = vo.augment_sample(x[idx[b]], x[mix[b]] if mix[b] >= 0 else None, None, dec)
+        assert relerr(got[b], want) < 1e-6, b
+    for b in (3, 4):         # noise only: x + 0.05 * N(0, 1)
+        nz = (got[b] - x[idx[b]]) / 0.05
+        assert abs(nz.mean()) < 0.05 and abs(nz.std() - 1.0) < 0.05 and abs((nz ** 3).mean()) < 0.15
+    assert abs(np.corrcoef(((got[3] - x[2]) / 0.05).ravel(), ((got[4] - x[2]) / 0.05).ravel())[0, 1]) < 0.05
+    eng.augment_collate(data, idx, seeds, scale, mix, lam)
+    np.testing.assert_array_equal(eng.activation("x_in", (B, cfg.num_node, cfg.num_time)), got)   # same seeds, same noise
+    # ragged last batch: fewer samples than max_batch
+    eng.augment_collate(data, idx[:2], seeds[:2], scale[:2], mix[:2], lam[:2])
+    np.testing.assert_array_equal(eng.activation("x_in", (2, cfg.num_node, cfg.num_time)), got[:2])
+    eng.close()
+
+
+def test_api_error_behaviour():
+    """Status codes + sgv_last_error text instead of crashes: wrong call order, bad sizes, unknown names."""
+    import torch
+    cfg = make_cfg(G0)
+    eng = E.Engine(cfg, max_batch=2, compute_dtype="f32")
+    with pytest.raises(E.SgvError):
+        eng.backward(1.0, 1.0)                         # no forward yet
+    eng.load_state(init_state(cfg, 3))
+    with pytest.raises(E.SgvError):
+        eng.set_input(torch.zeros((3, cfg.num_node, cfg.num_time), device="cuda"))    # batch > max_batch
+    with pytest.raises(E.SgvError):
+        eng.activation("enc_h0", (2, cfg.num_filter_enc[0], cfg.num_time))            # nothing computed yet
+    x = torch.from_numpy(synthetic_samples(1, range(1), cfg.num_node, cfg.num_time)).cuda()
+    eng.set_input(x)                                    # batch 1 of max 2
+    sc = eng.forward(train=False)
+    assert np.isfinite(sc["recon"])
+    with pytest.raises(E.SgvError):
+        eng.backward(1.0, 1.0)                         # eval forward is not differentiable state
+    with pytest.raises(E.SgvError):
+        eng.activation("no_such_map", (1,))
+    with pytest.raises(E.SgvError):
+        eng.activation("enc_h0", (1, 3))               # wrong element count
+    bad = init_state(cfg, 3)
+    k = next(iter(bad))
+    bad[k] = np.zeros((1,), np.float32)
+    with pytest.raises(E.SgvError):
+        eng.load_state(bad)
+    eng.forward(train=True)
+    eng.backward(1.0, 1.0)
+    assert eng.grad("encoder.xs_linear.0.weight_orig") is None       # dead parameter: grad=None as in the reference
+    eng.close()
