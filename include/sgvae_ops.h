@@ -1,0 +1,84 @@
+/* libsgvae.so -- operator-level C ABI for the image latent conditioner.
+ *
+ * The reference model (modules/latent_conditioner_model_cnn.py:28-362) is a ResNet-style CNN followed by two small
+ * MLP heads; its training loop is modules/latent_conditioner.py:213-386.  The MI355X build keeps the layer graph and
+ * the hand-derived backward on the host (simulgen-vae_amd/modules/latent_conditioner_model_cnn.py) and runs every
+ * tensor operation through the stateless entry points below.  Conventions: all pointers are device pointers owned by
+ * the caller; feature maps are channels-last [B][H][W][C] in the compute dtype (SGV_DTYPE_F32 = 0, SGV_DTYPE_BF16 = 1),
+ * P = H*W; tensors of shape [B][features] and every parameter / gradient are fp32; work is enqueued on `stream`
+ * (a hipStream_t, NULL = default stream) with no host synchronisation; return 0 on success, else a negative
+ * SGV_ERR_* code with the text in sgv_last_error().  There is no CPU fallback. */
+#ifndef SGVAE_OPS_H
+#define SGVAE_OPS_H
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* nn.Conv2d (latent_conditioner_model_cnn.py:93,97,103,186): lowered to im2col + GEMM.
+ * col[(b,oh,ow)][(kh*KW+kw)*C + c], rows zero-padded to Kp = roundup(KH*KW*C, 8); weights are expected as
+ * [Cout][KH][KW][Cin] rows padded the same way.  forward: im2col, gemm_nt; weight gradient: gemm_tn(dY, col);
+ * input gradient: gemm_nt(dY, W^T) then col2im (gather, deterministic).  A 1x1 stride-1 convolution needs no im2col. */
+int sgv_op_conv_out_shape(int H, int W, int C, int KH, int KW, int stride, int pad, int* Ho, int* Wo, int* Kp);
+int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream);
+int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream);
+/* C[M][N] = scale[0] * A[M][K] . W[N][K]^T (+ bias[N]) (+ addend[M][N]) on the MFMA kernels of the VAE path
+ * (K, N multiples of 8; scale/bias/addend may be NULL; out_f32 = 1 writes fp32 instead of the compute dtype). */
+int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend,
+                   int M, int N, int K, int out_f32, void* stream);
+/* dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]  (N1, N2 multiples of 8). */
+int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, void* stream);
+
+/* nn.GroupNorm + optional ReLU (model_cnn.py:94,98,104,187-188; act: 0 none, 3 relu) on [B][P][C], C % 8 == 0,
+ * G <= 32.  sums: B*G*2 doubles written by the forward and read by the backward; sums2: same size scratch;
+ * part: sgv_op_gn_workspace_floats() floats scratch; dgamma/dbeta are ACCUMULATED into (+=). */
+int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
+                  double* sums, void* stream);
+size_t sgv_op_gn_workspace_floats(int B, int P, int C);
+int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
+                  const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream);
+
+/* nn.MaxPool2d(3, 2, 1) (model_cnn.py:189); backward recomputes the first arg-max of each window. */
+int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
+int sgv_op_maxpool_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+/* out = relu(a + b) (model_cnn.py:131-132) and d = dout * (out > 0); plain add for gradient joins. */
+int sgv_op_add_relu_fwd(int dtype, const void* a, const void* b, void* out, long n, void* stream);
+int sgv_op_relu_bwd(int dtype, const void* out, const void* dout, void* d, long n, void* stream);
+int sgv_op_add(int dtype, const void* a, const void* b, void* out, long n, void* stream);
+/* AdaptiveAvgPool2d(1) (model_cnn.py:40,48,214): y[b][c] = mean_p x; backward dx (+)= dy / P. */
+int sgv_op_avgpool_fwd(int dtype, const void* x, float* y, int B, int P, int C, void* stream);
+int sgv_op_avgpool_bwd(int dtype, const float* dy, void* dx, int B, int P, int C, int accumulate, void* stream);
+/* SqueezeExcitation scaling x * y.view(b,c,1,1) (model_cnn.py:51): out = x * s[b][c]; backward dx = dout*s,
+ * ds[b][c] = sum_p dout*x. */
+int sgv_op_chan_scale_fwd(int dtype, const void* x, const float* s, void* out, int B, int P, int C, void* stream);
+int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* dout, void* dx, float* ds, int B, int P, int C, void* stream);
+
+/* Small fp32 layers of the SE blocks and heads (model_cnn.py:41-50,220-277).
+ * linear: y = act(scale[0] * x W^T + bias), act: 0 none, 1 relu, 2 sigmoid; act_bwd: dz = dy * act'(y) from the stored
+ * output; linear_bwd: dx (= or +=) scale * dz W, dW = scale * dz^T x, db = sum_b dz (dx, db may be NULL). */
+int sgv_op_linear_fwd(const float* x, const float* W, const float* bias, const float* scale, float* y, int B, int K, int O, int act, void* stream);
+int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, void* stream);
+int sgv_op_linear_bwd(const float* dz, const float* x, const float* W, const float* scale, float* dx, int accumulate_dx, float* dW, float* db,
+                      int B, int K, int O, void* stream);
+/* nn.LayerNorm(K) (eps 1e-5); stat: 2*B floats (mean, rstd) written by the forward. */
+int sgv_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, int B, int K, void* stream);
+int sgv_op_layernorm_bwd(const float* x, const float* gamma, const float* stat, const float* dy, float* dx, float* dgamma, float* dbeta,
+                         int B, int K, void* stream);
+/* nn.BatchNorm1d(K) (eps 1e-5, momentum 0.1): train = batch statistics + running-buffer update, eval = running
+ * statistics; stat: 2*K floats (mean, rstd used). */
+int sgv_op_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y, float* stat,
+                         int B, int K, int train, void* stream);
+int sgv_op_batchnorm_bwd(const float* x, const float* gamma, const float* stat, const float* dy, float* dx, float* dgamma, float* dbeta,
+                         int B, int K, int train, void* stream);
+/* out = a * mask * scale (nn.Dropout with an injected 0/1 mask and scale 1/(1-p); mask NULL = all ones), fp32 add,
+ * and nn.MSELoss: loss_dev[0] = mean((pred-target)^2) (double), dpred = gscale * dloss/dpred (may be NULL). */
+int sgv_op_mask_scale(const float* a, const float* mask, float scale, float* out, long n, void* stream);
+int sgv_op_addf(const float* a, const float* b, float* out, long n, void* stream);
+int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* dpred, float gscale, long n, void* stream);
+/* [Bn][I][J] -> [Bn][J][I] with dtype conversion (reference NCHW fp32 <-> channels-last compute dtype). */
+int sgv_op_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,538 @@
+// Operator-level C ABI for the image latent conditioner (reference
+// modules/latent_conditioner_model_cnn.py:28-362): 2-D convolutions as im2col + the MFMA GEMMs of gemm.hip,
+// GroupNorm(+ReLU) through the kernels of ew.hip, max-pool, squeeze-excitation, residual add+ReLU and the small
+// fp32 layers of the prediction heads (Linear, LayerNorm, BatchNorm1d, dropout with an injected mask, MSE).
+// Feature maps are channels-last [B][H][W][C] (= [B*H*W][C] rows, compute dtype bf16 or fp32), so a 1x1 convolution
+// is a plain GEMM and GroupNorm sees the same [rows][C] layout as in the VAE; everything [B][features] is fp32.
+// Stateless entry points on caller-owned device buffers; the host-side mirror
+// (simulgen-vae_amd/modules/latent_conditioner_model_cnn.py) holds the layer graph and its hand-written backward.
+#include "../../include/sgvae_ops.h"
+#include "sgv_ew.h"
+
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+int sgv_set_error(int code, const char* fmt, ...);   // engine.hip: fills sgv_last_error()
+
+static inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
+#define OPCHK(cond, ...) do { if (!(cond)) return sgv_set_error(-1, __VA_ARGS__); } while (0)
+#define OPLAUNCH_OK() (hipGetLastError() == hipSuccess ? 0 : sgv_set_error(-2, "kernel launch failed in %s", __func__))
+
+// ------------------------------------------------------------------------------------------------------------
+// im2col / col2im: col[(b,oh,ow)][(kh*KW + kw)*C + c] = x[b][oh*s - p + kh][ow*s - p + kw][c] (0 outside), rows padded
+// with zeros to Kp (multiple of 8) elements
+// ------------------------------------------------------------------------------------------------------------
+struct ConvGeom { int B, H, W, C, KH, KW, S, P, Ho, Wo, Kp; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeom g) {
+    const long total = (long)g.B * g.Ho * g.Wo * g.Kp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % g.Kp);
+        const long m = i / g.Kp;
+        T v = from_f32<T>(0.f);
+        if (k < g.KH * g.KW * g.C) {
+            const int c = k % g.C, t = k / g.C, kw = t % g.KW, kh = t / g.KW;
+            const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+            const int h = oh * g.S - g.P + kh, w = ow * g.S - g.P + kw;
+            if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) v = x[(((long)b * g.H + h) * g.W + w) * g.C + c];
+        }
+        col[i] = v;
+    }
+}
+// dx[b][h][w][c] = sum over the windows that cover (h,w) of dcol (gather form: no atomics, deterministic)
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, T* dx, ConvGeom g) {
+    const long total = (long)g.B * g.H * g.W * g.C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        const long pix = i / g.C;
+        const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
+        float acc = 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int hn = h + g.P - kh;
+            if (hn < 0 || hn % g.S) continue;
+            const int oh = hn / g.S;
+            if (oh >= g.Ho) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int wn = w + g.P - kw;
+                if (wn < 0 || wn % g.S) continue;
+                const int ow = wn / g.S;
+                if (ow >= g.Wo) continue;
+                acc += to_f32(dcol[(((long)b * g.Ho + oh) * g.Wo + ow) * g.Kp + (kh * g.KW + kw) * g.C + c]);
+            }
+        }
+        dx[i] = from_f32<T>(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// MaxPool2d(3, 2, 1): forward keeps nothing; backward recomputes each window's first arg-max (PyTorch tie rule:
+// first maximum in row-major window order) and gathers
+// ------------------------------------------------------------------------------------------------------------
+template <typename T>
+__device__ __forceinline__ void pool_argmax(const T* x, const ConvGeom& g, int b, int oh, int ow, int c, float& best, int& bh, int& bw) {
+    best = -INFINITY; bh = -1; bw = -1;
+    for (int kh = 0; kh < 3; ++kh) {
+        const int h = oh * 2 - 1 + kh;
+        if ((unsigned)h >= (unsigned)g.H) continue;
+        for (int kw = 0; kw < 3; ++kw) {
+            const int w = ow * 2 - 1 + kw;
+            if ((unsigned)w >= (unsigned)g.W) continue;
+            const float v = to_f32(x[(((long)b * g.H + h) * g.W + w) * g.C + c]);
+            if (v > best || bh < 0) { best = v; bh = h; bw = w; }
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, ConvGeom g) {
+    const long total = (long)g.B * g.Ho * g.Wo * g.C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        const long m = i / g.C;
+        const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+        float best; int bh, bw;
+        pool_argmax(x, g, b, oh, ow, c, best, bh, bw);
+        y[i] = from_f32<T>(best);
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, ConvGeom g) {
+    const long total = (long)g.B * g.H * g.W * g.C;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % g.C);
+        const long pix = i / g.C;
+        const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
+        float acc = 0.f;
+        // windows (oh, ow) with oh*2-1 <= h <= oh*2+1
+        for (int oh = (h + 1) / 2 - ((h + 1) % 2 == 0 ? 1 : 0); oh <= (h + 1) / 2; ++oh) {
+            if (oh < 0 || oh >= g.Ho) continue;
+            for (int ow = (w + 1) / 2 - ((w + 1) % 2 == 0 ? 1 : 0); ow <= (w + 1) / 2; ++ow) {
+                if (ow < 0 || ow >= g.Wo) continue;
+                float best; int bh, bw;
+                pool_argmax(x, g, b, oh, ow, c, best, bh, bw);
+                if (bh == h && bw == w) acc += to_f32(dy[(((long)b * g.Ho + oh) * g.Wo + ow) * g.C + c]);
+            }
+        }
+        dx[i] = from_f32<T>(acc);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// elementwise / per-channel helpers on [B][P][C] maps (P = H*W)
+// ------------------------------------------------------------------------------------------------------------
+// out = relu(a + b) ; backward: d = dout * (out > 0)
+template <typename T>
+__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* a, const T* b, T* out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = from_f32<T>(fmaxf(to_f32(a[i]) + to_f32(b[i]), 0.f));
+}
+template <typename T>
+__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* out, const T* dout, T* d, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        d[i] = to_f32(out[i]) > 0.f ? dout[i] : from_f32<T>(0.f);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+        out[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+}
+// y[b][c] = mean_p x[b][p][c]   (grid: (C/64, B), block 256 = 64 channels x 4 row lanes)
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, float* y, int P, int C) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+    float a = 0.f;
+    if (c < C) for (int p = rl; p < P; p += 4) a += to_f32(x[((long)b * P + p) * C + c]);
+    __shared__ float sm[4][64];
+    sm[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) y[(long)b * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)P;
+}
+// dx[b][p][c] (+)= dy[b][c] / P
+template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* dy, T* dx, int P, int C, long n, int accumulate) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((long)P * C));
+        const float v = dy[(long)b * C + c] / (float)P;
+        dx[i] = from_f32<T>(accumulate ? to_f32(dx[i]) + v : v);
+    }
+}
+// out[b][p][c] = x[b][p][c] * s[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scale_fwd_kernel(const T* x, const float* s, T* out, int P, int C, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % C);
+        const int b = (int)(i / ((long)P * C));
+        out[i] = from_f32<T>(to_f32(x[i]) * s[(long)b * C + c]);
+    }
+}
+// dx = dout * s ; ds[b][c] = sum_p dout * x
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* x, const float* s, const T* dout, T* dx, float* ds, int P, int C) {
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+    float a = 0.f;
+    if (c < C) {
+        const float sv = s[(long)b * C + c];
+        for (int p = rl; p < P; p += 4) {
+            const long i = ((long)b * P + p) * C + c;
+            const float d = to_f32(dout[i]);
+            a += d * to_f32(x[i]);
+            dx[i] = from_f32<T>(d * sv);
+        }
+    }
+    __shared__ float sm[4][64];
+    sm[rl][threadIdx.x & 63] = a;
+    __syncthreads();
+    if (rl == 0 && c < C) ds[(long)b * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// small fp32 layers on [B][K] (B <= a few hundred): one wave per output element / row
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float small_act(int act, float z) {
+    return act == 1 ? fmaxf(z, 0.f) : (act == 2 ? 1.f / (1.f + __expf(-z)) : z);
+}
+// y[b][o] = act(scale * sum_k x[b][k] W[o][k] + bias[o]); grid (O, B), one wave
+__global__ __launch_bounds__(64) void linear_fwd_kernel(const float* x, const float* W, const float* bias, const float* scale, float* y,
+                                                       int K, int O, int act) {
+    const int o = blockIdx.x, b = blockIdx.y;
+    float a = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) a += x[(long)b * K + k] * W[(long)o * K + k];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) y[(long)b * O + o] = small_act(act, a * (scale ? *scale : 1.f) + (bias ? bias[o] : 0.f));
+}
+// dz = dy * act'(y) (from the stored output y), in place capable
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const float* dy, float* dz, long n, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float v = y[i];
+        dz[i] = dy[i] * (act == 1 ? (v > 0.f ? 1.f : 0.f) : (act == 2 ? v * (1.f - v) : 1.f));
+    }
+}
+// dx[b][k] = scale * sum_o dz[b][o] W[o][k]; grid (ceil(K/256), B)
+__global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* dz, const float* W, const float* scale, float* dx, int K, int O,
+                                                           int accumulate) {
+    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (k >= K) return;
+    float a = 0.f;
+    for (int o = 0; o < O; ++o) a += dz[(long)b * O + o] * W[(long)o * K + k];
+    a *= scale ? *scale : 1.f;
+    dx[(long)b * K + k] = accumulate ? dx[(long)b * K + k] + a : a;
+}
+// dW[o][k] = scale * sum_b dz[b][o] x[b][k]; db[o] = sum_b dz[b][o]; grid (ceil(K/256), O)
+__global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* dz, const float* x, const float* scale, float* dW, float* db,
+                                                           int B, int K, int O) {
+    const int k = blockIdx.x * 256 + threadIdx.x, o = blockIdx.y;
+    if (k < K) {
+        float a = 0.f;
+        for (int b = 0; b < B; ++b) a += dz[(long)b * O + o] * x[(long)b * K + k];
+        dW[(long)o * K + k] = a * (scale ? *scale : 1.f);
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += dz[(long)b * O + o];
+        db[o] = s;
+    }
+}
+// LayerNorm over the K features of each row (eps 1e-5, biased variance); one wave per row; stores mean/rstd
+__global__ __launch_bounds__(64) void layernorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* y, float* stat, int K) {
+    const int b = blockIdx.x;
+    float s = 0.f, ss = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) { const float v = x[(long)b * K + k]; s += v; ss += v * v; }
+    s = __shfl(wave_sum(s), 0, 64); ss = __shfl(wave_sum(ss), 0, 64);      // wave_sum leaves the total in lane 0
+    const float mean = s / K;
+    const float var = fmaxf(ss / K - mean * mean, 0.f);
+    const float rstd = rsqrtf(var + 1e-5f);
+    for (int k = threadIdx.x; k < K; k += 64) y[(long)b * K + k] = (x[(long)b * K + k] - mean) * rstd * gamma[k] + beta[k];
+    if (threadIdx.x == 0) { stat[2 * b] = mean; stat[2 * b + 1] = rstd; }
+}
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dgamma/dbeta via per-row atomics
+__global__ __launch_bounds__(64) void layernorm_bwd_kernel(const float* x, const float* gamma, const float* stat, const float* dy, float* dx,
+                                                          float* dgamma, float* dbeta, int K) {
+    const int b = blockIdx.x;
+    const float mean = stat[2 * b], rstd = stat[2 * b + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        const float xh = (x[(long)b * K + k] - mean) * rstd, g = gamma[k] * dy[(long)b * K + k];
+        s1 += g; s2 += g * xh;
+    }
+    s1 = __shfl(wave_sum(s1), 0, 64) / K; s2 = __shfl(wave_sum(s2), 0, 64) / K;
+    for (int k = threadIdx.x; k < K; k += 64) {
+        const float xh = (x[(long)b * K + k] - mean) * rstd, d = dy[(long)b * K + k];
+        dx[(long)b * K + k] = rstd * (gamma[k] * d - s1 - xh * s2);
+        atomicAdd(dgamma + k, d * xh);
+        atomicAdd(dbeta + k, d);
+    }
+}
+// BatchNorm1d over the batch dimension; train: batch statistics (biased variance for normalisation, unbiased for the
+// running buffer, momentum 0.1) ; eval: running statistics.  One thread per feature.  stat[2k], stat[2k+1] = mean, rstd used.
+__global__ __launch_bounds__(256) void batchnorm_fwd_kernel(const float* x, const float* gamma, const float* beta, float* run_mean,
+                                                           float* run_var, float* y, float* stat, int B, int K, int train) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    float mean, var;
+    if (train) {
+        float s = 0.f;
+        for (int b = 0; b < B; ++b) s += x[(long)b * K + k];
+        mean = s / B;
+        float v = 0.f;
+        for (int b = 0; b < B; ++b) { const float d = x[(long)b * K + k] - mean; v += d * d; }
+        var = v / B;
+        run_mean[k] = 0.9f * run_mean[k] + 0.1f * mean;
+        run_var[k] = 0.9f * run_var[k] + 0.1f * (B > 1 ? v / (B - 1) : var);
+    } else { mean = run_mean[k]; var = run_var[k]; }
+    const float rstd = rsqrtf(var + 1e-5f);
+    for (int b = 0; b < B; ++b) y[(long)b * K + k] = (x[(long)b * K + k] - mean) * rstd * gamma[k] + beta[k];
+    stat[2 * k] = mean; stat[2 * k + 1] = rstd;
+}
+__global__ __launch_bounds__(256) void batchnorm_bwd_kernel(const float* x, const float* gamma, const float* stat, const float* dy, float* dx,
+                                                           float* dgamma, float* dbeta, int B, int K, int train) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    const float mean = stat[2 * k], rstd = stat[2 * k + 1];
+    float s1 = 0.f, s2 = 0.f;
+    for (int b = 0; b < B; ++b) { const float d = dy[(long)b * K + k], xh = (x[(long)b * K + k] - mean) * rstd; s1 += d; s2 += d * xh; }
+    dgamma[k] = s2; dbeta[k] = s1;
+    for (int b = 0; b < B; ++b) {
+        const float d = dy[(long)b * K + k], xh = (x[(long)b * K + k] - mean) * rstd;
+        dx[(long)b * K + k] = train ? gamma[k] * rstd * (d - s1 / B - xh * s2 / B) : gamma[k] * rstd * d;
+    }
+}
+// out = a * mask * keep_scale (dropout with an injected 0/1 mask), also used for its backward
+__global__ __launch_bounds__(256) void mask_scale_kernel(const float* a, const float* mask, float scale, float* out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] * (mask ? mask[i] : 1.f) * scale;
+}
+__global__ __launch_bounds__(256) void addf_kernel(const float* a, const float* b, float* out, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
+}
+// loss = mean((pred - target)^2) -> loss[0] (atomic double), dpred = gscale * 2 (pred - target) / n
+__global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, double* loss, float* dpred, float gscale, long n) {
+    float a = 0.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float d = pred[i] - target[i];
+        a += d * d;
+        if (dpred) dpred[i] = gscale * 2.f * d / (float)n;
+    }
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) atomicAdd(loss, (double)a / (double)n);
+}
+// dtype conversion / layout: [B][C][P] fp32 (reference NCHW with P = H*W) <-> [B][P][C] compute dtype is ew_transpose
+
+// ------------------------------------------------------------------------------------------------------------
+// C ABI
+// ------------------------------------------------------------------------------------------------------------
+static ConvGeom mk_geom(int B, int H, int W, int C, int KH, int KW, int S, int P) {
+    ConvGeom g; g.B = B; g.H = H; g.W = W; g.C = C; g.KH = KH; g.KW = KW; g.S = S; g.P = P;
+    g.Ho = (H + 2 * P - KH) / S + 1; g.Wo = (W + 2 * P - KW) / S + 1; g.Kp = (KH * KW * C + 7) / 8 * 8;
+    return g;
+}
+static dim3 grid1(long n) { long b = (n + 255) / 256; return dim3((unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b))); }
+// launch KERN<T>(args...) for T = bf16 (dtype 1) or float (dtype 0); pointer arguments are cast inside ARGS via PT/CPT
+#define ON_DTYPE(DT, ...)                                        \
+    do {                                                         \
+        if ((DT) == 1) { typedef bf16_t T; __VA_ARGS__; }        \
+        else { typedef float T; __VA_ARGS__; }                   \
+    } while (0)
+#define PT(p) reinterpret_cast<T*>(p)
+#define CPT(p) reinterpret_cast<const T*>(p)
+#define ST(s) reinterpret_cast<hipStream_t>(s)
+
+static GNParams gn_params(const void* y, int B, int P, int C, int G, const float* gamma, const float* beta, double* sums) {
+    GNParams p;
+    p.y = y; p.ldy = C; p.gamma = gamma; p.beta = beta; p.sums = sums;
+    p.B = B; p.T = P; p.C = C; p.G = G; p.Cg = C / G;
+    return p;
+}
+
+extern "C" {
+
+int sgv_op_conv_out_shape(int H, int W, int C, int KH, int KW, int stride, int pad, int* Ho, int* Wo, int* Kp) {
+    const ConvGeom g = mk_geom(1, H, W, C, KH, KW, stride, pad);
+    if (Ho) *Ho = g.Ho;
+    if (Wo) *Wo = g.Wo;
+    if (Kp) *Kp = g.Kp;
+    return 0;
+}
+int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
+    OPCHK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && KH > 0 && KW > 0, "sgv_op_im2col: bad argument");
+    const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
+    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, grid1((long)B * g.Ho * g.Wo * g.Kp), dim3(256), 0, ST(stream), CPT(x), PT(col), g));
+    return OPLAUNCH_OK();
+}
+int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
+    OPCHK(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "sgv_op_col2im: bad argument");
+    const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
+    ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, grid1((long)B * H * W * C), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g));
+    return OPLAUNCH_OK();
+}
+int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream) {
+    OPCHK(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_fwd: bad argument");
+    const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
+    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, grid1((long)B * g.Ho * g.Wo * C), dim3(256), 0, ST(stream), CPT(x), PT(y), g));
+    return OPLAUNCH_OK();
+}
+int sgv_op_maxpool_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+    OPCHK(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_bwd: bad argument");
+    const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
+    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, grid1((long)B * H * W * C), dim3(256), 0, ST(stream), CPT(x), CPT(dy), PT(dx), g));
+    return OPLAUNCH_OK();
+}
+int sgv_op_add_relu_fwd(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
+    OPCHK(a && b && out && n > 0, "sgv_op_add_relu_fwd: bad argument");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(add_relu_fwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(a), CPT(b), PT(out), n));
+    return OPLAUNCH_OK();
+}
+int sgv_op_relu_bwd(int dtype, const void* out, const void* dout, void* d, long n, void* stream) {
+    OPCHK(out && dout && d && n > 0, "sgv_op_relu_bwd: bad argument");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(relu_bwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(out), CPT(dout), PT(d), n));
+    return OPLAUNCH_OK();
+}
+int sgv_op_add(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
+    OPCHK(a && b && out && n > 0, "sgv_op_add: bad argument");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(add_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(a), CPT(b), PT(out), n));
+    return OPLAUNCH_OK();
+}
+int sgv_op_avgpool_fwd(int dtype, const void* x, float* y, int B, int P, int C, void* stream) {
+    OPCHK(x && y && B > 0 && P > 0 && C > 0, "sgv_op_avgpool_fwd: bad argument");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(cdivi(C, 64), B), dim3(256), 0, ST(stream), CPT(x), y, P, C));
+    return OPLAUNCH_OK();
+}
+int sgv_op_avgpool_bwd(int dtype, const float* dy, void* dx, int B, int P, int C, int accumulate, void* stream) {
+    OPCHK(dy && dx && B > 0 && P > 0 && C > 0, "sgv_op_avgpool_bwd: bad argument");
+    const long n = (long)B * P * C;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), dy, PT(dx), P, C, n, accumulate));
+    return OPLAUNCH_OK();
+}
+int sgv_op_chan_scale_fwd(int dtype, const void* x, const float* s, void* out, int B, int P, int C, void* stream) {
+    OPCHK(x && s && out && B > 0 && P > 0 && C > 0, "sgv_op_chan_scale_fwd: bad argument");
+    const long n = (long)B * P * C;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_fwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(x), s, PT(out), P, C, n));
+    return OPLAUNCH_OK();
+}
+int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* dout, void* dx, float* ds, int B, int P, int C, void* stream) {
+    OPCHK(x && s && dout && dx && ds && B > 0 && P > 0 && C > 0, "sgv_op_chan_scale_bwd: bad argument");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_bwd_kernel<T>, dim3(cdivi(C, 64), B), dim3(256), 0, ST(stream), CPT(x), s, CPT(dout), PT(dx), ds, P, C));
+    return OPLAUNCH_OK();
+}
+
+// GroupNorm (+ activation: 0 none, 3 relu) on [B][P][C]; sums: B*G*2 doubles (zeroed here); out may carry res + rscale*f
+int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
+                  double* sums, void* stream) {
+    OPCHK(y && out && gamma && beta && sums, "sgv_op_gn_fwd: null argument");
+    OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_fwd: C %% 8 == 0, 1 <= G <= %d, C %% G == 0 required", SGV_GN_MAX_GROUPS);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
+    ew_gn_stats(dtype, p, ST(stream));
+    p.out = out; p.ldout = C;
+    ew_gn_apply(dtype, act, p, ST(stream));
+    return OPLAUNCH_OK();
+}
+size_t sgv_op_gn_workspace_floats(int B, int P, int C) { return ew_gn_part_floats(B, P, C); }
+// backward of out = act(gn(y)): dy (same dtype) and dgamma/dbeta (+= , fp32); sums from the forward; sums2: B*G*2 doubles
+// scratch; part: sgv_op_gn_workspace_floats floats scratch
+int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
+                  const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream) {
+    OPCHK(y && dout && dy && gamma && beta && sums && sums2 && part && dgamma && dbeta, "sgv_op_gn_bwd: null argument");
+    OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_bwd: bad channel / group counts");
+    if (hipMemsetAsync(sums2, 0, sizeof(double) * 2 * B * G, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
+    p.sums2 = sums2; p.dout = dout; p.lddout = C; p.rscale = 1.f; p.dgamma = dgamma; p.dbeta = dbeta; p.part = part;
+    ew_gn_bwd_reduce_act(dtype, act, p, ST(stream));
+    p.out = dy; p.ldout = C;
+    ew_gn_bwd_apply_act(dtype, act, p, ST(stream));
+    return OPLAUNCH_OK();
+}
+
+// ---- small fp32 layers ------------------------------------------------------------------------------------
+int sgv_op_linear_fwd(const float* x, const float* W, const float* bias, const float* scale, float* y, int B, int K, int O, int act, void* stream) {
+    OPCHK(x && W && y && B > 0 && K > 0 && O > 0, "sgv_op_linear_fwd: bad argument");
+    hipLaunchKernelGGL(linear_fwd_kernel, dim3(O, B), dim3(64), 0, ST(stream), x, W, bias, scale, y, K, O, act);
+    return OPLAUNCH_OK();
+}
+int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, void* stream) {
+    OPCHK(y && dy && dz && n > 0, "sgv_op_act_bwd: bad argument");
+    hipLaunchKernelGGL(act_bwd_kernel, grid1(n), dim3(256), 0, ST(stream), y, dy, dz, n, act);
+    return OPLAUNCH_OK();
+}
+int sgv_op_linear_bwd(const float* dz, const float* x, const float* W, const float* scale, float* dx, int accumulate_dx, float* dW, float* db,
+                      int B, int K, int O, void* stream) {
+    OPCHK(dz && x && W && dW && B > 0 && K > 0 && O > 0, "sgv_op_linear_bwd: bad argument");
+    if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdivi(K, 256), B), dim3(256), 0, ST(stream), dz, W, scale, dx, K, O, accumulate_dx);
+    hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdivi(K, 256), O), dim3(256), 0, ST(stream), dz, x, scale, dW, db, B, K, O);
+    return OPLAUNCH_OK();
+}
+int sgv_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stat, int B, int K, void* stream) {
+    OPCHK(x && gamma && beta && y && stat && B > 0 && K > 0, "sgv_op_layernorm_fwd: bad argument");
+    hipLaunchKernelGGL(layernorm_fwd_kernel, dim3(B), dim3(64), 0, ST(stream), x, gamma, beta, y, stat, K);
+    return OPLAUNCH_OK();
+}
+int sgv_op_layernorm_bwd(const float* x, const float* gamma, const float* stat, const float* dy, float* dx, float* dgamma, float* dbeta,
+                         int B, int K, void* stream) {
+    OPCHK(x && gamma && stat && dy && dx && dgamma && dbeta && B > 0 && K > 0, "sgv_op_layernorm_bwd: bad argument");
+    if (hipMemsetAsync(dgamma, 0, sizeof(float) * K, ST(stream)) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * K, ST(stream)) != hipSuccess)
+        return sgv_set_error(-2, "memset failed");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), x, gamma, stat, dy, dx, dgamma, dbeta, K);
+    return OPLAUNCH_OK();
+}
+int sgv_op_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y, float* stat,
+                         int B, int K, int train, void* stream) {
+    OPCHK(x && gamma && beta && run_mean && run_var && y && stat && B > 0 && K > 0, "sgv_op_batchnorm_fwd: bad argument");
+    OPCHK(!train || B > 1, "BatchNorm1d in training mode needs more than one value per channel (as torch raises)");
+    hipLaunchKernelGGL(batchnorm_fwd_kernel, dim3(cdivi(K, 256)), dim3(256), 0, ST(stream), x, gamma, beta, run_mean, run_var, y, stat, B, K, train);
+    return OPLAUNCH_OK();
+}
+int sgv_op_batchnorm_bwd(const float* x, const float* gamma, const float* stat, const float* dy, float* dx, float* dgamma, float* dbeta,
+                         int B, int K, int train, void* stream) {
+    OPCHK(x && gamma && stat && dy && dx && dgamma && dbeta && B > 0 && K > 0, "sgv_op_batchnorm_bwd: bad argument");
+    hipLaunchKernelGGL(batchnorm_bwd_kernel, dim3(cdivi(K, 256)), dim3(256), 0, ST(stream), x, gamma, stat, dy, dx, dgamma, dbeta, B, K, train);
+    return OPLAUNCH_OK();
+}
+int sgv_op_mask_scale(const float* a, const float* mask, float scale, float* out, long n, void* stream) {
+    OPCHK(a && out && n > 0, "sgv_op_mask_scale: bad argument");
+    hipLaunchKernelGGL(mask_scale_kernel, grid1(n), dim3(256), 0, ST(stream), a, mask, scale, out, n);
+    return OPLAUNCH_OK();
+}
+int sgv_op_addf(const float* a, const float* b, float* out, long n, void* stream) {
+    OPCHK(a && b && out && n > 0, "sgv_op_addf: bad argument");
+    hipLaunchKernelGGL(addf_kernel, grid1(n), dim3(256), 0, ST(stream), a, b, out, n);
+    return OPLAUNCH_OK();
+}
+int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* dpred, float gscale, long n, void* stream) {
+    OPCHK(pred && target && loss_dev && n > 0, "sgv_op_mse: bad argument");
+    if (hipMemsetAsync(loss_dev, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    hipLaunchKernelGGL(mse_kernel, grid1(n), dim3(256), 0, ST(stream), pred, target, loss_dev, dpred, gscale, n);
+    return OPLAUNCH_OK();
+}
+// C[M][N] = scale * A[M][K] . W[N][K]^T (+ bias[N]) (+ addend[M][N]); K, N multiples of 8; out_f32: fp32 output
+int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend,
+                   int M, int N, int K, int out_f32, void* stream) {
+    OPCHK(A && W && C && M > 0 && N > 0 && K > 0, "sgv_op_gemm_nt: bad argument");
+    OPCHK(K % 8 == 0 && N % 8 == 0, "sgv_op_gemm_nt: K and N must be multiples of 8 (got K=%d N=%d)", K, N);
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N;
+    p.addend = addend; p.ldadd = N; p.bias = bias; p.scale = scale;
+    p.M = M; p.N = N; p.K = K; p.taps = 1; p.pad = 0; p.Tlen = M; p.splitk = 1; p.out_f32 = out_f32;
+    const int r = launch_gemm_nt(dtype, p, ST(stream));
+    if (r) return sgv_set_error(-1, "sgv_op_gemm_nt: launch rejected (%d) for M=%d N=%d K=%d", r, M, N, K);
+    return 0;
+}
+// dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]; N1, N2 multiples of 8
+int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, void* stream) {
+    OPCHK(A && Bm && dW && M > 0 && N1 > 0 && N2 > 0, "sgv_op_gemm_tn: bad argument");
+    OPCHK(N1 % 8 == 0 && N2 % 8 == 0, "sgv_op_gemm_tn: N1 and N2 must be multiples of 8 (got %d, %d)", N1, N2);
+    GemmTN p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = 1; p.pad = 0; p.Tlen = M; p.splitk = 1; p.use_tr = 1;
+    const int r = launch_gemm_tn(dtype, p, ST(stream));
+    if (r) return sgv_set_error(-1, "sgv_op_gemm_tn: launch rejected (%d) for M=%d N1=%d N2=%d", r, M, N1, N2);
+    return 0;
+}
+// [Bn][I][J] -> [Bn][J][I] with dtype conversion (NCHW fp32 <-> channels-last compute dtype)
+int sgv_op_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, void* stream) {
+    OPCHK(src && dst && Bn > 0 && I > 0 && J > 0, "sgv_op_transpose: bad argument");
+    ew_transpose(src_dtype, dst_dtype, src, dst, Bn, I, J, J, I, (long)I * J, (long)I * J, ST(stream));
+    return OPLAUNCH_OK();
+}
+
+}  // extern "C"

@@ -27,6 +27,14 @@ static int fail(int code, const char* fmt, ...) {
     va_end(ap);
     return code;
 }
+// same, for the other translation units of the library (cnn.hip)
+int sgv_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 #define HIPCHK(x)                                                                                   \
     do {                                                                                            \
         hipError_t e_ = (x);                                                                        \

@@ -61,7 +61,7 @@ __device__ __forceinline__ GNCtx gn_ctx(const GNParams& p) {
 template <bool WITH_M = false>
 __device__ __forceinline__ void gn_consts(const GNParams& p, const GNCtx& c, float mean[8], float rstd[8],
                                           float* m1 = nullptr, float* m2 = nullptr) {
-    __shared__ float gc[16][4];
+    __shared__ float gc[SGV_GN_MAX_GROUPS][4];
     if ((int)threadIdx.x < p.G) {
         const int g = threadIdx.x;
         const double n = (double)p.Cg * (double)p.T;
@@ -93,9 +93,9 @@ __device__ __forceinline__ void gn_block_reduce(const GNParams& p, const GNCtx& 
                                                 const float w[8], float* chanA, float* chanB, double* gsums) {
     __shared__ float smA[2048];
     __shared__ float smB[2048];
-    __shared__ float smG[16];
+    __shared__ float smG[2 * SGV_GN_MAX_GROUPS];
     const int tid = threadIdx.x;
-    if (tid < 16) smG[tid] = 0.f;
+    if (tid < 2 * SGV_GN_MAX_GROUPS) smG[tid] = 0.f;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         smA[(c.ty * p.CV + c.tx) * 8 + e] = colA[e];
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
 }
 
 __device__ __forceinline__ float act_apply(int act, float z) {
-    return act == 1 ? gelu_f(z) : (act == 2 ? tanh_f(z) : z);
+    return act == 1 ? gelu_f(z) : (act == 2 ? tanh_f(z) : (act == 3 ? fmaxf(z, 0.f) : z));
 }
 
 // out = [res + rscale *] act(gn(y))
@@ -283,7 +283,7 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
                     dz = loss_grad(p.loss_type, df) * (1.f - o * o);
                     v[e] = o;
                 } else {
-                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
+                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
                 }
                 col[0][e] += dz;
                 col[1][e] += dz * xh;
@@ -426,7 +426,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
                     const float o = tanh_f(z);
                     dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
                 } else {
-                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : 1.f);
+                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
                 }
                 const float r = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
                 dotacc += r * (v[e] - cb[e]);          // dY * (conv output without bias) -> <G, W_eff>
@@ -505,6 +505,10 @@ constexpr int GN_REDUCE_TARGET = 768;
         hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P);             \
     } while (0)
 
+static void gn_finalize(GNParams p, hipStream_t s) {
+    GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, s, p, g_.rowsplit);
+}
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
     if (dtype == 1) GN_LAUNCH((gn_stats_kernel<bf16_t>), p, s);
     else GN_LAUNCH((gn_stats_kernel<float>), p, s);
@@ -514,17 +518,41 @@ int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s) {
     if (dtype == 1) {
         if (act == 1) GN_LAUNCH((gn_apply_kernel<bf16_t, 1>), p, s);
         else if (act == 2) GN_LAUNCH((gn_apply_kernel<bf16_t, 2>), p, s);
+        else if (act == 3) GN_LAUNCH((gn_apply_kernel<bf16_t, 3>), p, s);
         else GN_LAUNCH((gn_apply_kernel<bf16_t, 0>), p, s);
     } else {
         if (act == 1) GN_LAUNCH((gn_apply_kernel<float, 1>), p, s);
         else if (act == 2) GN_LAUNCH((gn_apply_kernel<float, 2>), p, s);
+        else if (act == 3) GN_LAUNCH((gn_apply_kernel<float, 3>), p, s);
         else GN_LAUNCH((gn_apply_kernel<float, 0>), p, s);
     }
     return 0;
 }
-static void gn_finalize(GNParams p, hipStream_t s) {
-    GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, s, p, g_.rowsplit);
+// GroupNorm backward for act in {0 none, 1 gelu, 3 relu}: reduce + finalize, then the streaming dY pass
+int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s) {
+    if (dtype == 1) {
+        if (act == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);
+        else if (act == 3) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 3, false, true>), p, s);
+        else GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 0, false, true>), p, s);
+    } else {
+        if (act == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 1, false, true>), p, s);
+        else if (act == 3) GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 3, false, true>), p, s);
+        else GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 0, false, true>), p, s);
+    }
+    gn_finalize(p, s);
+    return 0;
+}
+int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s) {
+    if (dtype == 1) {
+        if (act == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 1, false>), p, s);
+        else if (act == 3) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 3, false>), p, s);
+        else GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 0, false>), p, s);
+    } else {
+        if (act == 1) GN_LAUNCH((gn_bwd_apply_kernel<float, 1, false>), p, s);
+        else if (act == 3) GN_LAUNCH((gn_bwd_apply_kernel<float, 3, false>), p, s);
+        else GN_LAUNCH((gn_bwd_apply_kernel<float, 0, false>), p, s);
+    }
+    return 0;
 }
 int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s) {   // gelu, stored gradient; + finalize
     if (dtype == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);

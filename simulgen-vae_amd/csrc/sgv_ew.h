@@ -25,7 +25,10 @@ struct GNParams {
     int loss_type = 0;
 };
 
+constexpr int SGV_GN_MAX_GROUPS = 32;
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s);
+int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // act: 0 none, 1 gelu, 3 relu
+int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s);
 size_t ew_gn_part_floats(int B, int T, int C);

@@ -1,0 +1,297 @@
+"""ctypes binding of the operator-level C ABI (include/sgvae_ops.h) used by the latent-conditioner mirror.
+
+Every function takes / returns torch CUDA tensors (device memory + the current stream are the only things torch
+is used for here); feature maps are channels-last [B, H, W, C] in the compute dtype, small tensors fp32.
+There is no CPU fallback: the library must be built and a GPU present."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
+
+OPS_SYMBOLS = [
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gn_fwd",
+    "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
+    "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
+    "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
+    "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
+    "sgv_op_mse", "sgv_op_transpose",
+]
+ACT_NONE, ACT_RELU_GN = 0, 3            # GroupNorm activation ids (ew.hip)
+LIN_NONE, LIN_RELU, LIN_SIGMOID = 0, 1, 2
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        l = load_library()
+        vp, i, f, lg = C.c_void_p, C.c_int, C.c_float, C.c_long
+        sig = {
+            "sgv_op_conv_out_shape": [i] * 7 + [C.POINTER(i)] * 3,
+            "sgv_op_im2col": [i, vp, vp] + [i] * 8 + [vp],
+            "sgv_op_col2im": [i, vp, vp] + [i] * 8 + [vp],
+            "sgv_op_gemm_nt": [i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp],
+            "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp],
+            "sgv_op_gn_workspace_floats": [i, i, i],
+            "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
+            "sgv_op_maxpool_fwd": [i, vp, vp, i, i, i, i, vp],
+            "sgv_op_maxpool_bwd": [i, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_add_relu_fwd": [i, vp, vp, vp, lg, vp],
+            "sgv_op_relu_bwd": [i, vp, vp, vp, lg, vp],
+            "sgv_op_add": [i, vp, vp, vp, lg, vp],
+            "sgv_op_avgpool_fwd": [i, vp, vp, i, i, i, vp],
+            "sgv_op_avgpool_bwd": [i, vp, vp, i, i, i, i, vp],
+            "sgv_op_chan_scale_fwd": [i, vp, vp, vp, i, i, i, vp],
+            "sgv_op_chan_scale_bwd": [i, vp, vp, vp, vp, vp, i, i, i, vp],
+            "sgv_op_linear_fwd": [vp, vp, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_act_bwd": [vp, vp, vp, lg, i, vp],
+            "sgv_op_linear_bwd": [vp, vp, vp, vp, vp, i, vp, vp, i, i, i, vp],
+            "sgv_op_layernorm_fwd": [vp, vp, vp, vp, vp, i, i, vp],
+            "sgv_op_layernorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i, i, vp],
+            "sgv_op_batchnorm_fwd": [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+            "sgv_op_batchnorm_bwd": [vp, vp, vp, vp, vp, vp, vp, i, i, i, vp],
+            "sgv_op_mask_scale": [vp, vp, f, vp, lg, vp],
+            "sgv_op_addf": [vp, vp, vp, lg, vp],
+            "sgv_op_mse": [vp, vp, vp, vp, f, lg, vp],
+            "sgv_op_transpose": [i, i, vp, vp, i, i, i, vp],
+        }
+        for name, args in sig.items():
+            getattr(l, name).argtypes = args
+        l.sgv_op_gn_workspace_floats.restype = C.c_size_t
+        _lib = l
+    return _lib
+
+
+def _p(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ck(rc, what):
+    if rc != 0:
+        raise SgvError(f"{what} failed ({rc}): {lib().sgv_last_error().decode()}")
+
+
+def tdtype(dtype: str):
+    return torch.bfloat16 if DTYPES[dtype] == 1 else torch.float32
+
+
+def conv_out_shape(H, W, Cin, KH, KW, stride, pad):
+    ho, wo, kp = C.c_int(), C.c_int(), C.c_int()
+    lib().sgv_op_conv_out_shape(H, W, Cin, KH, KW, stride, pad, C.byref(ho), C.byref(wo), C.byref(kp))
+    return ho.value, wo.value, kp.value
+
+
+def _d(t):
+    return 1 if t.dtype == torch.bfloat16 else 0
+
+
+def im2col(x, KH, KW, stride, pad):
+    B, H, W, Cin = x.shape
+    Ho, Wo, Kp = conv_out_shape(H, W, Cin, KH, KW, stride, pad)
+    col = torch.empty((B * Ho * Wo, Kp), dtype=x.dtype, device=x.device)
+    _ck(lib().sgv_op_im2col(_d(x), _p(x), _p(col), B, H, W, Cin, KH, KW, stride, pad, _stream()), "sgv_op_im2col")
+    return col, Ho, Wo
+
+
+def col2im(dcol, shape, KH, KW, stride, pad):
+    B, H, W, Cin = shape
+    dx = torch.empty(shape, dtype=dcol.dtype, device=dcol.device)
+    _ck(lib().sgv_op_col2im(_d(dcol), _p(dcol), _p(dx), B, H, W, Cin, KH, KW, stride, pad, _stream()), "sgv_op_col2im")
+    return dx
+
+
+def gemm_nt(A, W, bias=None, scale=None, addend=None, out_f32=False):
+    """A [M, K] . W [N, K]^T -> [M, N]."""
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=torch.float32 if out_f32 else A.dtype, device=A.device)
+    _ck(lib().sgv_op_gemm_nt(_d(A), _p(A), _p(W), _p(out), _p(bias), _p(scale), _p(addend), M, N, K, int(out_f32), _stream()),
+        "sgv_op_gemm_nt")
+    return out
+
+
+def gemm_tn(A, Bm):
+    """A [M, N1]^T . Bm [M, N2] -> fp32 [N1, N2]."""
+    M, N1 = A.shape
+    N2 = Bm.shape[1]
+    out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
+    _ck(lib().sgv_op_gemm_tn(_d(A), _p(A), _p(Bm), _p(out), M, N1, N2, _stream()), "sgv_op_gemm_tn")
+    return out
+
+
+def gn_fwd(y, G, gamma, beta, act):
+    """y [B, P, C] -> (out, sums)."""
+    B, P, Cc = y.shape
+    out = torch.empty_like(y)
+    sums = torch.empty(B * G * 2, dtype=torch.float64, device=y.device)
+    _ck(lib().sgv_op_gn_fwd(_d(y), act, _p(y), _p(out), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _stream()), "sgv_op_gn_fwd")
+    return out, sums
+
+
+def gn_bwd(y, dout, G, gamma, beta, sums, act, dgamma, dbeta):
+    B, P, Cc = y.shape
+    dy = torch.empty_like(y)
+    sums2 = torch.empty_like(sums)
+    part = torch.empty(int(lib().sgv_op_gn_workspace_floats(B, P, Cc)), dtype=torch.float32, device=y.device)
+    _ck(lib().sgv_op_gn_bwd(_d(y), act, _p(y), _p(dout), _p(dy), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _p(sums2), _p(part),
+                            _p(dgamma), _p(dbeta), _stream()), "sgv_op_gn_bwd")
+    return dy
+
+
+def maxpool_fwd(x):
+    B, H, W, Cc = x.shape
+    Ho, Wo, _ = conv_out_shape(H, W, Cc, 3, 3, 2, 1)
+    y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
+    _ck(lib().sgv_op_maxpool_fwd(_d(x), _p(x), _p(y), B, H, W, Cc, _stream()), "sgv_op_maxpool_fwd")
+    return y
+
+
+def maxpool_bwd(x, dy):
+    B, H, W, Cc = x.shape
+    dx = torch.empty_like(x)
+    _ck(lib().sgv_op_maxpool_bwd(_d(x), _p(x), _p(dy), _p(dx), B, H, W, Cc, _stream()), "sgv_op_maxpool_bwd")
+    return dx
+
+
+def add_relu(a, b):
+    out = torch.empty_like(a)
+    _ck(lib().sgv_op_add_relu_fwd(_d(a), _p(a), _p(b), _p(out), a.numel(), _stream()), "sgv_op_add_relu_fwd")
+    return out
+
+
+def relu_bwd(out, dout):
+    d = torch.empty_like(out)
+    _ck(lib().sgv_op_relu_bwd(_d(out), _p(out), _p(dout), _p(d), out.numel(), _stream()), "sgv_op_relu_bwd")
+    return d
+
+
+def add(a, b):
+    out = torch.empty_like(a)
+    _ck(lib().sgv_op_add(_d(a), _p(a), _p(b), _p(out), a.numel(), _stream()), "sgv_op_add")
+    return out
+
+
+def avgpool_fwd(x):
+    """x [B, P, C] -> fp32 [B, C]."""
+    B, P, Cc = x.shape
+    y = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    _ck(lib().sgv_op_avgpool_fwd(_d(x), _p(x), _p(y), B, P, Cc, _stream()), "sgv_op_avgpool_fwd")
+    return y
+
+
+def avgpool_bwd(dy, dx_or_shape, dtype=None):
+    """dy fp32 [B, C]; either accumulates into an existing dx [B, P, C] or creates one of `dx_or_shape`."""
+    if torch.is_tensor(dx_or_shape):
+        dx, acc = dx_or_shape, 1
+    else:
+        dx, acc = torch.empty(dx_or_shape, dtype=dtype, device=dy.device), 0
+    B, P, Cc = dx.shape
+    _ck(lib().sgv_op_avgpool_bwd(_d(dx), _p(dy), _p(dx), B, P, Cc, acc, _stream()), "sgv_op_avgpool_bwd")
+    return dx
+
+
+def chan_scale_fwd(x, s):
+    B, P, Cc = x.shape
+    out = torch.empty_like(x)
+    _ck(lib().sgv_op_chan_scale_fwd(_d(x), _p(x), _p(s), _p(out), B, P, Cc, _stream()), "sgv_op_chan_scale_fwd")
+    return out
+
+
+def chan_scale_bwd(x, s, dout):
+    B, P, Cc = x.shape
+    dx = torch.empty_like(x)
+    ds = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+    _ck(lib().sgv_op_chan_scale_bwd(_d(x), _p(x), _p(s), _p(dout), _p(dx), _p(ds), B, P, Cc, _stream()), "sgv_op_chan_scale_bwd")
+    return dx, ds
+
+
+def linear_fwd(x, W, bias=None, scale=None, act=LIN_NONE):
+    B, K = x.shape
+    O = W.shape[0]
+    y = torch.empty((B, O), dtype=torch.float32, device=x.device)
+    _ck(lib().sgv_op_linear_fwd(_p(x), _p(W), _p(bias), _p(scale), _p(y), B, K, O, act, _stream()), "sgv_op_linear_fwd")
+    return y
+
+
+def act_bwd(y, dy, act):
+    dz = torch.empty_like(y)
+    _ck(lib().sgv_op_act_bwd(_p(y), _p(dy), _p(dz), y.numel(), act, _stream()), "sgv_op_act_bwd")
+    return dz
+
+
+def linear_bwd(dz, x, W, scale=None, need_dx=True, has_bias=True, dx_accumulate=None):
+    B, K = x.shape
+    O = W.shape[0]
+    dW = torch.empty_like(W)
+    db = torch.empty(O, dtype=torch.float32, device=x.device) if has_bias else None
+    dx = dx_accumulate if dx_accumulate is not None else (torch.empty_like(x) if need_dx else None)
+    _ck(lib().sgv_op_linear_bwd(_p(dz), _p(x), _p(W), _p(scale), _p(dx), int(dx_accumulate is not None), _p(dW), _p(db), B, K, O,
+                                _stream()), "sgv_op_linear_bwd")
+    return dx, dW, db
+
+
+def layernorm_fwd(x, gamma, beta):
+    B, K = x.shape
+    y = torch.empty_like(x)
+    stat = torch.empty(2 * B, dtype=torch.float32, device=x.device)
+    _ck(lib().sgv_op_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stat), B, K, _stream()), "sgv_op_layernorm_fwd")
+    return y, stat
+
+
+def layernorm_bwd(x, gamma, stat, dy):
+    B, K = x.shape
+    dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+    _ck(lib().sgv_op_layernorm_bwd(_p(x), _p(gamma), _p(stat), _p(dy), _p(dx), _p(dg), _p(db), B, K, _stream()), "sgv_op_layernorm_bwd")
+    return dx, dg, db
+
+
+def batchnorm_fwd(x, gamma, beta, run_mean, run_var, train):
+    B, K = x.shape
+    y = torch.empty_like(x)
+    stat = torch.empty(2 * K, dtype=torch.float32, device=x.device)
+    _ck(lib().sgv_op_batchnorm_fwd(_p(x), _p(gamma), _p(beta), _p(run_mean), _p(run_var), _p(y), _p(stat), B, K, int(train), _stream()),
+        "sgv_op_batchnorm_fwd")
+    return y, stat
+
+
+def batchnorm_bwd(x, gamma, stat, dy, train):
+    B, K = x.shape
+    dx, dg, db = torch.empty_like(x), torch.empty_like(gamma), torch.empty_like(gamma)
+    _ck(lib().sgv_op_batchnorm_bwd(_p(x), _p(gamma), _p(stat), _p(dy), _p(dx), _p(dg), _p(db), B, K, int(train), _stream()),
+        "sgv_op_batchnorm_bwd")
+    return dx, dg, db
+
+
+def mask_scale(a, mask, scale):
+    out = torch.empty_like(a)
+    _ck(lib().sgv_op_mask_scale(_p(a), _p(mask), float(scale), _p(out), a.numel(), _stream()), "sgv_op_mask_scale")
+    return out
+
+
+def addf(a, b):
+    out = torch.empty_like(a)
+    _ck(lib().sgv_op_addf(_p(a), _p(b), _p(out), a.numel(), _stream()), "sgv_op_addf")
+    return out
+
+
+def mse(pred, target, gscale=1.0, need_grad=True):
+    loss = torch.empty(1, dtype=torch.float64, device=pred.device)
+    dp = torch.empty_like(pred) if need_grad else None
+    _ck(lib().sgv_op_mse(_p(pred), _p(target), _p(loss), _p(dp), float(gscale), pred.numel(), _stream()), "sgv_op_mse")
+    return loss, dp
+
+
+def transpose(src, dst_dtype, Bn, I, J):
+    """[Bn, I, J] -> [Bn, J, I] with dtype conversion."""
+    dst = torch.empty((Bn, J, I), dtype=dst_dtype, device=src.device)
+    _ck(lib().sgv_op_transpose(_d(src), 1 if dst_dtype == torch.bfloat16 else 0, _p(src), _p(dst), Bn, I, J, _stream()), "sgv_op_transpose")
+    return dst

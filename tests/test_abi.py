@@ -23,6 +23,17 @@ def test_library_exports_every_declared_symbol():
     assert lib.sgv_last_error() is not None
 
 
+def test_library_exports_every_operator_symbol():
+    """include/sgvae_ops.h (latent-conditioner operators) vs simulgen_vae_amd.ops.OPS_SYMBOLS vs the library."""
+    from simulgen_vae_amd import ops
+    hdr = open(os.path.join(ROOT, "include", "sgvae_ops.h")).read()
+    declared = set(re.findall(r"\b(sgv_op_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(ops.OPS_SYMBOLS), declared ^ set(ops.OPS_SYMBOLS)
+    lib = E.load_library()
+    for s in declared:
+        assert hasattr(lib, s), s
+
+
 def test_param_counts_match_reference_full_size():
     enc = [1024, 512, 256, 128]
     small = VAEConfig(32, 8, enc, enc[::-1], 95008, 200, "MSE", True)

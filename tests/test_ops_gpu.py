@@ -1,0 +1,208 @@
+"""Operator-level C ABI of the latent conditioner (include/sgvae_ops.h) against plain PyTorch fp32 on the CPU:
+every HIP kernel vs the torch op the reference model calls (modules/latent_conditioner_model_cnn.py), forward and
+backward (autograd of the CPU op).  Tolerances: fp32 compute 2e-5 relative (max-norm); bf16 compute 2e-2."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import simulgen_vae_amd  # noqa: F401
+from simulgen_vae_amd import ops
+
+pytestmark = pytest.mark.gpu
+TOL = {torch.float32: 2e-5, torch.bfloat16: 2e-2}
+
+
+def rel(a, b):
+    a, b = a.detach().double().cpu(), b.detach().double().cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def nhwc(x, dt):          # NCHW fp32 cpu -> channels-last device tensor
+    return x.permute(0, 2, 3, 1).contiguous().to(device="cuda", dtype=dt)
+
+
+def nchw(x):              # channels-last device -> NCHW fp32 cpu
+    return x.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def q(x, dt):             # round inputs to the compute dtype so the CPU reference sees the same numbers
+    return x.to(dt).float()
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 1, 16, 20, 20, 7, 1, 3), (2, 16, 32, 12, 10, 3, 2, 1), (3, 8, 24, 9, 9, 1, 2, 0),
+                                 (2, 24, 16, 8, 8, 3, 1, 1), (2, 32, 16, 6, 6, 1, 1, 0)])
+def test_conv2d_via_im2col(dt, cfg):
+    B, Ci, Co, H, W, k, s, p = cfg
+    g = torch.Generator().manual_seed(1)
+    x = q(torch.randn(B, Ci, H, W, generator=g), dt).requires_grad_()
+    w = q(torch.randn(Co, Ci, k, k, generator=g) * 0.2, dt).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    dy = q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    Ho, Wo, Kp = ops.conv_out_shape(H, W, Ci, k, k, s, p)
+    assert (Ho, Wo) == tuple(y.shape[2:]) and Kp % 8 == 0
+    xd = nhwc(x.detach(), dt)
+    wm = torch.zeros(Co, Kp)
+    wm[:, :k * k * Ci] = w.detach().permute(0, 2, 3, 1).reshape(Co, -1)        # [Cout][kh][kw][Cin]
+    wd = wm.to(device="cuda", dtype=dt)
+    col, ho, wo = ops.im2col(xd, k, k, s, p)
+    out = ops.gemm_nt(col, wd).view(B, ho, wo, Co)
+    assert rel(nchw(out), y) < TOL[dt]
+    dyd = nhwc(dy, dt).view(-1, Co)
+    dW = ops.gemm_tn(dyd, col)                                                 # [Cout][Kp]
+    dw_ref = torch.zeros(Co, Kp)
+    dw_ref[:, :k * k * Ci] = w.grad.permute(0, 2, 3, 1).reshape(Co, -1)
+    assert rel(dW, dw_ref) < TOL[dt]
+    assert float(dW[:, k * k * Ci:].abs().max()) == 0.0 if Kp > k * k * Ci else True
+    wt = wd.t().contiguous()                                                   # [Kp][Cout]
+    dcol = ops.gemm_nt(dyd, wt)
+    dx = ops.col2im(dcol, xd.shape, k, k, s, p)
+    assert rel(nchw(dx), x.grad) < TOL[dt]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 32, 32, 36, 3), (3, 64, 32, 25, 0), (2, 256, 32, 16, 3), (2, 48, 16, 300, 0)])
+def test_groupnorm_relu(dt, cfg):
+    B, Cc, G, P, act = cfg
+    g = torch.Generator().manual_seed(2)
+    y = q(torch.randn(B, Cc, P, generator=g) * 2 + 0.5, dt).requires_grad_()
+    gamma = (torch.rand(Cc, generator=g) + 0.5).requires_grad_()
+    beta = (torch.randn(Cc, generator=g) * 0.3).requires_grad_()
+    o = F.group_norm(y, G, gamma, beta, 1e-5)
+    if act == 3:
+        o = F.relu(o)
+    do = q(torch.randn(o.shape, generator=g), dt)
+    o.backward(do)
+    yd = y.detach().permute(0, 2, 1).contiguous().to(device="cuda", dtype=dt)      # [B][P][C]
+    gd, bd = gamma.detach().cuda(), beta.detach().cuda()
+    out, sums = ops.gn_fwd(yd, G, gd, bd, act)
+    assert rel(out.float().cpu().permute(0, 2, 1), o) < max(TOL[dt], 1e-4)
+    dgam, dbet = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    dyd = ops.gn_bwd(yd, do.permute(0, 2, 1).contiguous().to(device="cuda", dtype=dt), G, gd, bd, sums, act, dgam, dbet)
+    assert rel(dyd.float().cpu().permute(0, 2, 1), y.grad) < max(TOL[dt], 2e-4)
+    assert rel(dgam, gamma.grad) < max(TOL[dt], 2e-4) and rel(dbet, beta.grad) < max(TOL[dt], 2e-4)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_maxpool_residual_se_ops(dt):
+    g = torch.Generator().manual_seed(3)
+    B, Cc, H, W = 2, 16, 11, 14
+    x = q(torch.randn(B, Cc, H, W, generator=g), dt).requires_grad_()
+    y = F.max_pool2d(x, 3, 2, 1)
+    dy = q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    xd = nhwc(x.detach(), dt)
+    yd = ops.maxpool_fwd(xd)
+    assert rel(nchw(yd), y) == 0.0
+    assert rel(nchw(ops.maxpool_bwd(xd, nhwc(dy, dt))), x.grad) < TOL[dt]
+    # relu(a + b) and its gate
+    a = q(torch.randn(B, Cc, H, W, generator=g), dt).requires_grad_()
+    b = q(torch.randn(B, Cc, H, W, generator=g), dt).requires_grad_()
+    o = F.relu(a + b)
+    do = q(torch.randn(o.shape, generator=g), dt)
+    o.backward(do)
+    od = ops.add_relu(nhwc(a.detach(), dt), nhwc(b.detach(), dt))
+    assert rel(nchw(od), o) < TOL[dt]
+    assert rel(nchw(ops.relu_bwd(od, nhwc(do, dt))), a.grad) < TOL[dt]
+    assert rel(nchw(ops.add(nhwc(a.detach(), dt), nhwc(b.detach(), dt))), (a + b).to(dt).float()) < TOL[dt]
+    # squeeze-excitation pieces: global average pool and per-channel scaling
+    x2 = q(torch.randn(B, Cc, H, W, generator=g), dt).requires_grad_()
+    s = torch.rand(B, Cc, generator=g).requires_grad_()
+    pooled = x2.mean(dim=(2, 3))
+    scaled = x2 * s.view(B, Cc, 1, 1)
+    dp = torch.randn(B, Cc, generator=g)
+    dsc = q(torch.randn(scaled.shape, generator=g), dt)
+    (pooled * dp).sum().backward(retain_graph=True)
+    gx_pool = x2.grad.clone()
+    x2.grad = None
+    scaled.backward(dsc)
+    x2d = nhwc(x2.detach(), dt).view(B, H * W, Cc)
+    assert rel(ops.avgpool_fwd(x2d), pooled) < max(TOL[dt], 1e-5)
+    dxp = ops.avgpool_bwd(dp.cuda(), (B, H * W, Cc), dt)
+    assert rel(dxp.view(B, H, W, Cc).float().cpu().permute(0, 3, 1, 2), gx_pool) < TOL[dt]
+    acc = torch.ones((B, H * W, Cc), dtype=dt, device="cuda")
+    ops.avgpool_bwd(dp.cuda(), acc)
+    assert rel(acc.view(B, H, W, Cc).float().cpu().permute(0, 3, 1, 2), gx_pool + 1.0) < TOL[dt]
+    sd = s.detach().cuda()
+    assert rel(ops.chan_scale_fwd(x2d, sd).view(B, H, W, Cc).float().cpu().permute(0, 3, 1, 2), scaled) < TOL[dt]
+    dx, ds = ops.chan_scale_bwd(x2d, sd, nhwc(dsc, dt).view(B, H * W, Cc))
+    assert rel(dx.view(B, H, W, Cc).float().cpu().permute(0, 3, 1, 2), x2.grad) < TOL[dt]
+    assert rel(ds, s.grad) < max(TOL[dt], 1e-5)
+
+
+def test_small_fp32_layers():
+    g = torch.Generator().manual_seed(4)
+    B, K, O = 6, 40, 24
+    x = torch.randn(B, K, generator=g).requires_grad_()
+    W = (torch.randn(O, K, generator=g) * 0.3).requires_grad_()
+    bias = torch.randn(O, generator=g).requires_grad_()
+    sc = torch.tensor([0.7])
+    for act, fn in ((ops.LIN_NONE, lambda z: z), (ops.LIN_RELU, F.relu), (ops.LIN_SIGMOID, torch.sigmoid)):
+        for t in (x, W, bias):
+            t.grad = None
+        y = fn(F.linear(x, W * sc, bias))
+        dy = torch.randn(y.shape, generator=g)
+        y.backward(dy)
+        yd = ops.linear_fwd(x.detach().cuda(), W.detach().cuda(), bias.detach().cuda(), sc.cuda(), act)
+        assert rel(yd, y) < 2e-5
+        dz = ops.act_bwd(yd, dy.cuda(), act)
+        dx, dW, db = ops.linear_bwd(dz, x.detach().cuda(), W.detach().cuda(), sc.cuda())
+        assert rel(dx, x.grad) < 2e-5 and rel(dW, W.grad) < 2e-5 and rel(db, bias.grad) < 2e-5
+        dx2 = torch.ones_like(dx)
+        ops.linear_bwd(dz, x.detach().cuda(), W.detach().cuda(), sc.cuda(), dx_accumulate=dx2)
+        assert rel(dx2, x.grad + 1.0) < 2e-5
+    # LayerNorm
+    gam, bet = (torch.rand(K, generator=g) + 0.5).requires_grad_(), torch.randn(K, generator=g).requires_grad_()
+    x.grad = None
+    y = F.layer_norm(x, (K,), gam, bet, 1e-5)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    yd, stat = ops.layernorm_fwd(x.detach().cuda(), gam.detach().cuda(), bet.detach().cuda())
+    assert rel(yd, y) < 2e-5
+    dx, dg, db = ops.layernorm_bwd(x.detach().cuda(), gam.detach().cuda(), stat, dy.cuda())
+    assert rel(dx, x.grad) < 5e-5 and rel(dg, gam.grad) < 2e-5 and rel(db, bet.grad) < 2e-5
+    # BatchNorm1d, training then eval with the updated running buffers
+    bn = torch.nn.BatchNorm1d(K)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(K, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(K, generator=g))
+        bn.running_mean.copy_(torch.randn(K, generator=g) * 0.1)
+        bn.running_var.copy_(torch.rand(K, generator=g) + 0.5)
+    rm, rv = bn.running_mean.clone().cuda(), bn.running_var.clone().cuda()
+    x.grad = None
+    bn.train()
+    y = bn(x)
+    dy = torch.randn(y.shape, generator=g)
+    y.backward(dy)
+    gw, gb = bn.weight.detach().cuda(), bn.bias.detach().cuda()
+    yd, stat = ops.batchnorm_fwd(x.detach().cuda(), gw, gb, rm, rv, True)
+    assert rel(yd, y) < 2e-5 and rel(rm, bn.running_mean) < 2e-6 and rel(rv, bn.running_var) < 2e-6
+    dx, dg, db = ops.batchnorm_bwd(x.detach().cuda(), gw, stat, dy.cuda(), True)
+    assert rel(dx, x.grad) < 5e-5 and rel(dg, bn.weight.grad) < 2e-5 and rel(db, bn.bias.grad) < 2e-5
+    bn.eval()
+    x.grad = None
+    bn.weight.grad = None
+    y = bn(x)
+    y.backward(dy)
+    yd, stat = ops.batchnorm_fwd(x.detach().cuda(), gw, gb, rm, rv, False)
+    assert rel(yd, y) < 2e-5
+    dx, dg, db = ops.batchnorm_bwd(x.detach().cuda(), gw, stat, dy.cuda(), False)
+    assert rel(dx, x.grad) < 2e-5 and rel(dg, bn.weight.grad) < 2e-5
+    with pytest.raises(ops.SgvError):
+        ops.batchnorm_fwd(x.detach()[:1].contiguous().cuda(), gw, gb, rm, rv, True)     # torch raises for one value per channel
+    # dropout with an injected mask, add, MSE
+    mask = (torch.rand(B, K, generator=g) > 0.3).float()
+    assert rel(ops.mask_scale(x.detach().cuda(), mask.cuda(), 1 / 0.7), x.detach() * mask / 0.7) < 1e-6
+    assert rel(ops.addf(x.detach().cuda(), mask.cuda()), x.detach() + mask) < 1e-6
+    p = torch.randn(B, O, generator=g).requires_grad_()
+    t = torch.randn(B, O, generator=g)
+    loss = F.mse_loss(p, t)
+    (10.0 * loss).backward()
+    ld, dp = ops.mse(p.detach().cuda(), t.cuda(), gscale=10.0)
+    assert abs(float(ld) - float(loss.detach())) < 1e-6 * float(loss.detach()) and rel(dp, p.grad) < 2e-6
+    # NCHW fp32 <-> channels-last compute dtype
+    img = torch.randn(3, 5, 7 * 9, generator=g)
+    tr = ops.transpose(img.cuda(), torch.bfloat16, 3, 5, 63)
+    assert torch.equal(tr.cpu(), img.permute(0, 2, 1).contiguous().to(torch.bfloat16))
