@@ -57,6 +57,7 @@ int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* 
  * linear: y = act(scale[0] * x W^T + bias), act: 0 none, 1 relu, 2 sigmoid; act_bwd: dz = dy * act'(y) from the stored
  * output; linear_bwd: dx (= or +=) scale * dz W, dW = scale * dz^T x, db = sum_b dz (dx, db may be NULL). */
 int sgv_op_linear_fwd(const float* x, const float* W, const float* bias, const float* scale, float* y, int B, int K, int O, int act, void* stream);
+int sgv_op_act_fwd(const float* x, float* y, long n, int act, void* stream);
 int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, void* stream);
 int sgv_op_linear_bwd(const float* dz, const float* x, const float* W, const float* scale, float* dx, int accumulate_dx, float* dW, float* db,
                       int B, int K, int O, void* stream);
@@ -75,6 +76,24 @@ int sgv_op_batchnorm_bwd(const float* x, const float* gamma, const float* stat, 
 int sgv_op_mask_scale(const float* a, const float* mask, float scale, float* out, long n, void* stream);
 int sgv_op_addf(const float* a, const float* b, float* out, long n, void* stream);
 int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* dpred, float gscale, long n, void* stream);
+/* Parameter side.  Legacy spectral norm (modules/common.py:15-37 -> torch nn/utils/spectral_norm.py): with the weight
+ * as a [rows][cols] matrix, v = l2_normalize(W^T u), u = l2_normalize(W v) (eps 1e-12), sigma = u.(W v); the
+ * mat-vecs are sgv_op_linear_fwd / sgv_op_linear_bwd with B = 1.  sgv_op_dot writes {a.b, 1/(a.b)}.
+ * sgv_op_sn_grad: gradient wrt weight_orig from the gradient G wrt W/sigma: (G - (<G,W_orig>/sigma) u v^T) / sigma,
+ * gw = {<G,W_orig>}, sigma2 = {sigma, 1/sigma}.  conv_weight_pack/unpack: reference [Cout][Cin][KH][KW] fp32 <-> the
+ * GEMM layout [Cout][(kh*KW+kw)*Cin+ci] padded to a multiple of 8 (compute dtype / fp32).
+ * Gradient clipping (latent_conditioner.py:304): sumsq accumulates sum g^2 into a double, clip_coef writes
+ * {min(1, max_norm/(norm+1e-6)), norm}; sgv_op_adamw = torch.optim.AdamW on one tensor with g scaled by gscale[0]. */
+int sgv_op_l2_normalize(const float* x, float* out, long n, float eps, void* stream);
+int sgv_op_dot(const float* a, const float* b, float* out2, long n, void* stream);
+int sgv_op_sn_grad(const float* G, const float* u, const float* v, const float* gw, const float* sigma2, float* out, int rows, int cols,
+                   void* stream);
+int sgv_op_conv_weight_pack(int dtype, const float* w, void* packed, int Cout, int Cin, int KH, int KW, void* stream);
+int sgv_op_conv_weight_unpack(const float* packed, float* w, int Cout, int Cin, int KH, int KW, void* stream);
+int sgv_op_sumsq(const float* g, long n, double* acc, void* stream);
+int sgv_op_clip_coef(const double* sumsq, float max_norm, float* out2, void* stream);
+int sgv_op_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 int step, const float* gscale, void* stream);
 /* [Bn][I][J] -> [Bn][J][I] with dtype conversion (reference NCHW fp32 <-> channels-last compute dtype). */
 int sgv_op_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, void* stream);
 

@@ -12,6 +12,7 @@
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
+#include <math.h>
 
 int sgv_set_error(int code, const char* fmt, ...);   // engine.hip: fills sgv_last_error()
 
@@ -203,6 +204,9 @@ __global__ __launch_bounds__(64) void linear_fwd_kernel(const float* x, const fl
     a = wave_sum(a);
     if (threadIdx.x == 0) y[(long)b * O + o] = small_act(act, a * (scale ? *scale : 1.f) + (bias ? bias[o] : 0.f));
 }
+__global__ __launch_bounds__(256) void act_fwd_kernel(const float* x, float* y, long n, int act) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = small_act(act, x[i]);
+}
 // dz = dy * act'(y) (from the stored output y), in place capable
 __global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const float* dy, float* dz, long n, int act) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -318,6 +322,84 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, (double)a / (double)n);
 }
 // dtype conversion / layout: [B][C][P] fp32 (reference NCHW with P = H*W) <-> [B][P][C] compute dtype is ew_transpose
+
+// ------------------------------------------------------------------------------------------------------------
+// parameter-side helpers: spectral norm (torch legacy hook, modules/common.py:15-37), weight packing, clipping, AdamW
+// ------------------------------------------------------------------------------------------------------------
+// out = x / max(||x||, eps); one block
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* x, float* out, long n, float eps) {
+    __shared__ float sm[4];
+    float a = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) a += x[i] * x[i];
+    a = wave_sum(a);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    const float inv = 1.f / fmaxf(sqrtf(sm[0] + sm[1] + sm[2] + sm[3]), eps);
+    for (long i = threadIdx.x; i < n; i += 256) out[i] = x[i] * inv;
+}
+// out[0] = sum a*b (fp32), out[1] = 1/out[0]; one block
+__global__ __launch_bounds__(256) void dot_kernel(const float* a, const float* b, float* out, long n) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) acc += (double)a[i] * (double)b[i];
+    acc = wave_sum_d(acc);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) { const float d = (float)(sm[0] + sm[1] + sm[2] + sm[3]); out[0] = d; out[1] = 1.f / d; }
+}
+// g_orig[r][c] = (G[r][c] - (gw[0] * sig[1]) * u[r] * v[c]) * sig[1]    (sig = {sigma, 1/sigma}, gw[0] = <G, W_orig>)
+__global__ __launch_bounds__(256) void sn_grad_kernel(const float* G, const float* u, const float* v, const float* gw, const float* sig,
+                                                     float* out, int rows, int cols) {
+    const long n = (long)rows * cols;
+    const float inv = sig[1], coef = gw[0] * inv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int r = (int)(i / cols), c = (int)(i - (long)r * cols);
+        out[i] = (G[i] - coef * u[r] * v[c]) * inv;
+    }
+}
+// reference conv weight [Cout][Cin][KH][KW] fp32 <-> GEMM layout [Cout][(kh*KW+kw)*Cin + ci] padded to Kp
+template <typename T>
+__global__ __launch_bounds__(256) void conv_weight_pack_kernel(const float* w, T* out, int Cout, int Cin, int KH, int KW, int Kp) {
+    const long n = (long)Cout * Kp;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int k = (int)(i % Kp), co = (int)(i / Kp);
+        float v = 0.f;
+        if (k < KH * KW * Cin) { const int ci = k % Cin, t = k / Cin; v = w[(((long)co * Cin + ci) * KH + t / KW) * KW + t % KW]; }
+        out[i] = from_f32<T>(v);
+    }
+}
+__global__ __launch_bounds__(256) void conv_weight_unpack_kernel(const float* packed, float* w, int Cout, int Cin, int KH, int KW, int Kp) {
+    const long n = (long)Cout * Cin * KH * KW;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int kw = (int)(i % KW), kh = (int)((i / KW) % KH), ci = (int)((i / ((long)KW * KH)) % Cin), co = (int)(i / ((long)KW * KH * Cin));
+        w[i] = packed[(long)co * Kp + (kh * KW + kw) * Cin + ci];
+    }
+}
+__global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, double* acc) {
+    double a = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a += (double)g[i] * (double)g[i];
+    a = wave_sum_d(a);
+    if ((threadIdx.x & 63) == 0) atomicAdd(acc, a);
+}
+// torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)); out = {coef, total_norm}
+__global__ void clip_coef_kernel(const double* sumsq, float max_norm, float* out) {
+    const float tn = (float)sqrt(sumsq[0]);
+    out[0] = fminf(1.f, max_norm / (tn + 1e-6f));
+    out[1] = tn;
+}
+// torch.optim.AdamW step on one tensor; gscale (device scalar, may be NULL) multiplies the gradient first
+__global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, const float* g, float* m, float* v, long n, float lr, float b1, float b2,
+                                                        float eps, float wd, float bc1, float bc2s, const float* gscale) {
+    const float gs = gscale ? gscale[0] : 1.f;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float gi = g[i] * gs;
+        float pi = p[i] * (1.f - lr * wd);
+        const float mi = m[i] * b1 + (1.f - b1) * gi;
+        const float vi = v[i] * b2 + (1.f - b2) * gi * gi;
+        pi -= (lr / bc1) * (mi / (sqrtf(vi) / bc2s + eps));
+        p[i] = pi; m[i] = mi; v[i] = vi;
+    }
+}
 
 // ------------------------------------------------------------------------------------------------------------
 // C ABI
@@ -450,6 +532,11 @@ int sgv_op_linear_fwd(const float* x, const float* W, const float* bias, const f
     hipLaunchKernelGGL(linear_fwd_kernel, dim3(O, B), dim3(64), 0, ST(stream), x, W, bias, scale, y, K, O, act);
     return OPLAUNCH_OK();
 }
+int sgv_op_act_fwd(const float* x, float* y, long n, int act, void* stream) {
+    OPCHK(x && y && n > 0, "sgv_op_act_fwd: bad argument");
+    hipLaunchKernelGGL(act_fwd_kernel, grid1(n), dim3(256), 0, ST(stream), x, y, n, act);
+    return OPLAUNCH_OK();
+}
 int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, void* stream) {
     OPCHK(y && dy && dz && n > 0, "sgv_op_act_bwd: bad argument");
     hipLaunchKernelGGL(act_bwd_kernel, grid1(n), dim3(256), 0, ST(stream), y, dy, dz, n, act);
@@ -527,6 +614,52 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
     const int r = launch_gemm_tn(dtype, p, ST(stream));
     if (r) return sgv_set_error(-1, "sgv_op_gemm_tn: launch rejected (%d) for M=%d N1=%d N2=%d", r, M, N1, N2);
     return 0;
+}
+// ---- parameter-side helpers --------------------------------------------------------------------------------
+int sgv_op_l2_normalize(const float* x, float* out, long n, float eps, void* stream) {
+    OPCHK(x && out && n > 0, "sgv_op_l2_normalize: bad argument");
+    hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, ST(stream), x, out, n, eps);
+    return OPLAUNCH_OK();
+}
+int sgv_op_dot(const float* a, const float* b, float* out2, long n, void* stream) {
+    OPCHK(a && b && out2 && n > 0, "sgv_op_dot: bad argument");
+    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, ST(stream), a, b, out2, n);
+    return OPLAUNCH_OK();
+}
+int sgv_op_sn_grad(const float* G, const float* u, const float* v, const float* gw, const float* sigma2, float* out, int rows, int cols,
+                   void* stream) {
+    OPCHK(G && u && v && gw && sigma2 && out && rows > 0 && cols > 0, "sgv_op_sn_grad: bad argument");
+    hipLaunchKernelGGL(sn_grad_kernel, grid1((long)rows * cols), dim3(256), 0, ST(stream), G, u, v, gw, sigma2, out, rows, cols);
+    return OPLAUNCH_OK();
+}
+int sgv_op_conv_weight_pack(int dtype, const float* w, void* packed, int Cout, int Cin, int KH, int KW, void* stream) {
+    OPCHK(w && packed && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "sgv_op_conv_weight_pack: bad argument");
+    const int Kp = (KH * KW * Cin + 7) / 8 * 8;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(conv_weight_pack_kernel<T>, grid1((long)Cout * Kp), dim3(256), 0, ST(stream), w, PT(packed), Cout, Cin, KH, KW, Kp));
+    return OPLAUNCH_OK();
+}
+int sgv_op_conv_weight_unpack(const float* packed, float* w, int Cout, int Cin, int KH, int KW, void* stream) {
+    OPCHK(w && packed && Cout > 0 && Cin > 0 && KH > 0 && KW > 0, "sgv_op_conv_weight_unpack: bad argument");
+    const int Kp = (KH * KW * Cin + 7) / 8 * 8;
+    hipLaunchKernelGGL(conv_weight_unpack_kernel, grid1((long)Cout * Cin * KH * KW), dim3(256), 0, ST(stream), packed, w, Cout, Cin, KH, KW, Kp);
+    return OPLAUNCH_OK();
+}
+int sgv_op_sumsq(const float* g, long n, double* acc, void* stream) {
+    OPCHK(g && acc && n > 0, "sgv_op_sumsq: bad argument");
+    hipLaunchKernelGGL(sumsq_kernel, grid1(n), dim3(256), 0, ST(stream), g, n, acc);
+    return OPLAUNCH_OK();
+}
+int sgv_op_clip_coef(const double* sumsq, float max_norm, float* out2, void* stream) {
+    OPCHK(sumsq && out2, "sgv_op_clip_coef: bad argument");
+    hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(1), 0, ST(stream), sumsq, max_norm, out2);
+    return OPLAUNCH_OK();
+}
+int sgv_op_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
+                 int step, const float* gscale, void* stream) {
+    OPCHK(p && g && m && v && n > 0 && step >= 1, "sgv_op_adamw: bad argument");
+    const float bc1 = (float)(1.0 - pow((double)beta1, (double)step)), bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+    hipLaunchKernelGGL(adamw_flat_kernel, grid1(n), dim3(256), 0, ST(stream), p, g, m, v, n, lr, beta1, beta2, eps, weight_decay, bc1, bc2s, gscale);
+    return OPLAUNCH_OK();
 }
 // [Bn][I][J] -> [Bn][J][I] with dtype conversion (NCHW fp32 <-> channels-last compute dtype)
 int sgv_op_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, void* stream) {

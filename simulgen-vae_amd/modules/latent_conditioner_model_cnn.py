@@ -1,0 +1,415 @@
+"""`LatentConditionerImg` with the constructor / call surface of the reference's
+modules.latent_conditioner_model_cnn.LatentConditionerImg (latent_conditioner_model_cnn.py:138-362), on the MI355X.
+
+The layer graph and its hand-derived backward live here on the host; every tensor operation is a HIP kernel behind the
+operator-level C ABI (include/sgvae_ops.h, `simulgen_vae_amd.ops`): convolutions are im2col + the MFMA GEMMs of the VAE
+path, feature maps are channels-last [B, H, W, C] in the compute dtype, the heads are fp32.  torch supplies device
+memory, the stream and the random bits of the dropout masks -- nothing else (the two data-dependent input-range lines
+of the reference forward, `if x.min() < -0.1: x = (x + 1) / 2`, are kept as a torch expression on the input batch).
+
+  m = LatentConditionerImg(latent_conditioner_filter, latent_dim_end, input_shape, latent_dim, size2,
+                           latent_conditioner_data_shape, dropout_rate=0.3, use_attention=True, return_dict=False)
+  latent_main, xs = m(x)                       # x: [B, H*W] flattened square images, as in the reference
+  m.state_dict() / m.load_state_dict(sd)       # the reference's 148 keys (weight_orig / weight_u / weight_v, running stats)
+  m.train() / m.eval(), m.to(device), m.parameters() (names + tensors)
+Training (what latent_conditioner.py:246-314 does around `latent_conditioner(x)`): `m.loss_backward(x, y1, y2)` runs the
+forward, the loss 10*MSE(y1) + MSE(y2) and the backward and leaves `m.grads`; `modules.latent_conditioner` drives it."""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+
+from .. import ops
+from ..engine import SgvError
+
+_GROUPS = (32, 16, 8, 4, 2, 1)
+
+
+def _num_groups(channels):
+    for g in _GROUPS:
+        if channels % g == 0 and g <= channels:
+            return g
+    return 1
+
+
+class LatentConditionerImg:
+    def __init__(self, latent_conditioner_filter, latent_dim_end, input_shape, latent_dim, size2,
+                 latent_conditioner_data_shape, dropout_rate=0.3, use_attention=True, return_dict=False,
+                 compute_dtype="bf16", seed=0):
+        self.filters = [int(v) for v in latent_conditioner_filter]
+        self.latent_dim, self.size2, self.latent_dim_end = int(latent_dim), int(size2), int(latent_dim_end)
+        self.dropout_rate, self.use_attention, self.return_dict = float(dropout_rate), bool(use_attention), bool(return_dict)
+        self.compute_dtype = compute_dtype
+        self.dt = ops.tdtype(compute_dtype)
+        self.training = True
+        if any(c % 16 for c in self.filters):
+            raise SgvError("latent_conditioner_filter entries must be multiples of 16 (bottleneck channels feed 8-wide GEMM tiles)")
+        self.blocks = []
+        cin = self.filters[0]
+        for i, cout in enumerate(self.filters[1:]):
+            stride = 2 if i in (1, 3) else 1
+            self.blocks.append(dict(i=i, cin=cin, cout=cout, mid=cout // 2, stride=stride,
+                                    skip=(stride != 1 or cin != cout), se=self.use_attention and 2 <= i <= 4))
+            cin = cout
+        self.final_c = self.filters[-1]
+        self.hidden = self.final_c * 2
+        self.P = {}            # parameters and buffers, reference names, fp32 CUDA tensors
+        self.grads = {}
+        self._tape = None
+        self._init_state(seed)
+
+    # ---- parameters -------------------------------------------------------------------------------------------------
+    def _spec(self):
+        """(name, shape, kind) in the reference's state_dict order; kind: w (trainable), u/v (spectral-norm vectors), buf."""
+        out = []
+
+        def sn_conv(prefix, co, ci, k):
+            out.extend([(prefix + ".weight_orig", (co, ci, k, k), "w"), (prefix + ".weight_u", (co,), "u"), (prefix + ".weight_v", (ci * k * k,), "v")])
+
+        def gn(prefix, c):
+            out.extend([(prefix + ".weight", (c,), "w"), (prefix + ".bias", (c,), "w")])
+
+        def sn_lin(prefix, o, k):
+            out.extend([(prefix + ".bias", (o,), "w"), (prefix + ".weight_orig", (o, k), "w"), (prefix + ".weight_u", (o,), "u"), (prefix + ".weight_v", (k,), "v")])
+
+        def lin(prefix, o, k):
+            out.extend([(prefix + ".weight", (o, k), "w"), (prefix + ".bias", (o,), "w")])
+
+        def bn(prefix, c):
+            out.extend([(prefix + ".weight", (c,), "w"), (prefix + ".bias", (c,), "w"), (prefix + ".running_mean", (c,), "buf"),
+                        (prefix + ".running_var", (c,), "buf"), (prefix + ".num_batches_tracked", (), "buf")])
+        sn_conv("initial_conv.0", self.filters[0], 1, 7)
+        gn("initial_conv.1", self.filters[0])
+        for b in self.blocks:
+            p = f"layers.{b['i']}"
+            sn_conv(p + ".conv1", b["mid"], b["cin"], 1)
+            gn(p + ".gn1", b["mid"])
+            sn_conv(p + ".conv2", b["cout"], b["mid"], 3)
+            gn(p + ".gn2", b["cout"])
+            if b["skip"]:
+                sn_conv(p + ".skip.0", b["cout"], b["cin"], 1)
+                gn(p + ".skip.1", b["cout"])
+            if b["se"]:
+                lin(p + ".se.fc1", b["cout"] // 16, b["cout"])
+                lin(p + ".se.fc2", b["cout"], b["cout"] // 16)
+        h = self.hidden
+        sn_lin("feature_processor.1", h, self.final_c)
+        gn("feature_processor.2", h)
+        sn_lin("feature_processor.5", h, h)
+        gn("feature_processor.6", h)
+        for head, odim in (("latent_main", self.latent_dim_end), ("xs", self.latent_dim * self.size2)):
+            l1, l2 = (head + "_layer1", head + "_layer2")
+            sn_lin(l1 + ".0", h // 2, h)
+            bn(l1 + ".1", h // 2)
+            sn_lin(l2 + ".0", h // 4, h // 2)
+            bn(l2 + ".1", h // 4)
+            lin("main_skip_proj" if head == "latent_main" else "xs_skip_proj", h // 4, h)
+            lin(head + "_output", odim, h // 4)
+        return out
+
+    def _init_state(self, seed):
+        """Same distributions as the reference's `_init_weights` (kaiming_normal fan_out for convs and hidden Linears,
+        xavier_normal for the two output layers, zero biases, unit norms); values come from numpy Philox, so parity
+        tests load the reference's own state instead."""
+        rng = np.random.Generator(np.random.Philox(seed))
+        for name, shape, kind in self._spec():
+            if kind == "u" or kind == "v":
+                a = rng.standard_normal(shape).astype(np.float32)
+                a /= max(float(np.linalg.norm(a)), 1e-12)
+            elif name.endswith("num_batches_tracked"):
+                a = np.zeros((), np.float32)
+            elif name.endswith("running_var"):
+                a = np.ones(shape, np.float32)
+            elif name.endswith("running_mean") or name.endswith(".bias"):
+                a = np.zeros(shape, np.float32)
+            elif len(shape) == 1:
+                a = np.ones(shape, np.float32)                      # GroupNorm / LayerNorm / BatchNorm weights
+            elif len(shape) == 4:
+                a = (rng.standard_normal(shape) * math.sqrt(2.0 / (shape[0] * shape[2] * shape[3]))).astype(np.float32)
+            elif shape[0] in (self.latent_dim_end, self.latent_dim * self.size2):
+                a = (rng.standard_normal(shape) * math.sqrt(2.0 / (shape[0] + shape[1]))).astype(np.float32)
+            else:
+                a = (rng.standard_normal(shape) * math.sqrt(2.0 / shape[0])).astype(np.float32)
+            self.P[name] = torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+    def state_dict(self):
+        out = {}
+        for name, shape, kind in self._spec():
+            t = self.P[name].detach().cpu().clone()
+            out[name] = t.to(torch.int64) if name.endswith("num_batches_tracked") else t
+        return out
+
+    def load_state_dict(self, sd, strict=True):
+        names = [n for n, _, _ in self._spec()]
+        missing = [n for n in names if n not in sd]
+        extra = [k for k in sd if k not in names]
+        if strict and (missing or extra):
+            raise RuntimeError(f"Error(s) in loading state_dict: missing {missing[:4]}, unexpected {extra[:4]}")
+        for name, shape, _ in self._spec():
+            if name in sd:
+                v = sd[name]
+                a = torch.as_tensor(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v), dtype=torch.float32)
+                if tuple(a.shape) != tuple(shape):
+                    raise RuntimeError(f"size mismatch for {name}: {tuple(a.shape)} vs {tuple(shape)}")
+                self.P[name] = a.contiguous().cuda()
+        return self
+
+    def named_parameters(self):
+        return [(n, self.P[n]) for n, _, k in self._spec() if k == "w"]
+
+    def parameters(self):
+        return [t for _, t in self.named_parameters()]
+
+    def train(self, mode=True):
+        self.training = bool(mode)
+        return self
+
+    def eval(self):
+        return self.train(False)
+
+    def to(self, device=None, *a, **k):
+        if device is not None and str(device).startswith("cpu"):
+            raise SgvError("this model only runs on an MI355X: there is no CPU path")
+        return self
+
+    def apply(self, fn):
+        """latent_conditioner.apply(safe_initialize_weights_He) (latent_conditioner.py:223): on the spectrally normalised
+        layers the reference's hook recomputes `.weight` from `weight_orig` at the next forward, so that call only
+        re-initialises the non-normalised Linear layers; accepted as a no-op here (parity runs load a state)."""
+        return self
+
+    # ---- layer helpers: each returns (output, backward closure) ---------------------------------------------------
+    def _acc(self, name, g):
+        self.grads[name] = g if name not in self.grads else ops.addf(self.grads[name], g)
+
+    def _sn(self, prefix, Wm):
+        return ops.sn_power_iteration(Wm, self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"], self.training)
+
+    def _conv(self, prefix, x4, k, stride, pad, need_dx=True):
+        W = self.P[prefix + ".weight_orig"]
+        co, ci = W.shape[0], W.shape[1]
+        Wm = W.view(co, -1)
+        sig2 = self._sn(prefix, Wm)
+        Wp = ops.conv_weight_pack(W, self.dt)
+        B, H, Wd, _ = x4.shape
+        direct = (k == 1 and stride == 1 and ci % 8 == 0)
+        if direct:
+            col, Ho, Wo = x4.view(-1, ci), H, Wd
+        else:
+            col, Ho, Wo = ops.im2col(x4, k, k, stride, pad)
+        y = ops.gemm_nt(col, Wp, scale=sig2[1:2]).view(B, Ho, Wo, co)
+        u, v = self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"]
+
+        def bwd(dy4):
+            dy = dy4.reshape(-1, co)
+            G = ops.conv_weight_unpack(ops.gemm_tn(dy, col), W.shape)           # gradient wrt W / sigma
+            self._acc(prefix + ".weight_orig", ops.sn_grad(G.view(co, -1), u, v, Wm, sig2).view(W.shape))
+            if not need_dx:
+                return None
+            Wt = ops.transpose(Wp.view(1, co, -1), self.dt, 1, co, Wp.shape[1]).view(Wp.shape[1], co)
+            dcol = ops.gemm_nt(dy, Wt, scale=sig2[1:2])
+            return dcol.view(x4.shape) if direct else ops.col2im(dcol, x4.shape, k, k, stride, pad)
+        return y, bwd
+
+    def _gn(self, prefix, y4, act):
+        B, H, Wd, Cc = y4.shape
+        G = _num_groups(Cc)
+        gamma, beta = self.P[prefix + ".weight"], self.P[prefix + ".bias"]
+        y3 = y4.view(B, H * Wd, Cc)
+        out, sums = ops.gn_fwd(y3, G, gamma, beta, act)
+
+        def bwd(dout4):
+            dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
+            dy = ops.gn_bwd(y3, dout4.reshape(B, H * Wd, Cc), G, gamma, beta, sums, act, dg, db)
+            self._acc(prefix + ".weight", dg)
+            self._acc(prefix + ".bias", db)
+            return dy.view(y4.shape)
+        return out.view(y4.shape), bwd
+
+    def _linear(self, prefix, x, sn, act=ops.LIN_NONE):
+        W = self.P[prefix + (".weight_orig" if sn else ".weight")]
+        b = self.P[prefix + ".bias"]
+        sig2 = self._sn(prefix, W) if sn else None
+        scale = sig2[1:2] if sn else None
+        y = ops.linear_fwd(x, W, b, scale, act)
+
+        def bwd(dy):
+            dz = ops.act_bwd(y, dy, act) if act != ops.LIN_NONE else dy
+            dx, dW, db = ops.linear_bwd(dz, x, W, scale)        # dx = scale * dz W ; dW = scale * dz^T x
+            self._acc(prefix + ".bias", db)
+            if sn:       # sn_grad wants G = dz^T x, the gradient wrt W / sigma
+                G = ops.linear_bwd(dz, x, W, None, need_dx=False, has_bias=False)[1]
+                self._acc(prefix + ".weight_orig", ops.sn_grad(G, self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"], W, sig2))
+            else:
+                self._acc(prefix + ".weight", dW)
+            return dx
+        return y, bwd
+
+    def _dropout(self, x, p, masks):
+        if not self.training or p == 0.0:
+            return x, (lambda d: d)
+        if masks is not None:
+            mask = masks.pop(0)
+        else:
+            mask = (torch.rand(x.shape, device=x.device) >= p).float()
+        scale = 1.0 / (1.0 - p)
+        return ops.mask_scale(x, mask, scale), (lambda d: ops.mask_scale(d, mask, scale))
+
+    def _layernorm(self, prefix, x):
+        gamma, beta = self.P[prefix + ".weight"], self.P[prefix + ".bias"]
+        y, stat = ops.layernorm_fwd(x, gamma, beta)
+
+        def bwd(dy):
+            dx, dg, db = ops.layernorm_bwd(x, gamma, stat, dy)
+            self._acc(prefix + ".weight", dg)
+            self._acc(prefix + ".bias", db)
+            return dx
+        return y, bwd
+
+    def _batchnorm(self, prefix, x):
+        gamma, beta = self.P[prefix + ".weight"], self.P[prefix + ".bias"]
+        train = self.training
+        y, stat = ops.batchnorm_fwd(x, gamma, beta, self.P[prefix + ".running_mean"], self.P[prefix + ".running_var"], train)
+        if train:
+            self.P[prefix + ".num_batches_tracked"] = self.P[prefix + ".num_batches_tracked"] + 1
+
+        def bwd(dy):
+            dx, dg, db = ops.batchnorm_bwd(x, gamma, stat, dy, train)
+            self._acc(prefix + ".weight", dg)
+            self._acc(prefix + ".bias", db)
+            return dx
+        return y, bwd
+
+    def _relu(self, x):
+        y = ops.act_fwd(x, ops.LIN_RELU)
+        return y, (lambda d: ops.act_bwd(y, d, ops.LIN_RELU))
+
+    def _block(self, b, x4):
+        p = f"layers.{b['i']}"
+        c1, bw_c1 = self._conv(p + ".conv1", x4, 1, 1, 0)
+        a1, bw_g1 = self._gn(p + ".gn1", c1, ops.ACT_RELU_GN)
+        c2, bw_c2 = self._conv(p + ".conv2", a1, 3, b["stride"], 1)
+        o2, bw_g2 = self._gn(p + ".gn2", c2, ops.ACT_NONE)
+        B, H, Wd, Cc = o2.shape
+        if b["se"]:
+            o2f = o2.view(B, H * Wd, Cc)
+            pooled = ops.avgpool_fwd(o2f)
+            hid, bw_f1 = self._linear(p + ".se.fc1", pooled, False, ops.LIN_RELU)
+            s, bw_f2 = self._linear(p + ".se.fc2", hid, False, ops.LIN_SIGMOID)
+            o3 = ops.chan_scale_fwd(o2f, s).view(o2.shape)
+        else:
+            o3 = o2
+        if b["skip"]:
+            sc, bw_sc = self._conv(p + ".skip.0", x4, 1, b["stride"], 0)
+            sk, bw_sg = self._gn(p + ".skip.1", sc, ops.ACT_NONE)
+        else:
+            sk = x4
+        out = ops.add_relu(o3, sk)
+
+        def bwd(dout):
+            d = ops.relu_bwd(out, dout)
+            if b["se"]:
+                dx_scale, ds = ops.chan_scale_bwd(o2f, s, d.view(B, H * Wd, Cc))
+                dpool = bw_f1(bw_f2(ds))
+                d_o2 = ops.avgpool_bwd(dpool, dx_scale).view(o2.shape)
+            else:
+                d_o2 = d
+            dx_main = bw_c1(bw_g1(bw_c2(bw_g2(d_o2))))
+            dx_skip = bw_sc(bw_sg(d)) if b["skip"] else d
+            return ops.add(dx_main, dx_skip)
+        return out, bwd
+
+    # ---- forward / backward -----------------------------------------------------------------------------------------
+    def forward(self, x, dropout_masks=None):
+        """x: [B, H*W] (or anything reshapeable to it) -> (latent_main [B, latent_dim_end], xs [B, size2, latent_dim])."""
+        if not torch.is_tensor(x):
+            x = torch.as_tensor(np.asarray(x))
+        x = x.to(device="cuda", dtype=torch.float32)
+        B = x.shape[0]
+        side = int(math.sqrt(x.shape[-1]))
+        x = x.reshape(B, side, side)
+        if float(x.min()) < -0.1:          # reference forward: inputs in [-1, 1] are mapped to [0, 1]
+            x = (x + 1) / 2
+        masks = list(dropout_masks) if dropout_masks is not None else None
+        self.grads = {}
+        back = []
+        x4 = x.to(self.dt).contiguous().view(B, side, side, 1)
+        c0, bw = self._conv("initial_conv.0", x4, 7, 1, 3, need_dx=False)
+        back.append(bw)
+        a0, bw = self._gn("initial_conv.1", c0, ops.ACT_RELU_GN)
+        back.append(bw)
+        h = ops.maxpool_fwd(a0)
+        back.append(lambda d, a0=a0: ops.maxpool_bwd(a0, d))
+        for b in self.blocks:
+            h, bw = self._block(b, h)
+            back.append(bw)
+        Bh, H, Wd, Cc = h.shape
+        feat = ops.avgpool_fwd(h.view(Bh, H * Wd, Cc))
+        back.append(lambda d, shp=(Bh, H * Wd, Cc), s4=h.shape: ops.avgpool_bwd(d, shp, self.dt).view(s4))
+        r = self.dropout_rate
+        f = feat
+        for step in (lambda t: self._dropout(t, r * 0.3, masks), lambda t: self._linear("feature_processor.1", t, True),
+                     lambda t: self._layernorm("feature_processor.2", t), self._relu, lambda t: self._dropout(t, r * 0.4, masks),
+                     lambda t: self._linear("feature_processor.5", t, True), lambda t: self._layernorm("feature_processor.6", t),
+                     self._relu, lambda t: self._dropout(t, r * 0.4, masks)):
+            f, bw = step(f)
+            back.append(bw)
+        features = f
+
+        def head(name, skip_name, out_name):
+            t, chain = features, []
+            for step in (lambda z: self._linear(name + "_layer1.0", z, True), lambda z: self._batchnorm(name + "_layer1.1", z), self._relu,
+                         lambda z: self._dropout(z, r * 0.3, masks),
+                         lambda z: self._linear(name + "_layer2.0", z, True), lambda z: self._batchnorm(name + "_layer2.1", z), self._relu,
+                         lambda z: self._dropout(z, 0.2, masks)):
+                t, bw_ = step(t)
+                chain.append(bw_)
+            sk, bw_sk = self._linear(skip_name, features, False)
+            comb = ops.addf(t, sk)
+            o, bw_o = self._linear(out_name, comb, False)
+
+            def bwd(do):
+                dc = bw_o(do)
+                d = dc
+                for fn in reversed(chain):
+                    d = fn(d)
+                return ops.addf(d, bw_sk(dc))
+            return o, bwd
+        main, bw_main = head("latent_main", "main_skip_proj", "latent_main_output")
+        xs, bw_xs = head("xs", "xs_skip_proj", "xs_output")
+
+        def backward(d_main, d_xs):
+            d = ops.addf(bw_main(d_main.contiguous()), bw_xs(d_xs.reshape(B, -1).contiguous()))
+            for fn in reversed(back):
+                d = fn(d)
+                if d is None:
+                    break
+            return self.grads
+        self._tape = backward
+        xs3 = xs.view(B, self.size2, self.latent_dim)
+        if self.return_dict:
+            return {"latent_main": main, "xs": xs3, "features": features}
+        return main, xs3
+
+    __call__ = forward
+
+    def backward(self, d_main, d_xs):
+        if self._tape is None:
+            raise SgvError("backward() needs a preceding forward()")
+        g = self._tape(d_main, d_xs)
+        self._tape = None
+        return g
+
+    def loss_backward(self, x, y1, y2, dropout_masks=None):
+        """latent_conditioner.py:285-301: forward, A = MSE(y_pred1, y1), B = MSE(y_pred2, y2), loss = 10*A + B, backward.
+        Returns (loss, A, B) as floats; gradients are left in `self.grads` keyed by parameter name."""
+        p1, p2 = self.forward(x, dropout_masks)
+        y1 = torch.as_tensor(y1).to(device="cuda", dtype=torch.float32).contiguous()
+        y2 = torch.as_tensor(y2).to(device="cuda", dtype=torch.float32).contiguous()
+        la, d1 = ops.mse(p1, y1, gscale=10.0)
+        lb, d2 = ops.mse(p2.reshape(p2.shape[0], -1), y2.reshape(y2.shape[0], -1), gscale=1.0)
+        self.backward(d1, d2)
+        A, Bv = float(la), float(lb)
+        return 10.0 * A + Bv, A, Bv

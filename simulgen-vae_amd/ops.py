@@ -15,9 +15,10 @@ OPS_SYMBOLS = [
     "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gn_fwd",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
-    "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
+    "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
     "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
-    "sgv_op_mse", "sgv_op_transpose",
+    "sgv_op_mse", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
+    "sgv_op_conv_weight_unpack", "sgv_op_sumsq", "sgv_op_clip_coef", "sgv_op_adamw",
 ]
 ACT_NONE, ACT_RELU_GN = 0, 3            # GroupNorm activation ids (ew.hip)
 LIN_NONE, LIN_RELU, LIN_SIGMOID = 0, 1, 2
@@ -49,6 +50,7 @@ def lib():
             "sgv_op_chan_scale_fwd": [i, vp, vp, vp, i, i, i, vp],
             "sgv_op_chan_scale_bwd": [i, vp, vp, vp, vp, vp, i, i, i, vp],
             "sgv_op_linear_fwd": [vp, vp, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_act_fwd": [vp, vp, lg, i, vp],
             "sgv_op_act_bwd": [vp, vp, vp, lg, i, vp],
             "sgv_op_linear_bwd": [vp, vp, vp, vp, vp, i, vp, vp, i, i, i, vp],
             "sgv_op_layernorm_fwd": [vp, vp, vp, vp, vp, i, i, vp],
@@ -59,6 +61,14 @@ def lib():
             "sgv_op_addf": [vp, vp, vp, lg, vp],
             "sgv_op_mse": [vp, vp, vp, vp, f, lg, vp],
             "sgv_op_transpose": [i, i, vp, vp, i, i, i, vp],
+            "sgv_op_l2_normalize": [vp, vp, lg, f, vp],
+            "sgv_op_dot": [vp, vp, vp, lg, vp],
+            "sgv_op_sn_grad": [vp, vp, vp, vp, vp, vp, i, i, vp],
+            "sgv_op_conv_weight_pack": [i, vp, vp, i, i, i, i, vp],
+            "sgv_op_conv_weight_unpack": [vp, vp, i, i, i, i, vp],
+            "sgv_op_sumsq": [vp, lg, vp, vp],
+            "sgv_op_clip_coef": [vp, f, vp, vp],
+            "sgv_op_adamw": [vp, vp, vp, vp, lg, f, f, f, f, f, i, vp, vp],
         }
         for name, args in sig.items():
             getattr(l, name).argtypes = args
@@ -222,6 +232,12 @@ def linear_fwd(x, W, bias=None, scale=None, act=LIN_NONE):
     return y
 
 
+def act_fwd(x, act):
+    y = torch.empty_like(x)
+    _ck(lib().sgv_op_act_fwd(_p(x), _p(y), x.numel(), act, _stream()), "sgv_op_act_fwd")
+    return y
+
+
 def act_bwd(y, dy, act):
     dz = torch.empty_like(y)
     _ck(lib().sgv_op_act_bwd(_p(y), _p(dy), _p(dz), y.numel(), act, _stream()), "sgv_op_act_bwd")
@@ -295,3 +311,66 @@ def transpose(src, dst_dtype, Bn, I, J):
     dst = torch.empty((Bn, J, I), dtype=dst_dtype, device=src.device)
     _ck(lib().sgv_op_transpose(_d(src), 1 if dst_dtype == torch.bfloat16 else 0, _p(src), _p(dst), Bn, I, J, _stream()), "sgv_op_transpose")
     return dst
+
+
+# ---- parameter side ----
+def l2_normalize(x, eps=1e-12):
+    out = torch.empty_like(x)
+    _ck(lib().sgv_op_l2_normalize(_p(x), _p(out), x.numel(), float(eps), _stream()), "sgv_op_l2_normalize")
+    return out
+
+
+def dot(a, b):
+    """-> fp32 [2] = {a.b, 1/(a.b)}"""
+    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    _ck(lib().sgv_op_dot(_p(a), _p(b), _p(out), a.numel(), _stream()), "sgv_op_dot")
+    return out
+
+
+def sn_power_iteration(Wm, u, v, train):
+    """Legacy spectral norm on the [rows, cols] fp32 matrix view of a weight: updates u, v in place when `train`,
+    returns sigma2 = {sigma, 1/sigma} (device)."""
+    rows, cols = Wm.shape
+    if train:
+        wtu, _, _ = linear_bwd(u.view(1, rows), v.view(1, cols), Wm, need_dx=True, has_bias=False)      # W^T u  ([1, cols])
+        v.copy_(l2_normalize(wtu.view(-1)))
+        u.copy_(l2_normalize(linear_fwd(v.view(1, cols), Wm).view(-1)))
+    return dot(u, linear_fwd(v.view(1, cols), Wm).view(-1))
+
+
+def sn_grad(G, u, v, Wm, sigma2):
+    gw = dot(G.reshape(-1), Wm.reshape(-1))
+    out = torch.empty_like(G)
+    rows, cols = Wm.shape
+    _ck(lib().sgv_op_sn_grad(_p(G), _p(u), _p(v), _p(gw), _p(sigma2), _p(out), rows, cols, _stream()), "sgv_op_sn_grad")
+    return out
+
+
+def conv_weight_pack(w, dtype):
+    Cout, Cin, KH, KW = w.shape
+    Kp = (KH * KW * Cin + 7) // 8 * 8
+    out = torch.empty((Cout, Kp), dtype=dtype, device=w.device)
+    _ck(lib().sgv_op_conv_weight_pack(1 if dtype == torch.bfloat16 else 0, _p(w), _p(out), Cout, Cin, KH, KW, _stream()), "sgv_op_conv_weight_pack")
+    return out
+
+
+def conv_weight_unpack(packed, shape):
+    Cout, Cin, KH, KW = shape
+    w = torch.empty(shape, dtype=torch.float32, device=packed.device)
+    _ck(lib().sgv_op_conv_weight_unpack(_p(packed), _p(w), Cout, Cin, KH, KW, _stream()), "sgv_op_conv_weight_unpack")
+    return w
+
+
+def sumsq(g, acc):
+    _ck(lib().sgv_op_sumsq(_p(g), g.numel(), _p(acc), _stream()), "sgv_op_sumsq")
+
+
+def clip_coef(sumsq_acc, max_norm):
+    out = torch.empty(2, dtype=torch.float32, device=sumsq_acc.device)
+    _ck(lib().sgv_op_clip_coef(_p(sumsq_acc), float(max_norm), _p(out), _stream()), "sgv_op_clip_coef")
+    return out
+
+
+def adamw(p, g, m, v, lr, step, weight_decay, gscale=None, betas=(0.9, 0.999), eps=1e-8):
+    _ck(lib().sgv_op_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
+                           float(weight_decay), int(step), _p(gscale), _stream()), "sgv_op_adamw")
