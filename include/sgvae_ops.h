@@ -76,6 +76,14 @@ int sgv_op_batchnorm_bwd(const float* x, const float* gamma, const float* stat, 
 int sgv_op_mask_scale(const float* a, const float* mask, float scale, float* out, long n, void* stream);
 int sgv_op_addf(const float* a, const float* b, float* out, long n, void* stream);
 int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* dpred, float gscale, long n, void* stream);
+/* Input augmentation of the training loop (latent_conditioner.py:107-159,261-279) on [B][H][W] fp32 images, random
+ * draws made by the caller: flip_roll = torch.flip(dims=[2]) where flip[b] then torch.roll by (shift_x[b], shift_y[b]);
+ * affine_sample = F.affine_grid(theta [B][2][3], align_corners=False) + F.grid_sample(bilinear, 'border', False)
+ * (small rotation / scaling); mixup_rows: out[b] = lam*x[b] + (1-lam)*x[perm[b]] on rows of n floats. */
+int sgv_op_flip_roll(const float* x, float* out, int B, int H, int W, const int* flip, const int* shift_x, const int* shift_y, void* stream);
+int sgv_op_affine_sample(const float* x, float* out, int B, int H, int W, const float* theta, void* stream);
+int sgv_op_mixup_rows(const float* x, const int* perm, float lam, float* out, int B, long n, void* stream);
+
 /* Parameter side.  Legacy spectral norm (modules/common.py:15-37 -> torch nn/utils/spectral_norm.py): with the weight
  * as a [rows][cols] matrix, v = l2_normalize(W^T u), u = l2_normalize(W v) (eps 1e-12), sigma = u.(W v); the
  * mat-vecs are sgv_op_linear_fwd / sgv_op_linear_bwd with B = 1.  sgv_op_dot writes {a.b, 1/(a.b)}.

@@ -17,6 +17,7 @@ def install_reference_api():
     import sys
     pkg = importlib.import_module(__name__ + ".modules")
     sys.modules["modules"] = pkg
-    for sub in ("VAE_network", "train", "utils", "augmentation", "losses", "data_preprocess"):
+    for sub in ("VAE_network", "train", "utils", "augmentation", "losses", "data_preprocess", "latent_conditioner_model_cnn",
+                "latent_conditioner"):
         sys.modules["modules." + sub] = importlib.import_module(__name__ + ".modules." + sub)
     return pkg

@@ -402,6 +402,51 @@ __global__ __launch_bounds__(256) void adamw_flat_kernel(float* p, const float* 
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// input augmentation of the latent-conditioner loop (modules/latent_conditioner.py:107-159,261-279) on [B][H][W] fp32
+// ------------------------------------------------------------------------------------------------------------
+// torch.flip(dims=[2]) where flip[b], then torch.roll by (sx[b] along W, sy[b] along H), in that order
+__global__ __launch_bounds__(256) void flip_roll_kernel(const float* x, float* out, int B, int H, int W, const int* flip, const int* sx, const int* sy) {
+    const long n = (long)B * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+        int hs = (h - sy[b]) % H; if (hs < 0) hs += H;          // roll: out[h] = in[h - shift]
+        int ws = (w - sx[b]) % W; if (ws < 0) ws += W;
+        if (flip[b]) ws = W - 1 - ws;
+        out[i] = x[((long)b * H + hs) * W + ws];
+    }
+}
+// F.affine_grid(theta, align_corners=False) + F.grid_sample(bilinear, padding_mode='border', align_corners=False)
+__global__ __launch_bounds__(256) void affine_sample_kernel(const float* x, float* out, int B, int H, int W, const float* theta) {
+    const long n = (long)B * H * W;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int w = (int)(i % W), h = (int)((i / W) % H), b = (int)(i / ((long)W * H));
+        const float* t = theta + 6 * b;
+        if (t[0] == 1.f && t[1] == 0.f && t[2] == 0.f && t[3] == 0.f && t[4] == 1.f && t[5] == 0.f) {   // sample not selected: untouched
+            out[i] = x[i];
+            continue;
+        }
+        const float xn = (2.f * w + 1.f) / W - 1.f, yn = (2.f * h + 1.f) / H - 1.f;      // pixel centres in [-1, 1]
+        const float gx = t[0] * xn + t[1] * yn + t[2], gy = t[3] * xn + t[4] * yn + t[5];
+        float px = ((gx + 1.f) * W - 1.f) * 0.5f, py = ((gy + 1.f) * H - 1.f) * 0.5f;
+        px = fminf(fmaxf(px, 0.f), (float)(W - 1)); py = fminf(fmaxf(py, 0.f), (float)(H - 1));   // border padding
+        const int x0 = (int)floorf(px), y0 = (int)floorf(py);
+        const int x1 = min(x0 + 1, W - 1), y1 = min(y0 + 1, H - 1);
+        const float fx = px - x0, fy = py - y0;
+        const float* img = x + (long)b * H * W;
+        out[i] = (1.f - fy) * ((1.f - fx) * img[(long)y0 * W + x0] + fx * img[(long)y0 * W + x1]) +
+                 fy * ((1.f - fx) * img[(long)y1 * W + x0] + fx * img[(long)y1 * W + x1]);
+    }
+}
+// out[b] = lam * x[b] + (1 - lam) * x[perm[b]]   (rows of n floats)
+__global__ __launch_bounds__(256) void mixup_rows_kernel(const float* x, const int* perm, float lam, float* out, int B, long n) {
+    const long tot = (long)B * n;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < tot; i += (long)gridDim.x * 256) {
+        const int b = (int)(i / n);
+        out[i] = lam * x[i] + (1.f - lam) * x[(long)perm[b] * n + (i - (long)b * n)];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // C ABI
 // ------------------------------------------------------------------------------------------------------------
 static ConvGeom mk_geom(int B, int H, int W, int C, int KH, int KW, int S, int P) {
@@ -614,6 +659,22 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
     const int r = launch_gemm_tn(dtype, p, ST(stream));
     if (r) return sgv_set_error(-1, "sgv_op_gemm_tn: launch rejected (%d) for M=%d N1=%d N2=%d", r, M, N1, N2);
     return 0;
+}
+// ---- input augmentation ------------------------------------------------------------------------------------
+int sgv_op_flip_roll(const float* x, float* out, int B, int H, int W, const int* flip, const int* shift_x, const int* shift_y, void* stream) {
+    OPCHK(x && out && flip && shift_x && shift_y && B > 0 && H > 0 && W > 0, "sgv_op_flip_roll: bad argument");
+    hipLaunchKernelGGL(flip_roll_kernel, grid1((long)B * H * W), dim3(256), 0, ST(stream), x, out, B, H, W, flip, shift_x, shift_y);
+    return OPLAUNCH_OK();
+}
+int sgv_op_affine_sample(const float* x, float* out, int B, int H, int W, const float* theta, void* stream) {
+    OPCHK(x && out && theta && B > 0 && H > 0 && W > 0, "sgv_op_affine_sample: bad argument");
+    hipLaunchKernelGGL(affine_sample_kernel, grid1((long)B * H * W), dim3(256), 0, ST(stream), x, out, B, H, W, theta);
+    return OPLAUNCH_OK();
+}
+int sgv_op_mixup_rows(const float* x, const int* perm, float lam, float* out, int B, long n, void* stream) {
+    OPCHK(x && perm && out && B > 0 && n > 0, "sgv_op_mixup_rows: bad argument");
+    hipLaunchKernelGGL(mixup_rows_kernel, grid1((long)B * n), dim3(256), 0, ST(stream), x, perm, lam, out, B, n);
+    return OPLAUNCH_OK();
 }
 // ---- parameter-side helpers --------------------------------------------------------------------------------
 int sgv_op_l2_normalize(const float* x, float* out, long n, float eps, void* stream) {

@@ -156,6 +156,16 @@ class LatentConditionerImg:
                 self.P[name] = a.contiguous().cuda()
         return self
 
+    def __getstate__(self):
+        d = dict(self.__dict__)
+        d["P"] = {k: v.detach().cpu().numpy() for k, v in self.P.items()}
+        d["grads"], d["_tape"] = {}, None
+        return d
+
+    def __setstate__(self, d):
+        self.__dict__.update(d)
+        self.P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d["P"].items()}
+
     def named_parameters(self):
         return [(n, self.P[n]) for n, _, k in self._spec() if k == "w"]
 

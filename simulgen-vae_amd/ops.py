@@ -18,7 +18,8 @@ OPS_SYMBOLS = [
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
     "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
     "sgv_op_mse", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
-    "sgv_op_conv_weight_unpack", "sgv_op_sumsq", "sgv_op_clip_coef", "sgv_op_adamw",
+    "sgv_op_conv_weight_unpack", "sgv_op_sumsq", "sgv_op_clip_coef", "sgv_op_adamw", "sgv_op_flip_roll", "sgv_op_affine_sample",
+    "sgv_op_mixup_rows",
 ]
 ACT_NONE, ACT_RELU_GN = 0, 3            # GroupNorm activation ids (ew.hip)
 LIN_NONE, LIN_RELU, LIN_SIGMOID = 0, 1, 2
@@ -69,6 +70,9 @@ def lib():
             "sgv_op_sumsq": [vp, lg, vp, vp],
             "sgv_op_clip_coef": [vp, f, vp, vp],
             "sgv_op_adamw": [vp, vp, vp, vp, lg, f, f, f, f, f, i, vp, vp],
+            "sgv_op_flip_roll": [vp, vp, i, i, i, vp, vp, vp, vp],
+            "sgv_op_affine_sample": [vp, vp, i, i, i, vp, vp],
+            "sgv_op_mixup_rows": [vp, vp, f, vp, i, lg, vp],
         }
         for name, args in sig.items():
             getattr(l, name).argtypes = args
@@ -374,3 +378,35 @@ def clip_coef(sumsq_acc, max_norm):
 def adamw(p, g, m, v, lr, step, weight_decay, gscale=None, betas=(0.9, 0.999), eps=1e-8):
     _ck(lib().sgv_op_adamw(_p(p), _p(g), _p(m), _p(v), p.numel(), float(lr), float(betas[0]), float(betas[1]), float(eps),
                            float(weight_decay), int(step), _p(gscale), _stream()), "sgv_op_adamw")
+
+
+# ---- input augmentation ----
+def _ivec(v, device):
+    return torch.as_tensor(list(v), dtype=torch.int32, device=device)
+
+
+def flip_roll(x, flip, shift_x, shift_y):
+    """x fp32 [B, H, W]; per-sample flags / shifts (python sequences)."""
+    B, H, W = x.shape
+    out = torch.empty_like(x)
+    f, sx, sy = _ivec(flip, x.device), _ivec(shift_x, x.device), _ivec(shift_y, x.device)
+    _ck(lib().sgv_op_flip_roll(_p(x), _p(out), B, H, W, _p(f), _p(sx), _p(sy), _stream()), "sgv_op_flip_roll")
+    return out
+
+
+def affine_sample(x, theta):
+    """x fp32 [B, H, W]; theta fp32 [B, 2, 3] (device or host)."""
+    B, H, W = x.shape
+    th = torch.as_tensor(theta, dtype=torch.float32).to(x.device).contiguous()
+    out = torch.empty_like(x)
+    _ck(lib().sgv_op_affine_sample(_p(x), _p(out), B, H, W, _p(th), _stream()), "sgv_op_affine_sample")
+    return out
+
+
+def mixup_rows(x, perm, lam):
+    B = x.shape[0]
+    n = x.numel() // B
+    out = torch.empty_like(x)
+    pm = _ivec(perm, x.device)
+    _ck(lib().sgv_op_mixup_rows(_p(x), _p(pm), float(lam), _p(out), B, n, _stream()), "sgv_op_mixup_rows")
+    return out

@@ -201,3 +201,19 @@ def test_input_pipeline_host_side_matches_reference_fixture():
     rows = raw.reshape(-1, N)[idx]
     np.testing.assert_allclose(rows.min(0), g["data_min"], rtol=0, atol=0)     # the reference saw exactly these rows
     np.testing.assert_allclose(rows.max(0), g["data_max"], rtol=0, atol=0)
+
+
+def test_latent_conditioner_lr_schedule_matches_torch_schedulers():
+    """lc_learning_rate (closed form) vs the reference's LinearLR + CosineAnnealingLR pair stepped exactly as
+    latent_conditioner.py:196-209,358-361 does (warm-up scheduler for epoch < 100, cosine afterwards)."""
+    import torch
+    from simulgen_vae_amd.modules.latent_conditioner import lc_learning_rate
+    for epochs, base in ((300, 1e-3), (101, 5e-4), (150, 2e-3)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=base, weight_decay=1e-4)
+        warm = torch.optim.lr_scheduler.LinearLR(opt, start_factor=0.01, total_iters=100)
+        main = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=epochs - 100, eta_min=1e-8)
+        for epoch in range(epochs):
+            assert abs(opt.param_groups[0]["lr"] - lc_learning_rate(base, epochs, epoch)) <= 1e-9 * base + 1e-15, (epochs, epoch)
+            opt.step()
+            (warm if epoch < 100 else main).step()

@@ -257,3 +257,86 @@ def test_latent_conditioner_matches_reference_golden():
         if k.endswith("weight_u") or k.endswith("weight_v") or "running_" in k:
             assert rel(s1[k], torch.from_numpy(g["s1." + k])) < 2e-4, k
     assert int(s1["xs_layer2.1.num_batches_tracked"]) == 1
+
+
+def test_latent_conditioner_augmentation_kernels():
+    """flip / roll / small rotation / scaling (latent_conditioner.py:107-159) and mixup (:267-274) vs the torch calls the
+    reference makes, with injected random draws."""
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 5, 12, 12
+    x = torch.rand(B, H, W, generator=g)
+    flip, sx, sy = [1, 0, 1, 0, 0], [1, -1, 0, 0, 1], [0, 1, -1, 0, -1]
+    ref = x.clone()
+    fl = torch.flip(ref, dims=[2])
+    ref = torch.where(torch.tensor(flip).bool()[:, None, None], fl, ref)
+    for i in range(B):
+        if sx[i]:
+            ref[i] = torch.roll(ref[i], shifts=sx[i], dims=1)
+        if sy[i]:
+            ref[i] = torch.roll(ref[i], shifts=sy[i], dims=0)
+    assert torch.equal(ops.flip_roll(x.cuda(), flip, sx, sy).cpu(), ref)
+    th = torch.tensor([[[1, 0, 0], [0, 1, 0]]] * B, dtype=torch.float32)
+    a = math.radians(4.0)
+    th[1] = torch.tensor([[math.cos(a), -math.sin(a), 0], [math.sin(a), math.cos(a), 0]])
+    th[2] = torch.tensor([[0.96, 0, 0], [0, 0.96, 0]])
+    th[3] = torch.tensor([[1.04, 0, 0], [0, 1.04, 0]])
+    grid = F.affine_grid(th, (B, 1, H, W), align_corners=False)
+    want = F.grid_sample(x[:, None], grid, mode="bilinear", padding_mode="border", align_corners=False)[:, 0]
+    got = ops.affine_sample(x.cuda(), th)
+    assert rel(got, want) < 2e-6 and torch.equal(got[0].cpu(), x[0])          # identity theta reproduces the image exactly
+    rows = torch.randn(B, 37, generator=g)
+    perm = [3, 0, 4, 1, 2]
+    assert rel(ops.mixup_rows(rows.cuda(), perm, 0.3), 0.3 * rows + 0.7 * rows[perm]) < 1e-6
+
+
+def test_latent_conditioner_optimizer_and_training_loop(tmp_path, monkeypatch):
+    """clip_grad_norm_(10) + AdamW(lr 1e-3, wd 1e-4) step vs the parameters the reference held after its step (golden), then a
+    short run of train_latent_conditioner: log/return/files of the reference loop, loss going down on a fixed batch."""
+    import os
+    import random
+    from simulgen_vae_amd.modules.latent_conditioner_model_cnn import LatentConditionerImg
+    from simulgen_vae_amd.modules import latent_conditioner as lc
+    monkeypatch.chdir(tmp_path)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lc_small.npz"))
+    latent_end, latent, size2, img, B = (int(v) for v in g["meta"])
+    mk = lambda: LatentConditionerImg([int(v) for v in g["filters"]], latent_end, (1, img, img), latent, size2, (img, img), dropout_rate=0.3,
+                                      use_attention=True, compute_dtype="f32")
+    m = mk()
+    keys = [k[3:] for k in g.files if k.startswith("s0.")]
+    m.load_state_dict({k: torch.from_numpy(g["s0." + k]) for k in keys})
+    m.train()
+    masks = [torch.from_numpy(g[f"mask{i}"]).cuda() for i in range(7)]
+    m.loss_backward(torch.from_numpy(g["x"]), g["y1"], g["y2"], dropout_masks=masks)
+    opt, sched, _, warm = lc.setup_optimizer_and_scheduler(m, 1e-3, 1e-4, 300)
+    assert warm == 100 and abs(sched(0) - 1e-5) < 1e-12
+    total = opt.clip_and_step(max_norm=10.0, lr=1e-3)
+    assert abs(total - float(g["total_norm"][0])) < 1e-3 * float(g["total_norm"][0])
+    s1 = m.state_dict()
+    # the four Linear biases in front of a training-mode BatchNorm have a true gradient of exactly zero; the reference's
+    # ~1e-9 rounding noise there is turned into +-lr by Adam's first step, so those entries are not comparable
+    noise = {"latent_main_layer1.0.bias", "latent_main_layer2.0.bias", "xs_layer1.0.bias", "xs_layer2.0.bias"}
+    worst = max((rel(s1[n], torch.from_numpy(g["s1." + n])), n) for n, _ in m.named_parameters() if n not in noise)
+    assert worst[0] < 5e-4, worst            # first Adam step moves every weight by ~lr: a wrong gradient sign would show as >= 5e-3 here
+    for n in noise:
+        assert float((s1[n] - torch.from_numpy(g["s0." + n])).abs().max()) <= 1.001e-3
+    # short training run on a fixed tiny dataset (bf16 compute as in production)
+    random.seed(0)
+    np.random.seed(0)
+    torch.manual_seed(0)
+    m2 = LatentConditionerImg([int(v) for v in g["filters"]], latent_end, (1, img, img), latent, size2, (img, img), dropout_rate=0.1,
+                              use_attention=True, compute_dtype="bf16")
+    gen = torch.Generator().manual_seed(3)
+    data = [(torch.rand(8, img * img, generator=gen), torch.randn(8, latent_end, generator=gen) * 0.3, torch.randn(8, size2, latent, generator=gen) * 0.3)
+            for _ in range(2)]
+    m2.eval()
+    before = sum(10 * float(ops.mse(m2(x)[0], y1.cuda(), need_grad=False)[0]) for x, y1, _ in data)
+    val = lc.train_latent_conditioner(12, data, data[:1], m2, 2e-2, weight_decay=1e-5, is_image_data=True)
+    m2.eval()
+    after = sum(10 * float(ops.mse(m2(x)[0], y1.cuda(), need_grad=False)[0]) for x, y1, _ in data)
+    assert np.isfinite(val) and after < before
+    sd = torch.load("checkpoints/latent_conditioner.pth", weights_only=True)
+    assert list(sd.keys()) == keys
+    import pickle
+    m3 = pickle.load(open("model_save/LatentConditioner", "rb"))           # our own file, written a few lines above
+    m3.eval()
+    assert rel(m3(data[0][0])[0], m2(data[0][0])[0]) < 1e-6
