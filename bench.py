@@ -82,6 +82,48 @@ def cpu_baseline(sample_batch, cores, small=True):
     return sample_batch / dt, dt, r
 
 
+def bench_latent_conditioner(args):
+    """Secondary line: LatentConditionerImg training step (forward, 10*MSE+MSE, backward, clip, AdamW) on synthetic
+    [B, side*side] images, preset filters 32-64-128-256-512-1024, single GPU."""
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: there is no CPU fallback for the product path")
+    import simulgen_vae_amd  # noqa: F401
+    from simulgen_vae_amd.modules.latent_conditioner_model_cnn import LatentConditionerImg
+    from simulgen_vae_amd.modules.latent_conditioner import LCOptimizer
+    filters = [32, 64, 128, 256, 512, 1024]          # reference preset.txt:4 (latent_conditioner_filter)
+    B, side = args.batch, args.image
+    m = LatentConditionerImg(filters, LATENT, (1, side, side), HIER, len(ENC) - 1, (side, side), dropout_rate=0.2, use_attention=True,
+                             compute_dtype=args.dtype)
+    m.train()
+    opt = LCOptimizer(m, 1e-3, 1e-5)
+    g = torch.Generator(device="cuda").manual_seed(1)
+    x = torch.rand((B, side * side), generator=g, device="cuda")
+    y1 = torch.randn((B, LATENT), generator=g, device="cuda") * 0.3
+    y2 = torch.randn((B, len(ENC) - 1, HIER), generator=g, device="cuda") * 0.3
+
+    def step():
+        opt.zero_grad()
+        m.loss_backward(x, y1, y2)
+        opt.clip_and_step(10.0, 1e-3)
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    fwd_gf = {256: 304.9, 512: 1218.0}.get(side)       # SURVEY 8(f) N1, measured on the reference at batch 16
+    res = {"metric": "latent-conditioner training samples/sec (preset filters, batch 16)", "value": round(B * args.steps / el, 2), "unit": "samples/s",
+           "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic U(0,1) images, random-init weights",
+           "config": {"workload": f"LatentConditionerImg training step, {side}x{side} images, batch {B} (BASELINE.json configs[4])",
+                      "filters": filters, "image": side, "per_gpu_batch": B},
+           "step_tflops": round(3 * fwd_gf * (B / 16) / (el / args.steps) / 1e3, 2) if fwd_gf else None, "roofline": None, "cpu_baseline": None}
+    print(json.dumps(res), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -98,7 +140,12 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--layer-times", action="store_true", help="print a per-layer GEMM table (stderr) after the run")
+    ap.add_argument("--workload", default="vae", choices=["vae", "lc"],
+                    help="vae = the headline hot path; lc = image latent-conditioner training step (BASELINE.json configs[4], secondary)")
+    ap.add_argument("--image", type=int, default=512, help="lc: image side (configs[4] names 512x512)")
     args = ap.parse_args()
+    if args.workload == "lc":
+        return bench_latent_conditioner(args)
 
     import torch
     import torch.distributed as dist

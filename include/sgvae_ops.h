@@ -26,8 +26,11 @@ int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, in
  * (K, N multiples of 8; scale/bias/addend may be NULL; out_f32 = 1 writes fp32 instead of the compute dtype). */
 int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend,
                    int M, int N, int K, int out_f32, void* stream);
-/* dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]  (N1, N2 multiples of 8). */
-int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, void* stream);
+/* dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]  (N1, N2 multiples of 8).  The reduction runs over M = B*H*W rows:
+ * sgv_op_gemm_tn_splitk() returns the number of row slices to use, the caller passes that many N1*N2 fp32 slabs
+ * (slabs may be NULL when splitk == 1). */
+int sgv_op_gemm_tn_splitk(int dtype, int M, int N1, int N2);
+int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, float* slabs, int splitk, void* stream);
 
 /* nn.GroupNorm + optional ReLU (model_cnn.py:94,98,104,187-188; act: 0 none, 3 relu) on [B][P][C], C % 8 == 0,
  * G <= 32.  sums: B*G*2 doubles written by the forward and read by the backward; sums2: same size scratch;
@@ -86,14 +89,15 @@ int sgv_op_mixup_rows(const float* x, const int* perm, float lam, float* out, in
 
 /* Parameter side.  Legacy spectral norm (modules/common.py:15-37 -> torch nn/utils/spectral_norm.py): with the weight
  * as a [rows][cols] matrix, v = l2_normalize(W^T u), u = l2_normalize(W v) (eps 1e-12), sigma = u.(W v); the
- * mat-vecs are sgv_op_linear_fwd / sgv_op_linear_bwd with B = 1.  sgv_op_dot writes {a.b, 1/(a.b)}.
+ * mat-vecs are sgv_op_linear_fwd (W v) and sgv_op_matvec_t (W^T u).  sgv_op_dot writes {a.b, 1/(a.b)}.
  * sgv_op_sn_grad: gradient wrt weight_orig from the gradient G wrt W/sigma: (G - (<G,W_orig>/sigma) u v^T) / sigma,
  * gw = {<G,W_orig>}, sigma2 = {sigma, 1/sigma}.  conv_weight_pack/unpack: reference [Cout][Cin][KH][KW] fp32 <-> the
  * GEMM layout [Cout][(kh*KW+kw)*Cin+ci] padded to a multiple of 8 (compute dtype / fp32).
  * Gradient clipping (latent_conditioner.py:304): sumsq accumulates sum g^2 into a double, clip_coef writes
  * {min(1, max_norm/(norm+1e-6)), norm}; sgv_op_adamw = torch.optim.AdamW on one tensor with g scaled by gscale[0]. */
 int sgv_op_l2_normalize(const float* x, float* out, long n, float eps, void* stream);
-int sgv_op_dot(const float* a, const float* b, float* out2, long n, void* stream);
+int sgv_op_dot(const float* a, const float* b, float* out4, long n, void* stream);     /* out4: {a.b, 1/(a.b), 8 bytes of scratch} */
+int sgv_op_matvec_t(const float* W, const float* x, float* out, int rows, int cols, void* stream);   /* out = W^T x */
 int sgv_op_sn_grad(const float* G, const float* u, const float* v, const float* gw, const float* sigma2, float* out, int rows, int cols,
                    void* stream);
 int sgv_op_conv_weight_pack(int dtype, const float* w, void* packed, int Cout, int Cin, int KH, int KW, void* stream);

@@ -337,15 +337,28 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* x, float
     const float inv = 1.f / fmaxf(sqrtf(sm[0] + sm[1] + sm[2] + sm[3]), eps);
     for (long i = threadIdx.x; i < n; i += 256) out[i] = x[i] * inv;
 }
-// out[0] = sum a*b (fp32), out[1] = 1/out[0]; one block
-__global__ __launch_bounds__(256) void dot_kernel(const float* a, const float* b, float* out, long n) {
+// out4 = {sum a*b, 1/(sum a*b), <8-byte fp64 scratch>}: blocks accumulate into the scratch, dot_final converts
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* a, const float* b, double* acc, long n) {
     __shared__ double sm[4];
-    double acc = 0.0;
-    for (long i = threadIdx.x; i < n; i += 256) acc += (double)a[i] * (double)b[i];
-    acc = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    double x = 0.0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) x += (double)a[i] * (double)b[i];
+    x = wave_sum_d(x);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = x;
     __syncthreads();
-    if (threadIdx.x == 0) { const float d = (float)(sm[0] + sm[1] + sm[2] + sm[3]); out[0] = d; out[1] = 1.f / d; }
+    if (threadIdx.x == 0) atomicAdd(acc, sm[0] + sm[1] + sm[2] + sm[3]);
+}
+__global__ void dot_final_kernel(float* out4) {
+    const float d = (float)*reinterpret_cast<double*>(out4 + 2);
+    out4[0] = d; out4[1] = 1.f / d;
+}
+// out[c] += sum_{r in block} W[r][c] * x[r]   (W^T x; grid (cols/256, rows/64), out zeroed by the caller)
+__global__ __launch_bounds__(256) void matvec_t_kernel(const float* W, const float* x, float* out, int rows, int cols) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= cols) return;
+    const int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
+    float a = 0.f;
+    for (int r = r0; r < r1; ++r) a += W[(long)r * cols + c] * x[r];
+    atomicAdd(out + c, a);
 }
 // g_orig[r][c] = (G[r][c] - (gw[0] * sig[1]) * u[r] * v[c]) * sig[1]    (sig = {sigma, 1/sigma}, gw[0] = <G, W_orig>)
 __global__ __launch_bounds__(256) void sn_grad_kernel(const float* G, const float* u, const float* v, const float* gw, const float* sig,
@@ -649,16 +662,38 @@ int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float
     if (r) return sgv_set_error(-1, "sgv_op_gemm_nt: launch rejected (%d) for M=%d N=%d K=%d", r, M, N, K);
     return 0;
 }
-// dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]; N1, N2 multiples of 8
-int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, void* stream) {
+// dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]; N1, N2 multiples of 8.  The reduction runs over the M = B*H*W rows, up to
+// a million of them for a handful of output tiles: sgv_op_gemm_tn_splitk() says how many row slices to use and the caller
+// provides splitk * N1 * N2 floats of slab workspace (deterministic: plain stores + one sum pass).
+int sgv_op_gemm_tn_splitk(int dtype, int M, int N1, int N2) {
+    const long tiles = (long)cdivi(N1, 128) * cdivi(N2, 128);
+    const long steps = cdivi(M, dtype == 1 ? 32 : 16);
+    long sk = 768 / tiles;                       // three 128x128 blocks per CU
+    if (sk > steps / 8) sk = steps / 8;          // keep >= 8 K-steps per slice
+    if (sk > 256) sk = 256;
+    return sk < 1 ? 1 : (int)sk;
+}
+__global__ __launch_bounds__(256) void op_sum_slabs_kernel(float* out, const float* slabs, int splitk, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        float v = 0.f;
+        for (int z = 0; z < splitk; ++z) v += slabs[(long)z * n + i];
+        out[i] = v;
+    }
+}
+int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, float* slabs, int splitk, void* stream) {
     OPCHK(A && Bm && dW && M > 0 && N1 > 0 && N2 > 0, "sgv_op_gemm_tn: bad argument");
     OPCHK(N1 % 8 == 0 && N2 % 8 == 0, "sgv_op_gemm_tn: N1 and N2 must be multiples of 8 (got %d, %d)", N1, N2);
+    OPCHK(splitk <= 1 || slabs, "sgv_op_gemm_tn: split-K needs a slab workspace");
     GemmTN p; memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
-    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = 1; p.pad = 0; p.Tlen = M; p.splitk = 1; p.use_tr = 1;
+    p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = 1; p.pad = 0; p.Tlen = M; p.use_tr = 1;
+    p.splitk = splitk < 1 ? 1 : splitk;
+    p.out = p.splitk > 1 ? slabs : dW; p.out_slab_stride = (long)N1 * N2;
     const int r = launch_gemm_tn(dtype, p, ST(stream));
     if (r) return sgv_set_error(-1, "sgv_op_gemm_tn: launch rejected (%d) for M=%d N1=%d N2=%d", r, M, N1, N2);
-    return 0;
+    if (p.splitk > 1)
+        hipLaunchKernelGGL(op_sum_slabs_kernel, grid1((long)N1 * N2), dim3(256), 0, ST(stream), dW, slabs, p.splitk, (long)N1 * N2);
+    return OPLAUNCH_OK();
 }
 // ---- input augmentation ------------------------------------------------------------------------------------
 int sgv_op_flip_roll(const float* x, float* out, int B, int H, int W, const int* flip, const int* shift_x, const int* shift_y, void* stream) {
@@ -682,9 +717,19 @@ int sgv_op_l2_normalize(const float* x, float* out, long n, float eps, void* str
     hipLaunchKernelGGL(l2_normalize_kernel, dim3(1), dim3(256), 0, ST(stream), x, out, n, eps);
     return OPLAUNCH_OK();
 }
-int sgv_op_dot(const float* a, const float* b, float* out2, long n, void* stream) {
-    OPCHK(a && b && out2 && n > 0, "sgv_op_dot: bad argument");
-    hipLaunchKernelGGL(dot_kernel, dim3(1), dim3(256), 0, ST(stream), a, b, out2, n);
+int sgv_op_dot(const float* a, const float* b, float* out4, long n, void* stream) {
+    OPCHK(a && b && out4 && n > 0, "sgv_op_dot: bad argument");
+    OPCHK(((uintptr_t)out4 & 7) == 0, "sgv_op_dot: out4 must be 8-byte aligned");
+    if (hipMemsetAsync(out4 + 2, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    long blocks = (n + 8191) / 8192; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), a, b, reinterpret_cast<double*>(out4 + 2), n);
+    hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(1), 0, ST(stream), out4);
+    return OPLAUNCH_OK();
+}
+int sgv_op_matvec_t(const float* W, const float* x, float* out, int rows, int cols, void* stream) {
+    OPCHK(W && x && out && rows > 0 && cols > 0, "sgv_op_matvec_t: bad argument");
+    if (hipMemsetAsync(out, 0, sizeof(float) * cols, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdivi(cols, 256), cdivi(rows, 64)), dim3(256), 0, ST(stream), W, x, out, rows, cols);
     return OPLAUNCH_OK();
 }
 int sgv_op_sn_grad(const float* G, const float* u, const float* v, const float* gw, const float* sigma2, float* out, int rows, int cols,

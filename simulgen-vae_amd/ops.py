@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gn_fwd",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -37,7 +37,9 @@ def lib():
             "sgv_op_im2col": [i, vp, vp] + [i] * 8 + [vp],
             "sgv_op_col2im": [i, vp, vp] + [i] * 8 + [vp],
             "sgv_op_gemm_nt": [i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
-            "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp],
+            "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp, i, vp],
+            "sgv_op_gemm_tn_splitk": [i, i, i, i],
+            "sgv_op_matvec_t": [vp, vp, vp, i, i, vp],
             "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp],
             "sgv_op_gn_workspace_floats": [i, i, i],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
@@ -138,7 +140,9 @@ def gemm_tn(A, Bm):
     M, N1 = A.shape
     N2 = Bm.shape[1]
     out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
-    _ck(lib().sgv_op_gemm_tn(_d(A), _p(A), _p(Bm), _p(out), M, N1, N2, _stream()), "sgv_op_gemm_tn")
+    sk = int(lib().sgv_op_gemm_tn_splitk(_d(A), M, N1, N2))
+    slabs = torch.empty((sk, N1, N2), dtype=torch.float32, device=A.device) if sk > 1 else None
+    _ck(lib().sgv_op_gemm_tn(_d(A), _p(A), _p(Bm), _p(out), M, N1, N2, _p(slabs), sk, _stream()), "sgv_op_gemm_tn")
     return out
 
 
@@ -325,8 +329,8 @@ def l2_normalize(x, eps=1e-12):
 
 
 def dot(a, b):
-    """-> fp32 [2] = {a.b, 1/(a.b)}"""
-    out = torch.empty(2, dtype=torch.float32, device=a.device)
+    """-> fp32 [4]: {a.b, 1/(a.b), scratch}"""
+    out = torch.empty(4, dtype=torch.float32, device=a.device)
     _ck(lib().sgv_op_dot(_p(a), _p(b), _p(out), a.numel(), _stream()), "sgv_op_dot")
     return out
 
@@ -336,8 +340,9 @@ def sn_power_iteration(Wm, u, v, train):
     returns sigma2 = {sigma, 1/sigma} (device)."""
     rows, cols = Wm.shape
     if train:
-        wtu, _, _ = linear_bwd(u.view(1, rows), v.view(1, cols), Wm, need_dx=True, has_bias=False)      # W^T u  ([1, cols])
-        v.copy_(l2_normalize(wtu.view(-1)))
+        wtu = torch.empty(cols, dtype=torch.float32, device=Wm.device)
+        _ck(lib().sgv_op_matvec_t(_p(Wm), _p(u), _p(wtu), rows, cols, _stream()), "sgv_op_matvec_t")      # W^T u
+        v.copy_(l2_normalize(wtu))
         u.copy_(l2_normalize(linear_fwd(v.view(1, cols), Wm).view(-1)))
     return dot(u, linear_fwd(v.view(1, cols), Wm).view(-1))
 
