@@ -214,15 +214,21 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const floa
         dz[i] = dy[i] * (act == 1 ? (v > 0.f ? 1.f : 0.f) : (act == 2 ? v * (1.f - v) : 1.f));
     }
 }
-// dx[b][k] = scale * sum_o dz[b][o] W[o][k]; grid (ceil(K/256), B)
+// dx[b][k] = scale * sum_o dz[b][o] W[o][k]; grid (ceil(K/64), B): 64 columns x 4 row lanes per block
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* dz, const float* W, const float* scale, float* dx, int K, int O,
                                                            int accumulate) {
-    const int k = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (k >= K) return;
+    const int kl = threadIdx.x & 63, ol = threadIdx.x >> 6;
+    const int k = blockIdx.x * 64 + kl, b = blockIdx.y;
     float a = 0.f;
-    for (int o = 0; o < O; ++o) a += dz[(long)b * O + o] * W[(long)o * K + k];
-    a *= scale ? *scale : 1.f;
-    dx[(long)b * K + k] = accumulate ? dx[(long)b * K + k] + a : a;
+    if (k < K)
+        for (int o = ol; o < O; o += 4) a += dz[(long)b * O + o] * W[(long)o * K + k];
+    __shared__ float sm[4][64];
+    sm[ol][kl] = a;
+    __syncthreads();
+    if (ol == 0 && k < K) {
+        a = (sm[0][kl] + sm[1][kl] + sm[2][kl] + sm[3][kl]) * (scale ? *scale : 1.f);
+        dx[(long)b * K + k] = accumulate ? dx[(long)b * K + k] + a : a;
+    }
 }
 // dW[o][k] = scale * sum_b dz[b][o] x[b][k]; db[o] = sum_b dz[b][o]; grid (ceil(K/256), O)
 __global__ __launch_bounds__(256) void linear_bwd_dw_kernel(const float* dz, const float* x, const float* scale, float* dW, float* db,
@@ -389,10 +395,13 @@ __global__ __launch_bounds__(256) void conv_weight_unpack_kernel(const float* pa
     }
 }
 __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, double* acc) {
+    __shared__ double sm[4];
     double a = 0.0;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) a += (double)g[i] * (double)g[i];
     a = wave_sum_d(a);
-    if ((threadIdx.x & 63) == 0) atomicAdd(acc, a);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(acc, sm[0] + sm[1] + sm[2] + sm[3]);      // one atomic per block, <= 256 blocks
 }
 // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)); out = {coef, total_norm}
 __global__ void clip_coef_kernel(const double* sumsq, float max_norm, float* out) {
@@ -603,7 +612,7 @@ int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, 
 int sgv_op_linear_bwd(const float* dz, const float* x, const float* W, const float* scale, float* dx, int accumulate_dx, float* dW, float* db,
                       int B, int K, int O, void* stream) {
     OPCHK(dz && x && W && dW && B > 0 && K > 0 && O > 0, "sgv_op_linear_bwd: bad argument");
-    if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdivi(K, 256), B), dim3(256), 0, ST(stream), dz, W, scale, dx, K, O, accumulate_dx);
+    if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdivi(K, 64), B), dim3(256), 0, ST(stream), dz, W, scale, dx, K, O, accumulate_dx);
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdivi(K, 256), O), dim3(256), 0, ST(stream), dz, x, scale, dW, db, B, K, O);
     return OPLAUNCH_OK();
 }
@@ -752,7 +761,8 @@ int sgv_op_conv_weight_unpack(const float* packed, float* w, int Cout, int Cin, 
 }
 int sgv_op_sumsq(const float* g, long n, double* acc, void* stream) {
     OPCHK(g && acc && n > 0, "sgv_op_sumsq: bad argument");
-    hipLaunchKernelGGL(sumsq_kernel, grid1(n), dim3(256), 0, ST(stream), g, n, acc);
+    long blocks = (n + 4095) / 4096; if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), g, n, acc);
     return OPLAUNCH_OK();
 }
 int sgv_op_clip_coef(const double* sumsq, float max_norm, float* out2, void* stream) {
