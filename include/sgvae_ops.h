@@ -41,9 +41,10 @@ size_t sgv_op_gn_workspace_floats(int B, int P, int C);
 int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
                   const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream);
 
-/* nn.MaxPool2d(3, 2, 1) (model_cnn.py:189); backward recomputes the first arg-max of each window. */
-int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream);
-int sgv_op_maxpool_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
+/* nn.MaxPool2d(3, 2, 1) (model_cnn.py:189); argmax: one byte per output element (window position of the first
+ * maximum, may be NULL in the forward when no backward follows). */
+int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, void* stream);
+int sgv_op_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
 /* out = relu(a + b) (model_cnn.py:131-132) and d = dout * (out > 0); plain add for gradient joins. */
 int sgv_op_add_relu_fwd(int dtype, const void* a, const void* b, void* out, long n, void* stream);
 int sgv_op_relu_bwd(int dtype, const void* out, const void* dout, void* d, long n, void* stream);

@@ -26,30 +26,40 @@ static inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
 // ------------------------------------------------------------------------------------------------------------
 struct ConvGeom { int B, H, W, C, KH, KW, S, P, Ho, Wo, Kp; };
 
+// block = 32 consecutive output pixels (blockIdx.x) x a 256-wide slice of k (blockIdx.y): a thread decodes its k once and
+// walks the pixels with an incrementally updated (b, oh, ow), so the inner loop has no divisions
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeom g) {
-    const long total = (long)g.B * g.Ho * g.Wo * g.Kp;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int k = (int)(i % g.Kp);
-        const long m = i / g.Kp;
-        T v = from_f32<T>(0.f);
-        if (k < g.KH * g.KW * g.C) {
-            const int c = k % g.C, t = k / g.C, kw = t % g.KW, kh = t / g.KW;
-            const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+    const int k = blockIdx.y * 256 + threadIdx.x;
+    if (k >= g.Kp) return;
+    const bool live = k < g.KH * g.KW * g.C;
+    const int c = live ? k % g.C : 0, t = live ? k / g.C : 0, kw = t % g.KW, kh = t / g.KW;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    long m = (long)blockIdx.x * 32;
+    const long m_end = m + 32 < M ? m + 32 : M;
+    int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+    const T zero = from_f32<T>(0.f);
+    for (; m < m_end; ++m) {
+        T v = zero;
+        if (live) {
             const int h = oh * g.S - g.P + kh, w = ow * g.S - g.P + kw;
             if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) v = x[(((long)b * g.H + h) * g.W + w) * g.C + c];
         }
-        col[i] = v;
+        col[m * g.Kp + k] = v;
+        if (++ow == g.Wo) { ow = 0; if (++oh == g.Ho) { oh = 0; ++b; } }
     }
 }
-// dx[b][h][w][c] = sum over the windows that cover (h,w) of dcol (gather form: no atomics, deterministic)
+// dx[b][h][w][c] = sum over the windows that cover (h,w) of dcol (gather form: no atomics, deterministic);
+// block = 16 consecutive input pixels x a 256-wide slice of channels
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, T* dx, ConvGeom g) {
-    const long total = (long)g.B * g.H * g.W * g.C;
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int c = (int)(i % g.C);
-        const long pix = i / g.C;
-        const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
+    const int c = blockIdx.y * 256 + threadIdx.x;
+    if (c >= g.C) return;
+    const long NP = (long)g.B * g.H * g.W;
+    long pix = (long)blockIdx.x * 16;
+    const long p_end = pix + 16 < NP ? pix + 16 : NP;
+    int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
+    for (; pix < p_end; ++pix) {
         float acc = 0.f;
         for (int kh = 0; kh < g.KH; ++kh) {
             const int hn = h + g.P - kh;
@@ -64,13 +74,14 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, T* dx, ConvG
                 acc += to_f32(dcol[(((long)b * g.Ho + oh) * g.Wo + ow) * g.Kp + (kh * g.KW + kw) * g.C + c]);
             }
         }
-        dx[i] = from_f32<T>(acc);
+        dx[pix * g.C + c] = from_f32<T>(acc);
+        if (++w == g.W) { w = 0; if (++h == g.H) { h = 0; ++b; } }
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// MaxPool2d(3, 2, 1): forward keeps nothing; backward recomputes each window's first arg-max (PyTorch tie rule:
-// first maximum in row-major window order) and gathers
+// MaxPool2d(3, 2, 1): the forward stores the window position (0..8) of each output's first arg-max (PyTorch tie rule:
+// first maximum in row-major window order); the backward gathers through it
 // ------------------------------------------------------------------------------------------------------------
 template <typename T>
 __device__ __forceinline__ void pool_argmax(const T* x, const ConvGeom& g, int b, int oh, int ow, int c, float& best, int& bh, int& bw) {
@@ -87,7 +98,7 @@ __device__ __forceinline__ void pool_argmax(const T* x, const ConvGeom& g, int b
     }
 }
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, ConvGeom g) {
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, unsigned char* idx, ConvGeom g) {
     const long total = (long)g.B * g.Ho * g.Wo * g.C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % g.C);
@@ -96,24 +107,24 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, Conv
         float best; int bh, bw;
         pool_argmax(x, g, b, oh, ow, c, best, bh, bw);
         y[i] = from_f32<T>(best);
+        if (idx) idx[i] = (unsigned char)((bh - (oh * 2 - 1)) * 3 + (bw - (ow * 2 - 1)));      // window position of the arg-max
     }
 }
+// gather: an input pixel receives dy of every window whose stored arg-max points at it
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* x, const T* dy, T* dx, ConvGeom g) {
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* idx, const T* dy, T* dx, ConvGeom g) {
     const long total = (long)g.B * g.H * g.W * g.C;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
         const int c = (int)(i % g.C);
         const long pix = i / g.C;
         const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
         float acc = 0.f;
-        // windows (oh, ow) with oh*2-1 <= h <= oh*2+1
         for (int oh = (h + 1) / 2 - ((h + 1) % 2 == 0 ? 1 : 0); oh <= (h + 1) / 2; ++oh) {
             if (oh < 0 || oh >= g.Ho) continue;
             for (int ow = (w + 1) / 2 - ((w + 1) % 2 == 0 ? 1 : 0); ow <= (w + 1) / 2; ++ow) {
                 if (ow < 0 || ow >= g.Wo) continue;
-                float best; int bh, bw;
-                pool_argmax(x, g, b, oh, ow, c, best, bh, bw);
-                if (bh == h && bw == w) acc += to_f32(dy[(((long)b * g.Ho + oh) * g.Wo + ow) * g.C + c]);
+                const long o = (((long)b * g.Ho + oh) * g.Wo + ow) * g.C + c;
+                if ((int)idx[o] == (h - (oh * 2 - 1)) * 3 + (w - (ow * 2 - 1))) acc += to_f32(dy[o]);
             }
         }
         dx[i] = from_f32<T>(acc);
@@ -139,16 +150,17 @@ __global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
         out[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
 }
-// y[b][c] = mean_p x[b][p][c]   (grid: (C/64, B), block 256 = 64 channels x 4 row lanes)
+// y[b][c] += (1/P) sum_{p in chunk} x[b][p][c]   (grid (C/64, B, chunks); 64 channels x 4 row lanes; y zeroed by the launcher)
 template <typename T>
-__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, float* y, int P, int C) {
+__global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, float* y, int P, int C, int chunk) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+    const int p0 = blockIdx.z * chunk, p1 = min(P, p0 + chunk);
     float a = 0.f;
-    if (c < C) for (int p = rl; p < P; p += 4) a += to_f32(x[((long)b * P + p) * C + c]);
+    if (c < C) for (int p = p0 + rl; p < p1; p += 4) a += to_f32(x[((long)b * P + p) * C + c]);
     __shared__ float sm[4][64];
     sm[rl][threadIdx.x & 63] = a;
     __syncthreads();
-    if (rl == 0 && c < C) y[(long)b * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)P;
+    if (rl == 0 && c < C) atomicAdd(y + (long)b * C + c, (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)P);
 }
 // dx[b][p][c] (+)= dy[b][c] / P
 template <typename T>
@@ -169,14 +181,15 @@ __global__ __launch_bounds__(256) void chan_scale_fwd_kernel(const T* x, const f
         out[i] = from_f32<T>(to_f32(x[i]) * s[(long)b * C + c]);
     }
 }
-// dx = dout * s ; ds[b][c] = sum_p dout * x
+// dx = dout * s ; ds[b][c] += sum_{p in chunk} dout * x   (grid (C/64, B, chunks); ds zeroed by the launcher)
 template <typename T>
-__global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* x, const float* s, const T* dout, T* dx, float* ds, int P, int C) {
+__global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* x, const float* s, const T* dout, T* dx, float* ds, int P, int C, int chunk) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
+    const int p0 = blockIdx.z * chunk, p1 = min(P, p0 + chunk);
     float a = 0.f;
     if (c < C) {
         const float sv = s[(long)b * C + c];
-        for (int p = rl; p < P; p += 4) {
+        for (int p = p0 + rl; p < p1; p += 4) {
             const long i = ((long)b * P + p) * C + c;
             const float d = to_f32(dout[i]);
             a += d * to_f32(x[i]);
@@ -186,7 +199,7 @@ __global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* x, const f
     __shared__ float sm[4][64];
     sm[rl][threadIdx.x & 63] = a;
     __syncthreads();
-    if (rl == 0 && c < C) ds[(long)b * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
+    if (rl == 0 && c < C) atomicAdd(ds + (long)b * C + c, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -506,25 +519,27 @@ int sgv_op_conv_out_shape(int H, int W, int C, int KH, int KW, int stride, int p
 int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
     OPCHK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && KH > 0 && KW > 0, "sgv_op_im2col: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
-    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, grid1((long)B * g.Ho * g.Wo * g.Kp), dim3(256), 0, ST(stream), CPT(x), PT(col), g));
+    const long Mrows = (long)B * g.Ho * g.Wo;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3((unsigned)((Mrows + 31) / 32), cdivi(g.Kp, 256)), dim3(256), 0, ST(stream), CPT(x), PT(col), g));
     return OPLAUNCH_OK();
 }
 int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
     OPCHK(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "sgv_op_col2im: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
-    ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, grid1((long)B * H * W * C), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g));
+    const long NPix = (long)B * H * W;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, dim3((unsigned)((NPix + 15) / 16), cdivi(C, 256)), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g));
     return OPLAUNCH_OK();
 }
-int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, int B, int H, int W, int C, void* stream) {
+int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, void* stream) {
     OPCHK(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_fwd: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
-    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, grid1((long)B * g.Ho * g.Wo * C), dim3(256), 0, ST(stream), CPT(x), PT(y), g));
+    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, grid1((long)B * g.Ho * g.Wo * C), dim3(256), 0, ST(stream), CPT(x), PT(y), argmax, g));
     return OPLAUNCH_OK();
 }
-int sgv_op_maxpool_bwd(int dtype, const void* x, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
-    OPCHK(x && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_bwd: bad argument");
+int sgv_op_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
+    OPCHK(argmax && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_bwd: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
-    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, grid1((long)B * H * W * C), dim3(256), 0, ST(stream), CPT(x), CPT(dy), PT(dx), g));
+    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, grid1((long)B * H * W * C), dim3(256), 0, ST(stream), argmax, CPT(dy), PT(dx), g));
     return OPLAUNCH_OK();
 }
 int sgv_op_add_relu_fwd(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
@@ -544,7 +559,9 @@ int sgv_op_add(int dtype, const void* a, const void* b, void* out, long n, void*
 }
 int sgv_op_avgpool_fwd(int dtype, const void* x, float* y, int B, int P, int C, void* stream) {
     OPCHK(x && y && B > 0 && P > 0 && C > 0, "sgv_op_avgpool_fwd: bad argument");
-    ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(cdivi(C, 64), B), dim3(256), 0, ST(stream), CPT(x), y, P, C));
+    if (hipMemsetAsync(y, 0, sizeof(float) * B * C, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    const int chunk = P > 512 ? 256 : P;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(cdivi(C, 64), B, cdivi(P, chunk)), dim3(256), 0, ST(stream), CPT(x), y, P, C, chunk));
     return OPLAUNCH_OK();
 }
 int sgv_op_avgpool_bwd(int dtype, const float* dy, void* dx, int B, int P, int C, int accumulate, void* stream) {
@@ -561,7 +578,9 @@ int sgv_op_chan_scale_fwd(int dtype, const void* x, const float* s, void* out, i
 }
 int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* dout, void* dx, float* ds, int B, int P, int C, void* stream) {
     OPCHK(x && s && dout && dx && ds && B > 0 && P > 0 && C > 0, "sgv_op_chan_scale_bwd: bad argument");
-    ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_bwd_kernel<T>, dim3(cdivi(C, 64), B), dim3(256), 0, ST(stream), CPT(x), s, CPT(dout), PT(dx), ds, P, C));
+    if (hipMemsetAsync(ds, 0, sizeof(float) * B * C, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    const int chunk = P > 512 ? 256 : P;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_bwd_kernel<T>, dim3(cdivi(C, 64), B, cdivi(P, chunk)), dim3(256), 0, ST(stream), CPT(x), s, CPT(dout), PT(dx), ds, P, C, chunk));
     return OPLAUNCH_OK();
 }
 

@@ -350,8 +350,8 @@ class LatentConditionerImg:
         back.append(bw)
         a0, bw = self._gn("initial_conv.1", c0, ops.ACT_RELU_GN)
         back.append(bw)
-        h = ops.maxpool_fwd(a0)
-        back.append(lambda d, a0=a0: ops.maxpool_bwd(a0, d))
+        h, pool_idx = ops.maxpool_fwd(a0)
+        back.append(lambda d, idx=pool_idx, shp=tuple(a0.shape): ops.maxpool_bwd(idx, d, shp))
         for b in self.blocks:
             h, bw = self._block(b, h)
             back.append(bw)

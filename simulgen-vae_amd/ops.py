@@ -43,7 +43,7 @@ def lib():
             "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp],
             "sgv_op_gn_workspace_floats": [i, i, i],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
-            "sgv_op_maxpool_fwd": [i, vp, vp, i, i, i, i, vp],
+            "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_maxpool_bwd": [i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_add_relu_fwd": [i, vp, vp, vp, lg, vp],
             "sgv_op_relu_bwd": [i, vp, vp, vp, lg, vp],
@@ -169,14 +169,15 @@ def maxpool_fwd(x):
     B, H, W, Cc = x.shape
     Ho, Wo, _ = conv_out_shape(H, W, Cc, 3, 3, 2, 1)
     y = torch.empty((B, Ho, Wo, Cc), dtype=x.dtype, device=x.device)
-    _ck(lib().sgv_op_maxpool_fwd(_d(x), _p(x), _p(y), B, H, W, Cc, _stream()), "sgv_op_maxpool_fwd")
-    return y
+    idx = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
+    _ck(lib().sgv_op_maxpool_fwd(_d(x), _p(x), _p(y), _p(idx), B, H, W, Cc, _stream()), "sgv_op_maxpool_fwd")
+    return y, idx
 
 
-def maxpool_bwd(x, dy):
-    B, H, W, Cc = x.shape
-    dx = torch.empty_like(x)
-    _ck(lib().sgv_op_maxpool_bwd(_d(x), _p(x), _p(dy), _p(dx), B, H, W, Cc, _stream()), "sgv_op_maxpool_bwd")
+def maxpool_bwd(idx, dy, in_shape):
+    B, H, W, Cc = in_shape
+    dx = torch.empty(in_shape, dtype=dy.dtype, device=dy.device)
+    _ck(lib().sgv_op_maxpool_bwd(_d(dy), _p(idx), _p(dy), _p(dx), B, H, W, Cc, _stream()), "sgv_op_maxpool_bwd")
     return dx
 
 

@@ -114,7 +114,7 @@ x4 = x.view(4, 32, 32, 1).contiguous()
 c0, bw0 = m._conv("initial_conv.0", x4, 7, 1, 3, need_dx=False)
 a0, bwg = m._gn("initial_conv.1", c0, 3)
 from simulgen_vae_amd import ops
-h = ops.maxpool_fwd(a0)
+h, _pool_idx = ops.maxpool_fwd(a0)
 mine = [h]
 bws = []
 for b in m.blocks:

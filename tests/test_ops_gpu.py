@@ -96,9 +96,9 @@ def test_maxpool_residual_se_ops(dt):
     dy = q(torch.randn(y.shape, generator=g), dt)
     y.backward(dy)
     xd = nhwc(x.detach(), dt)
-    yd = ops.maxpool_fwd(xd)
+    yd, pidx = ops.maxpool_fwd(xd)
     assert rel(nchw(yd), y) == 0.0
-    assert rel(nchw(ops.maxpool_bwd(xd, nhwc(dy, dt))), x.grad) < TOL[dt]
+    assert rel(nchw(ops.maxpool_bwd(pidx, nhwc(dy, dt), tuple(xd.shape))), x.grad) < TOL[dt]
     # relu(a + b) and its gate
     a = q(torch.randn(B, Cc, H, W, generator=g), dt).requires_grad_()
     b = q(torch.randn(B, Cc, H, W, generator=g), dt).requires_grad_()
