@@ -26,40 +26,42 @@ static inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
 // ------------------------------------------------------------------------------------------------------------
 struct ConvGeom { int B, H, W, C, KH, KW, S, P, Ho, Wo, Kp; };
 
-// block = 32 consecutive output pixels (blockIdx.x) x a 256-wide slice of k (blockIdx.y): a thread decodes its k once and
-// walks the pixels with an incrementally updated (b, oh, ow), so the inner loop has no divisions
+// thread = (row lane, k lane): a block covers `rows_pb` = 256 / kw_ consecutive output pixels x kw_ = min(Kp, 256) values of
+// k per pass and 8 passes of rows; a thread decodes its k once, the (b, oh, ow) of a row costs three divisions per 56..256
+// contiguous elements written
 template <typename T>
-__global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeom g) {
-    const int k = blockIdx.y * 256 + threadIdx.x;
-    if (k >= g.Kp) return;
+__global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeom g, int kw_) {
+    const int kl = threadIdx.x % kw_, rl = threadIdx.x / kw_, rows_pb = 256 / kw_;
+    const int k = blockIdx.y * kw_ + kl;
+    if (k >= g.Kp || rl >= rows_pb) return;
     const bool live = k < g.KH * g.KW * g.C;
     const int c = live ? k % g.C : 0, t = live ? k / g.C : 0, kw = t % g.KW, kh = t / g.KW;
     const long M = (long)g.B * g.Ho * g.Wo;
-    long m = (long)blockIdx.x * 32;
-    const long m_end = m + 32 < M ? m + 32 : M;
-    int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
     const T zero = from_f32<T>(0.f);
-    for (; m < m_end; ++m) {
+    for (int pass = 0; pass < 8; ++pass) {
+        const long m = ((long)blockIdx.x * 8 + pass) * rows_pb + rl;
+        if (m >= M) return;
         T v = zero;
         if (live) {
+            const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
             const int h = oh * g.S - g.P + kh, w = ow * g.S - g.P + kw;
             if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) v = x[(((long)b * g.H + h) * g.W + w) * g.C + c];
         }
         col[m * g.Kp + k] = v;
-        if (++ow == g.Wo) { ow = 0; if (++oh == g.Ho) { oh = 0; ++b; } }
     }
 }
 // dx[b][h][w][c] = sum over the windows that cover (h,w) of dcol (gather form: no atomics, deterministic);
-// block = 16 consecutive input pixels x a 256-wide slice of channels
+// thread = (pixel lane, channel lane) with cw_ = min(C, 256) channel lanes
 template <typename T>
-__global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, T* dx, ConvGeom g) {
-    const int c = blockIdx.y * 256 + threadIdx.x;
-    if (c >= g.C) return;
+__global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, T* dx, ConvGeom g, int cw_) {
+    const int cl = threadIdx.x % cw_, pl = threadIdx.x / cw_, pix_pb = 256 / cw_;
+    const int c = blockIdx.y * cw_ + cl;
+    if (c >= g.C || pl >= pix_pb) return;
     const long NP = (long)g.B * g.H * g.W;
-    long pix = (long)blockIdx.x * 16;
-    const long p_end = pix + 16 < NP ? pix + 16 : NP;
-    int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
-    for (; pix < p_end; ++pix) {
+    for (int pass = 0; pass < 4; ++pass) {
+        const long pix = ((long)blockIdx.x * 4 + pass) * pix_pb + pl;
+        if (pix >= NP) return;
+        const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
         float acc = 0.f;
         for (int kh = 0; kh < g.KH; ++kh) {
             const int hn = h + g.P - kh;
@@ -75,7 +77,6 @@ __global__ __launch_bounds__(256) void col2im_kernel(const T* dcol, T* dx, ConvG
             }
         }
         dx[pix * g.C + c] = from_f32<T>(acc);
-        if (++w == g.W) { w = 0; if (++h == g.H) { h = 0; ++b; } }
     }
 }
 
@@ -520,14 +521,16 @@ int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int 
     OPCHK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && KH > 0 && KW > 0, "sgv_op_im2col: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
     const long Mrows = (long)B * g.Ho * g.Wo;
-    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3((unsigned)((Mrows + 31) / 32), cdivi(g.Kp, 256)), dim3(256), 0, ST(stream), CPT(x), PT(col), g));
+    const int kw_ = g.Kp < 256 ? g.Kp : 256, rows_pb = 256 / kw_;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3((unsigned)((Mrows + 8L * rows_pb - 1) / (8L * rows_pb)), cdivi(g.Kp, kw_)), dim3(256), 0, ST(stream), CPT(x), PT(col), g, kw_));
     return OPLAUNCH_OK();
 }
 int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
     OPCHK(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "sgv_op_col2im: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
     const long NPix = (long)B * H * W;
-    ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, dim3((unsigned)((NPix + 15) / 16), cdivi(C, 256)), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g));
+    const int cw_ = C < 256 ? C : 256, pix_pb = 256 / cw_;
+    ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, dim3((unsigned)((NPix + 4L * pix_pb - 1) / (4L * pix_pb)), cdivi(C, cw_)), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g, cw_));
     return OPLAUNCH_OK();
 }
 int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, void* stream) {
