@@ -121,6 +121,23 @@ def bench_latent_conditioner(args):
            "config": {"workload": f"LatentConditionerImg training step, {side}x{side} images, batch {B} (BASELINE.json configs[4])",
                       "filters": filters, "image": side, "per_gpu_batch": B},
            "step_tflops": round(3 * fwd_gf * (B / 16) / (el / args.steps) / 1e3, 2) if fwd_gf else None, "roofline": None, "cpu_baseline": None}
+    if args.cpu_baseline == "auto":
+        # the CPU restatement (oracle/lc_torch_port.py, PyTorch-CPU fp32) on the host cores: 1 untimed + 1 timed training
+        # step at the same image size, batch 4
+        from oracle.lc_torch_port import TorchPortLC
+        cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), args.cpu_threads)
+        torch.set_num_threads(cores)
+        cb = 4
+        port = TorchPortLC(filters, LATENT, HIER, len(ENC) - 1, {k: v.clone() for k, v in m.state_dict().items()}, dropout_rate=0.2)
+        xc, y1c, y2c = x[:cb].cpu(), y1[:cb].cpu(), y2[:cb].cpu()
+        port.loss_backward(xc, y1c, y2c)
+        port.clip_and_step(1e-3, 1e-5)
+        t0 = time.perf_counter()
+        port.loss_backward(xc, y1c, y2c)
+        port.clip_and_step(1e-3, 1e-5)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {"value": round(cb / dt, 3), "unit": "samples/s", "cores": cores, "kind": "port",
+                               "sample": f"oracle/lc_torch_port.py, 1 timed training step at {side}x{side}, batch {cb} ({dt:.1f}s)"}
     print(json.dumps(res), flush=True)
 
 

@@ -173,3 +173,34 @@ def test_torch_port_matches_golden(tag, cfgd, small, lossfun):
     for k in g.files:
         if k.startswith("s3."):
             assert relerr(m.P[k[3:]].detach().numpy(), g[k]) < 3e-4, k
+
+
+def test_lc_torch_port_matches_reference_golden():
+    """oracle/lc_torch_port.py (the CPU restatement of the image latent conditioner) against the vectors
+    recorded from the reference model: eval / training forward, loss, gradients, clipped norm, one AdamW step."""
+    import torch
+    from oracle.lc_torch_port import TorchPortLC
+    g = np.load(os.path.join(GOLD, "lc_small.npz"))
+    latent_end, latent, size2, img, B = (int(v) for v in g["meta"])
+    state = {k[3:]: g[k] for k in g.files if k.startswith("s0.")}
+    m = TorchPortLC(g["filters"], latent_end, latent, size2, state)
+    m.training = False
+    with torch.no_grad():
+        e1, e2 = m.forward(torch.from_numpy(g["x"]))
+    assert np.abs(e1.numpy() - g["eval_main"]).max() < 1e-5 and np.abs(e2.numpy() - g["eval_xs"]).max() < 1e-5
+    m = TorchPortLC(g["filters"], latent_end, latent, size2, state)
+    masks = [torch.from_numpy(g[f"mask{i}"]) for i in range(7)]
+    loss, A, Bl, p1, p2 = m.loss_backward(torch.from_numpy(g["x"]), g["y1"], g["y2"], masks)
+    assert abs(loss - g["loss"][0]) < 1e-5 * g["loss"][0]
+    gmax = max(np.abs(g[k]).max() for k in g.files if k.startswith("g."))
+    for k in m.trainable:
+        d = np.abs(m.S[k].grad.numpy() - g["g." + k]).max()
+        assert d <= 1e-4 * max(np.abs(g["g." + k]).max(), 1e-4 * gmax), k
+    total = m.clip_and_step(1e-3, 1e-4)
+    assert abs(total - g["total_norm"][0]) < 1e-4 * g["total_norm"][0]
+    noise = {"latent_main_layer1.0.bias", "latent_main_layer2.0.bias", "xs_layer1.0.bias", "xs_layer2.0.bias"}   # zero true gradient
+    for k in m.trainable:
+        if k not in noise:
+            assert np.abs(m.S[k].detach().numpy() - g["s1." + k]).max() <= 5e-5 * max(1.0, np.abs(g["s1." + k]).max()), k
+    for k in ("initial_conv.0.weight_u", "layers.3.conv2.weight_v", "xs_layer1.1.running_var"):
+        assert np.abs(m.S[k].detach().numpy() - g["s1." + k]).max() < 1e-5, k
