@@ -107,6 +107,23 @@ int sgv_op_sumsq(const float* g, long n, double* acc, void* stream);
 int sgv_op_clip_coef(const double* sumsq, float max_norm, float* out2, void* stream);
 int sgv_op_adamw(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2, float eps, float weight_decay,
                  int step, const float* gscale, void* stream);
+/* Parameter set: the same steps for a whole list of tensors in a handful of launches (multi-tensor kernels of the VAE
+ * path).  Entry: parameter p and its gradient buffer g (fp32, n elements, n % 4 == 0, 16-byte aligned, both owned by
+ * the caller and at fixed addresses); rows > 0 marks a spectrally normalised [rows][cols] weight (cols % 4 == 0) with
+ * its u [rows] / v [cols] vectors -- for those, g must hold the gradient wrt W/sigma and the step applies the chain
+ * rule.  Adam moments live inside the object.
+ *   sgv_pset_power_iteration: one legacy power iteration for every normalised weight (train != 0 updates u, v), sigma
+ *     = u.(W v); sgv_pset_sigma(ps, entry) -> device pointer to {sigma, 1/sigma} of that entry (NULL if not normalised);
+ *   sgv_pset_step: clip_grad_norm_(max_norm) (max_norm <= 0: no clipping) + AdamW(lr, betas (0.9, 0.999), eps 1e-8,
+ *     weight_decay) on every entry; total_norm_host (may be NULL: no host sync) receives the norm before clipping. */
+typedef struct sgv_pset sgv_pset;
+typedef struct sgv_pset_entry { float* p; float* g; long n; int rows, cols; float* u; float* v; } sgv_pset_entry;
+int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out);
+int sgv_pset_destroy(sgv_pset* ps);
+int sgv_pset_power_iteration(sgv_pset* ps, int train, void* stream);
+const float* sgv_pset_sigma(const sgv_pset* ps, int entry);
+int sgv_pset_step(sgv_pset* ps, float lr, float weight_decay, float max_norm, float* total_norm_host, void* stream);
+
 /* [Bn][I][J] -> [Bn][J][I] with dtype conversion (reference NCHW fp32 <-> channels-last compute dtype). */
 int sgv_op_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, void* stream);
 

@@ -144,7 +144,7 @@ int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipSt
 template <bool UPDATE, bool WC_BF16>
 __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
                                                    float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
-                                                   double* gnorm_sq) {
+                                                   double* gnorm_sq, const float* gscale) {
     const WorkItem it = items[blockIdx.x];
     const AdamDesc a = adam[it.desc];
     const long lo = (long)it.chunk * OPT_CHUNK;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
         }
         nacc += g.x * g.x + g.y * g.y + g.z * g.z + g.w * g.w;
         if constexpr (UPDATE) {
+            if (gscale) { const float gs = gscale[0]; g.x *= gs; g.y *= gs; g.z *= gs; g.w *= gs; }   // clip_grad_norm_ coefficient
             float4 p = *reinterpret_cast<const float4*>(a.p + i);
             float4 m = *reinterpret_cast<const float4*>(a.m + i);
             float4 vs = *reinterpret_cast<const float4*>(a.v + i);
@@ -302,14 +303,14 @@ int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem*
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
-              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s) {
-    if (n > 0 && compute_dtype == 1) hipLaunchKernelGGL((adamw_kernel<true, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
-    else if (n > 0) hipLaunchKernelGGL((adamw_kernel<true, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* gscale) {
+    if (n > 0 && compute_dtype == 1) hipLaunchKernelGGL((adamw_kernel<true, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, gscale);
+    else if (n > 0) hipLaunchKernelGGL((adamw_kernel<true, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, gscale);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
                   hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL((adamw_kernel<false, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, gnorm_sq);
+    if (n > 0) hipLaunchKernelGGL((adamw_kernel<false, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, 0.f, 0.f, 0.f, 0.f, 0.f, 1.f, 1.f, gnorm_sq, (const float*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 

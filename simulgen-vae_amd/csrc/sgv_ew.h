@@ -99,7 +99,7 @@ int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int 
                            int ndesc, int train, hipStream_t s);
 int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipStream_t s);
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
-              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s);
+              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* gscale = nullptr);
 // 64x64-tile AdamW for spectrally-normalised conv weights; also writes wc/wct and accumulates W_new^T u into tmp_t
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s);

@@ -48,6 +48,9 @@ class LCOptimizer:
     def clip_and_step(self, max_norm=10.0, lr=None):
         """-> total gradient norm before clipping (float, as clip_grad_norm_ returns)."""
         lr = self.param_groups[0]["lr"] if lr is None else lr
+        if self.model._fused():            # multi-tensor path: <G,W> dots, norm, clip coefficient, AdamW in 5 launches
+            self.steps += 1
+            return self.model.pset.step(lr, self.weight_decay, max_norm)
         params = self.model.named_parameters()
         acc = torch.zeros(1, dtype=torch.float64, device="cuda")
         have = [(n, p, self.model.grads[n]) for n, p in params if n in self.model.grads]

@@ -37,13 +37,17 @@ def _num_groups(channels):
 class LatentConditionerImg:
     def __init__(self, latent_conditioner_filter, latent_dim_end, input_shape, latent_dim, size2,
                  latent_conditioner_data_shape, dropout_rate=0.3, use_attention=True, return_dict=False,
-                 compute_dtype="bf16", seed=0):
+                 compute_dtype="bf16", seed=0, fused_params=True):
         self.filters = [int(v) for v in latent_conditioner_filter]
         self.latent_dim, self.size2, self.latent_dim_end = int(latent_dim), int(size2), int(latent_dim_end)
         self.dropout_rate, self.use_attention, self.return_dict = float(dropout_rate), bool(use_attention), bool(return_dict)
         self.compute_dtype = compute_dtype
         self.dt = ops.tdtype(compute_dtype)
         self.training = True
+        # fused_params: spectral-norm power iteration, clipping and AdamW run as multi-tensor passes over fixed gradient
+        # buffers (ops.ParamSet); otherwise one operator call per tensor (the mode the gradient parity tests read)
+        self.fused_params = bool(fused_params)
+        self.pset = None
         if any(c % 16 for c in self.filters):
             raise SgvError("latent_conditioner_filter entries must be multiples of 16 (bottleneck channels feed 8-wide GEMM tiles)")
         self.blocks = []
@@ -154,17 +158,21 @@ class LatentConditionerImg:
                 if tuple(a.shape) != tuple(shape):
                     raise RuntimeError(f"size mismatch for {name}: {tuple(a.shape)} vs {tuple(shape)}")
                 self.P[name] = a.contiguous().cuda()
+        self.pset = None            # parameter tensors were replaced: rebuild the tables on next use
         return self
 
     def __getstate__(self):
         d = dict(self.__dict__)
         d["P"] = {k: v.detach().cpu().numpy() for k, v in self.P.items()}
-        d["grads"], d["_tape"] = {}, None
+        d["grads"], d["_tape"], d["pset"] = {}, None, None
+        d.pop("G", None)
+        d.pop("_entry", None)
         return d
 
     def __setstate__(self, d):
         self.__dict__.update(d)
         self.P = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in d["P"].items()}
+        self.pset = None
 
     def named_parameters(self):
         return [(n, self.P[n]) for n, _, k in self._spec() if k == "w"]
@@ -190,18 +198,62 @@ class LatentConditionerImg:
         re-initialises the non-normalised Linear layers; accepted as a no-op here (parity runs load a state)."""
         return self
 
+    # ---- fused parameter passes -----------------------------------------------------------------------------------
+    def _build_pset(self):
+        """One flat gradient arena (views per parameter) + the multi-tensor tables.  Normalised weights whose matrix has
+        cols % 4 == 0 are registered as such (their arena slot then holds the gradient wrt W/sigma and the step applies the
+        chain rule); the 7x7 stem (49 columns) keeps the per-tensor path."""
+        names = [(n, sh) for n, sh, k in self._spec() if k == "w"]
+        sizes = [(int(np.prod(sh)) + 3) // 4 * 4 for _, sh in names]
+        self._arena = torch.zeros(sum(sizes), dtype=torch.float32, device="cuda")
+        self.G, self._entry, entries, off = {}, {}, [], 0
+        for (n, sh), sz in zip(names, sizes):
+            numel = int(np.prod(sh))
+            self.G[n] = self._arena[off:off + numel].view(sh)
+            off += sz
+            e = dict(p=self.P[n], g=self.G[n])
+            if n.endswith("weight_orig"):
+                rows, cols = sh[0], numel // sh[0]
+                if cols % 4 == 0 and numel % 4 == 0:
+                    pre = n[:-len(".weight_orig")]
+                    e.update(rows=rows, cols=cols, u=self.P[pre + ".weight_u"], v=self.P[pre + ".weight_v"])
+            if numel % 4:
+                self.pset = False        # a tensor the vector kernels cannot take: stay on the per-tensor path
+                return
+            self._entry[n] = len(entries)
+            entries.append(e)
+        self.pset = ops.ParamSet(entries)
+
+    def _fused(self):
+        if not self.fused_params:
+            return False
+        if self.pset is None:
+            self._build_pset()
+        return bool(self.pset)
+
+    def _is_fused_sn(self, prefix):
+        return self._fused() and self.pset.entries[self._entry[prefix + ".weight_orig"]].get("rows", 0) > 0
+
     # ---- layer helpers: each returns (output, backward closure) ---------------------------------------------------
     def _acc(self, name, g):
-        self.grads[name] = g if name not in self.grads else ops.addf(self.grads[name], g)
+        if self._fused():
+            self.G[name].copy_(g.view(self.G[name].shape))        # fixed buffer the multi-tensor step reads
+            self.grads[name] = self.G[name]
+        else:
+            self.grads[name] = g if name not in self.grads else ops.addf(self.grads[name], g)
 
     def _sn(self, prefix, Wm):
-        return ops.sn_power_iteration(Wm, self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"], self.training)
+        """-> (sigma2 tensor or None, device address of 1/sigma)"""
+        if self._is_fused_sn(prefix):          # sigma was computed for every layer at the start of this forward
+            return None, self.pset.sigma_ptr(self._entry[prefix + ".weight_orig"]) + 4
+        sig2 = ops.sn_power_iteration(Wm, self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"], self.training)
+        return sig2, sig2.data_ptr() + 4
 
     def _conv(self, prefix, x4, k, stride, pad, need_dx=True):
         W = self.P[prefix + ".weight_orig"]
         co, ci = W.shape[0], W.shape[1]
         Wm = W.view(co, -1)
-        sig2 = self._sn(prefix, Wm)
+        sig2, inv_sigma = self._sn(prefix, Wm)
         Wp = ops.conv_weight_pack(W, self.dt)
         B, H, Wd, _ = x4.shape
         direct = (k == 1 and stride == 1 and ci % 8 == 0)
@@ -209,17 +261,20 @@ class LatentConditionerImg:
             col, Ho, Wo = x4.view(-1, ci), H, Wd
         else:
             col, Ho, Wo = ops.im2col(x4, k, k, stride, pad)
-        y = ops.gemm_nt(col, Wp, scale=sig2[1:2]).view(B, Ho, Wo, co)
+        y = ops.gemm_nt(col, Wp, scale=inv_sigma).view(B, Ho, Wo, co)
         u, v = self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"]
 
         def bwd(dy4):
             dy = dy4.reshape(-1, co)
             G = ops.conv_weight_unpack(ops.gemm_tn(dy, col), W.shape)           # gradient wrt W / sigma
-            self._acc(prefix + ".weight_orig", ops.sn_grad(G.view(co, -1), u, v, Wm, sig2).view(W.shape))
+            if sig2 is None:
+                self._acc(prefix + ".weight_orig", G)                            # chain rule applied by the fused step
+            else:
+                self._acc(prefix + ".weight_orig", ops.sn_grad(G.view(co, -1), u, v, Wm, sig2).view(W.shape))
             if not need_dx:
                 return None
             Wt = ops.transpose(Wp.view(1, co, -1), self.dt, 1, co, Wp.shape[1]).view(Wp.shape[1], co)
-            dcol = ops.gemm_nt(dy, Wt, scale=sig2[1:2])
+            dcol = ops.gemm_nt(dy, Wt, scale=inv_sigma)
             return dcol.view(x4.shape) if direct else ops.col2im(dcol, x4.shape, k, k, stride, pad)
         return y, bwd
 
@@ -241,8 +296,7 @@ class LatentConditionerImg:
     def _linear(self, prefix, x, sn, act=ops.LIN_NONE):
         W = self.P[prefix + (".weight_orig" if sn else ".weight")]
         b = self.P[prefix + ".bias"]
-        sig2 = self._sn(prefix, W) if sn else None
-        scale = sig2[1:2] if sn else None
+        sig2, scale = self._sn(prefix, W) if sn else (None, None)
         y = ops.linear_fwd(x, W, b, scale, act)
 
         def bwd(dy):
@@ -251,7 +305,10 @@ class LatentConditionerImg:
             self._acc(prefix + ".bias", db)
             if sn:       # sn_grad wants G = dz^T x, the gradient wrt W / sigma
                 G = ops.linear_bwd(dz, x, W, None, need_dx=False, has_bias=False)[1]
-                self._acc(prefix + ".weight_orig", ops.sn_grad(G, self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"], W, sig2))
+                if sig2 is None:
+                    self._acc(prefix + ".weight_orig", G)
+                else:
+                    self._acc(prefix + ".weight_orig", ops.sn_grad(G, self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"], W, sig2))
             else:
                 self._acc(prefix + ".weight", dW)
             return dx
@@ -344,6 +401,8 @@ class LatentConditionerImg:
             x = (x + 1) / 2
         masks = list(dropout_masks) if dropout_masks is not None else None
         self.grads = {}
+        if self._fused():
+            self.pset.power_iteration(self.training)       # every normalised layer at once (legacy hook semantics per module)
         back = []
         x4 = x.to(self.dt).contiguous().view(B, side, side, 1)
         c0, bw = self._conv("initial_conv.0", x4, 7, 1, 3, need_dx=False)

@@ -19,7 +19,7 @@ OPS_SYMBOLS = [
     "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
     "sgv_op_mse", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
     "sgv_op_conv_weight_unpack", "sgv_op_sumsq", "sgv_op_clip_coef", "sgv_op_adamw", "sgv_op_flip_roll", "sgv_op_affine_sample",
-    "sgv_op_mixup_rows",
+    "sgv_op_mixup_rows", "sgv_pset_create", "sgv_pset_destroy", "sgv_pset_power_iteration", "sgv_pset_sigma", "sgv_pset_step",
 ]
 ACT_NONE, ACT_RELU_GN = 0, 3            # GroupNorm activation ids (ew.hip)
 LIN_NONE, LIN_RELU, LIN_SIGMOID = 0, 1, 2
@@ -76,15 +76,23 @@ def lib():
             "sgv_op_affine_sample": [vp, vp, i, i, i, vp, vp],
             "sgv_op_mixup_rows": [vp, vp, f, vp, i, lg, vp],
         }
+        sig["sgv_pset_create"] = [vp, i, vp]
+        sig["sgv_pset_destroy"] = [vp]
+        sig["sgv_pset_power_iteration"] = [vp, i, vp]
+        sig["sgv_pset_sigma"] = [vp, i]
+        sig["sgv_pset_step"] = [vp, f, f, f, vp, vp]
         for name, args in sig.items():
             getattr(l, name).argtypes = args
+        l.sgv_pset_sigma.restype = C.c_void_p
         l.sgv_op_gn_workspace_floats.restype = C.c_size_t
         _lib = l
     return _lib
 
 
 def _p(t):
-    return None if t is None else C.c_void_p(t.data_ptr())
+    if t is None:
+        return None
+    return C.c_void_p(t) if isinstance(t, int) else C.c_void_p(t.data_ptr())        # raw device address or tensor
 
 
 def _stream():
@@ -416,3 +424,49 @@ def mixup_rows(x, perm, lam):
     pm = _ivec(perm, x.device)
     _ck(lib().sgv_op_mixup_rows(_p(x), _p(pm), float(lam), _p(out), B, n, _stream()), "sgv_op_mixup_rows")
     return out
+
+
+# ---- parameter set ----
+class PsetEntry(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("n", C.c_long), ("rows", C.c_int), ("cols", C.c_int), ("u", C.c_void_p), ("v", C.c_void_p)]
+
+
+class ParamSet:
+    """sgv_pset_*: multi-tensor spectral-norm power iteration + clip + AdamW over fixed (parameter, gradient) buffers.
+    entries: list of dicts(p=, g=, u=None, v=None, rows=0, cols=0) of fp32 CUDA tensors (kept alive by this object)."""
+
+    def __init__(self, entries):
+        self.entries = entries
+        arr = (PsetEntry * len(entries))()
+        for k, e in enumerate(entries):
+            arr[k].p, arr[k].g, arr[k].n = e["p"].data_ptr(), e["g"].data_ptr(), e["p"].numel()
+            arr[k].rows, arr[k].cols = int(e.get("rows", 0)), int(e.get("cols", 0))
+            arr[k].u = e["u"].data_ptr() if e.get("u") is not None else None
+            arr[k].v = e["v"].data_ptr() if e.get("v") is not None else None
+        h = C.c_void_p()
+        _ck(lib().sgv_pset_create(arr, len(entries), C.byref(h)), "sgv_pset_create")
+        self.h = h
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib().sgv_pset_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def power_iteration(self, train):
+        _ck(lib().sgv_pset_power_iteration(self.h, int(train), _stream()), "sgv_pset_power_iteration")
+
+    def sigma_ptr(self, entry):
+        """device address of {sigma, 1/sigma} of a normalised entry"""
+        return int(lib().sgv_pset_sigma(self.h, entry))
+
+    def step(self, lr, weight_decay, max_norm, want_norm=True):
+        out = C.c_float(0.0)
+        _ck(lib().sgv_pset_step(self.h, float(lr), float(weight_decay), float(max_norm), C.byref(out) if want_norm else None, _stream()),
+            "sgv_pset_step")
+        return out.value if want_norm else None

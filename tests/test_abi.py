@@ -27,7 +27,7 @@ def test_library_exports_every_operator_symbol():
     """include/sgvae_ops.h (latent-conditioner operators) vs simulgen_vae_amd.ops.OPS_SYMBOLS vs the library."""
     from simulgen_vae_amd import ops
     hdr = open(os.path.join(ROOT, "include", "sgvae_ops.h")).read()
-    declared = set(re.findall(r"\b(sgv_op_[a-z_0-9]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b(sgv_(?:op|pset)_[a-z_0-9]+)\s*\(", hdr))
     assert declared == set(ops.OPS_SYMBOLS), declared ^ set(ops.OPS_SYMBOLS)
     lib = E.load_library()
     for s in declared:

@@ -223,7 +223,7 @@ def test_latent_conditioner_matches_reference_golden():
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lc_small.npz"))
     latent_end, latent, size2, img, B = (int(v) for v in g["meta"])
     m = LatentConditionerImg([int(v) for v in g["filters"]], latent_end, (1, img, img), latent, size2, (img, img), dropout_rate=0.3,
-                             use_attention=True, compute_dtype="f32")
+                             use_attention=True, compute_dtype="f32", fused_params=False)     # per-tensor mode: m.grads = d loss / d parameter
     keys = [k[3:] for k in g.files if k.startswith("s0.")]
     assert keys == list(m.state_dict().keys())                      # the reference's 148 state_dict keys, same order
     sd0 = {k: torch.from_numpy(g["s0." + k]) for k in keys}
@@ -299,26 +299,30 @@ def test_latent_conditioner_optimizer_and_training_loop(tmp_path, monkeypatch):
     monkeypatch.chdir(tmp_path)
     g = np.load(os.path.join(os.path.dirname(__file__), "golden", "lc_small.npz"))
     latent_end, latent, size2, img, B = (int(v) for v in g["meta"])
-    mk = lambda: LatentConditionerImg([int(v) for v in g["filters"]], latent_end, (1, img, img), latent, size2, (img, img), dropout_rate=0.3,
-                                      use_attention=True, compute_dtype="f32")
-    m = mk()
     keys = [k[3:] for k in g.files if k.startswith("s0.")]
-    m.load_state_dict({k: torch.from_numpy(g["s0." + k]) for k in keys})
-    m.train()
-    masks = [torch.from_numpy(g[f"mask{i}"]).cuda() for i in range(7)]
-    m.loss_backward(torch.from_numpy(g["x"]), g["y1"], g["y2"], dropout_masks=masks)
-    opt, sched, _, warm = lc.setup_optimizer_and_scheduler(m, 1e-3, 1e-4, 300)
-    assert warm == 100 and abs(sched(0) - 1e-5) < 1e-12
-    total = opt.clip_and_step(max_norm=10.0, lr=1e-3)
-    assert abs(total - float(g["total_norm"][0])) < 1e-3 * float(g["total_norm"][0])
-    s1 = m.state_dict()
     # the four Linear biases in front of a training-mode BatchNorm have a true gradient of exactly zero; the reference's
     # ~1e-9 rounding noise there is turned into +-lr by Adam's first step, so those entries are not comparable
     noise = {"latent_main_layer1.0.bias", "latent_main_layer2.0.bias", "xs_layer1.0.bias", "xs_layer2.0.bias"}
-    worst = max((rel(s1[n], torch.from_numpy(g["s1." + n])), n) for n, _ in m.named_parameters() if n not in noise)
-    assert worst[0] < 5e-4, worst            # first Adam step moves every weight by ~lr: a wrong gradient sign would show as >= 5e-3 here
-    for n in noise:
-        assert float((s1[n] - torch.from_numpy(g["s0." + n])).abs().max()) <= 1.001e-3
+    for fused in (False, True):      # per-tensor operators, then the multi-tensor parameter set (sgv_pset_*)
+        m = LatentConditionerImg([int(v) for v in g["filters"]], latent_end, (1, img, img), latent, size2, (img, img), dropout_rate=0.3,
+                                 use_attention=True, compute_dtype="f32", fused_params=fused)
+        m.load_state_dict({k: torch.from_numpy(g["s0." + k]) for k in keys})
+        m.train()
+        masks = [torch.from_numpy(g[f"mask{i}"]).cuda() for i in range(7)]
+        m.loss_backward(torch.from_numpy(g["x"]), g["y1"], g["y2"], dropout_masks=masks)
+        assert bool(m._fused()) == fused
+        opt, sched, _, warm = lc.setup_optimizer_and_scheduler(m, 1e-3, 1e-4, 300)
+        assert warm == 100 and abs(sched(0) - 1e-5) < 1e-12
+        total = opt.clip_and_step(max_norm=10.0, lr=1e-3)
+        assert abs(total - float(g["total_norm"][0])) < 1e-3 * float(g["total_norm"][0]), fused
+        s1 = m.state_dict()
+        worst = max((rel(s1[n], torch.from_numpy(g["s1." + n])), n) for n, _ in m.named_parameters() if n not in noise)
+        assert worst[0] < 5e-4, (fused, worst)   # first Adam step moves every weight by ~lr: a wrong gradient sign would show as >= 5e-3
+        for n in noise:
+            assert float((s1[n] - torch.from_numpy(g["s0." + n])).abs().max()) <= 1.001e-3
+        for k in keys:
+            if k.endswith("weight_u") or k.endswith("weight_v"):
+                assert rel(s1[k], torch.from_numpy(g["s1." + k])) < 2e-4, (fused, k)
     # short training run on a fixed tiny dataset (bf16 compute as in production)
     random.seed(0)
     np.random.seed(0)
