@@ -281,3 +281,46 @@ def test_fused_backward_step_equals_separate_calls():
     for k in sa:
         a, b = sa[k].astype(np.float64), sb[k].astype(np.float64)
         assert np.mean(np.abs(a - b)) <= 1e-4 * np.mean(np.abs(a)) + 1e-9, k
+
+
+def test_end_to_end_pipeline_of_the_reference_main(tmp_path, monkeypatch):
+    """The stages SimulGen-VAE.py chains (SimulGen-VAE.py:267-473), through the mirrors only: raw [P,T,N] array ->
+    data_scaler (HBM-resident) -> create_augmented_dataloaders -> train (VAE) -> export_latents (model_save/*.npy) ->
+    LatentConditionerImg + train_latent_conditioner on images with the exported latents as targets.  Checks that every
+    hand-off has the reference's shapes / files; values are covered by the per-stage parity tests."""
+    from modules import data_preprocess as dp
+    from modules import utils as U
+    from modules.latent_conditioner_model_cnn import LatentConditionerImg
+    from modules.latent_conditioner import train_latent_conditioner
+    monkeypatch.chdir(tmp_path)
+    torch.manual_seed(0)
+    random.seed(0)
+    np.random.seed(0)
+    enc = [64, 32, 16, 8]
+    P, T, N, B, latent_end, latent = 8, 16, 512, 4, 32, 8
+    raw = np.random.default_rng(1).standard_normal((P, T, N)).astype(np.float32) * 3.0
+    dev, shape, scaler = dp.data_scaler(raw.copy(), raw, T, N, 1, device_dataset=True, compute_dtype="bf16")
+    assert dev.shape == (P, N, T) and tuple(shape) == (T, N)
+    tl, vl = aug.create_augmented_dataloaders(dev, B, load_all=True)
+    out = tr.train(4, B, tl, vl, 1e-3, enc, enc[::-1], N, latent_end, latent, T, 1e6, "MSE", True, True)
+    assert len(out) == 4 and all(len(a) == 4 for a in out) and np.all(np.isfinite(out[0]))
+    m = torch.load("model_save/SimulGen-VAE", weights_only=False)          # our own pickle, written by train() above
+    m.eval()
+    x_all = np.stack([dev[i].cpu().numpy() for i in range(P)])             # [P, N, T] as the reference holds new_x_train
+    lat, hier, rl = U.export_latents(m, x_all, enc, latent, latent_end)
+    assert lat.shape == (P, latent_end) and hier.shape == (P, len(enc) - 1, latent) and np.all(np.isfinite(rl))
+    assert os.path.exists("model_save/latent_vectors.npy") and os.path.exists("model_save/xs.npy") and os.path.exists("SimulGen-VAE_L2_loss.txt")
+    # latent conditioner on synthetic 16x16 "images" with the exported latents as regression targets
+    imgs = np.random.default_rng(2).random((P, 16 * 16)).astype(np.float32)
+    y1 = np.load("model_save/latent_vectors.npy").astype(np.float32)
+    y2 = np.load("model_save/xs.npy").astype(np.float32)
+    batches = [(imgs[i:i + 4], y1[i:i + 4], y2[i:i + 4]) for i in range(0, P, 4)]
+    lcm = LatentConditionerImg([16, 32, 32, 64, 64, 128], latent_end, (1, 16, 16), latent, len(enc) - 1, (16, 16), dropout_rate=0.2)
+    val = train_latent_conditioner(3, batches, batches[:1], lcm, 1e-3, weight_decay=1e-5, is_image_data=True)
+    assert np.isfinite(val) and os.path.exists("checkpoints/latent_conditioner.pth") and os.path.exists("model_save/LatentConditioner")
+    lcm.eval()
+    p1, p2 = lcm(imgs[:2])
+    assert tuple(p1.shape) == (2, latent_end) and tuple(p2.shape) == (2, len(enc) - 1, latent)
+    # the conditioner's predictions feed the VAE decoder (reference: latent_conditioner_e2e.py:371, utils.py:499)
+    xh, _ = m.decoder(p1, [p2[:, i].contiguous() for i in range(p2.shape[1])], mode="fix")
+    assert tuple(xh.shape) == (2, N, T) and bool(torch.isfinite(xh).all())
