@@ -26,9 +26,9 @@ static inline int cdivi(long a, long b) { return (int)((a + b - 1) / b); }
 // ------------------------------------------------------------------------------------------------------------
 struct ConvGeom { int B, H, W, C, KH, KW, S, P, Ho, Wo, Kp; };
 
-// thread = (row lane, k lane): a block covers `rows_pb` = 256 / kw_ consecutive output pixels x kw_ = min(Kp, 256) values of
-// k per pass and 8 passes of rows; a thread decodes its k once, the (b, oh, ow) of a row costs three divisions per 56..256
-// contiguous elements written
+// thread = (row lane, k lane): kw_ = min(Kp, 256) k lanes, rows_pb = 256 / kw_ row lanes; a block walks 32 * rows_pb
+// consecutive output pixels.  A thread decodes its k once and keeps (b, oh, ow) of its row incrementally (stride
+// rows_pb), so the loop body has no divisions and every row of `col` is written as one contiguous run.
 template <typename T>
 __global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeom g, int kw_) {
     const int kl = threadIdx.x % kw_, rl = threadIdx.x / kw_, rows_pb = 256 / kw_;
@@ -37,17 +37,19 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeo
     const bool live = k < g.KH * g.KW * g.C;
     const int c = live ? k % g.C : 0, t = live ? k / g.C : 0, kw = t % g.KW, kh = t / g.KW;
     const long M = (long)g.B * g.Ho * g.Wo;
+    long m = (long)blockIdx.x * 32 * rows_pb + rl;
+    if (m >= M) return;
+    int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
     const T zero = from_f32<T>(0.f);
-    for (int pass = 0; pass < 8; ++pass) {
-        const long m = ((long)blockIdx.x * 8 + pass) * rows_pb + rl;
-        if (m >= M) return;
+    for (int pass = 0; pass < 32 && m < M; ++pass, m += rows_pb) {
         T v = zero;
         if (live) {
-            const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
             const int h = oh * g.S - g.P + kh, w = ow * g.S - g.P + kw;
             if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) v = x[(((long)b * g.H + h) * g.W + w) * g.C + c];
         }
         col[m * g.Kp + k] = v;
+        ow += rows_pb;
+        while (ow >= g.Wo) { ow -= g.Wo; if (++oh == g.Ho) { oh = 0; ++b; } }
     }
 }
 // dx[b][h][w][c] = sum over the windows that cover (h,w) of dcol (gather form: no atomics, deterministic);
@@ -522,7 +524,7 @@ int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int 
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
     const long Mrows = (long)B * g.Ho * g.Wo;
     const int kw_ = g.Kp < 256 ? g.Kp : 256, rows_pb = 256 / kw_;
-    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3((unsigned)((Mrows + 8L * rows_pb - 1) / (8L * rows_pb)), cdivi(g.Kp, kw_)), dim3(256), 0, ST(stream), CPT(x), PT(col), g, kw_));
+    ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3((unsigned)((Mrows + 32L * rows_pb - 1) / (32L * rows_pb)), cdivi(g.Kp, kw_)), dim3(256), 0, ST(stream), CPT(x), PT(col), g, kw_));
     return OPLAUNCH_OK();
 }
 int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
