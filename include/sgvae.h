@@ -202,7 +202,7 @@ int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const flo
                      const void* addend, int M, int N, int K, int taps, int Tlen, int splitk, int out_f32,
                      void* stream);
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,
-                     int Tlen, int splitk, int use_tr /* 2: also force the opt-in 128x256 kernel */, void* stream);
+                     int Tlen, int splitk, int use_tr /* 2: force the 128x256 two-blocks-per-CU kernel */, void* stream);
 
 #ifdef __cplusplus
 }

@@ -814,20 +814,24 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
 }
 
 // =========================================================================================
-// TN, LDS-DMA, 128 (N1) x 256 (N2) tile, 64 reduction rows per stage, software-pipelined ("tn_wide", bf16 only).
-// Same ring / hand-off / fragment double-buffering as gemm_nt_wide64p_kernel; the operands are m-major, so a stage is
-// 64 rows x 256 B of dY and 64 rows x 512 B of X exactly as they lie in memory, and MFMA fragments come from
+// TN, LDS-DMA, 128 (N1) x 256 (N2) tile, 32 reduction rows per stage, TWO blocks per CU ("tn_w2", bf16 only).
+// The operands are m-major, so a stage is 32 rows x 256 B of dY and 32 rows x 512 B of X exactly as they lie in memory
+// (HBM/L2 -> LDS with buffer_load ... lds, 3 x 24 KiB ring, counted vmcnt), and MFMA fragments come from
 // ds_read_b64_tr_b16.  A 16-lane group of that instruction reads 4 consecutive rows x 32 B: with 256/512-byte row
 // pitches those rows would share banks, so the 16-byte chunk c of row r is stored at chunk slot c ^ ((r & 3) << 2)
 // (the DMA applies the permutation on the source side, the fragment reads on the LDS side): the four rows land in four
-// different 64-byte bank groups.  Wave w DMAs rows [16w, 16w+16) of both operands (4 + 8 ops per stage, vmcnt(12)).
-// Needs Tlen >= 64 (one conditional subtract keeps the per-row time index).
+// different 64-byte bank groups.  The 64x128 per-wave tile keeps LDS traffic at 0.75 KiB per MFMA (the 128x128 kernel
+// needs 1 KiB, which is the LDS peak at full MFMA rate); 72 KiB of LDS and 198 registers let two blocks share a CU, so
+// one block's stage hand-off, prologue and epilogue hide under the other's MFMAs.  Wave w DMAs rows [8w, 8w+8) of both
+// operands (2 + 4 ops per stage, vmcnt(6)).  Needs Tlen >= 32 (one conditional subtract keeps the per-row time index).
+// The transposed reads and the boundary stores are inline asm with hand-tracked lgkmcnt: the builtin / plain C++ LDS
+// accesses make the compiler put s_waitcnt vmcnt(0) in front of them while LDS-DMA is in flight.
 // =========================================================================================
-__global__ __launch_bounds__(256, 1) void gemm_tn_wide_kernel(const GemmTN p) {
-    constexpr int ESZ = 2, KR = 64;
+__global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
+    constexpr int ESZ = 2, KR = 32;
     constexpr int ROWA = 256, ROWX = 512;
     constexpr int TILEA = KR * ROWA, TILEX = KR * ROWX;
-    constexpr int STAGEB = TILEA + TILEX;       // 48 KiB
+    constexpr int STAGEB = TILEA + TILEX;       // 24 KiB
     constexpr int NS = 3;
     __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * STAGEB];
 
@@ -850,64 +854,62 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_wide_kernel(const GemmTN p) {
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
     const int lda_b = (int)(p.lda * ESZ), ldx_b = (int)(p.ldb * ESZ);
-    // DMA lane roles.  dY op q: rows 16w + 4q + (lane>>4), slot lane&15.  X op q: rows 16w + 2q + (lane>>5), slot lane&31.
-    // No per-row predicates at issue time (with one wave per SIMD every VALU/SALU instruction competes with MFMA issue):
+    // DMA lane roles.  dY op q: rows 8w + 4q + (lane>>4), slot lane&15.  X op q: rows 8w + 2q + (lane>>5), slot lane&31.
+    // No per-row predicates at issue time:
     //  * rows >= M and rows m+dt outside [0, M) fall outside the buffer extents -> the hardware returns zeros;
     //  * columns past N1/N2 start from OOB_OFF (sum stays >= the extent, < 2^32 because row offsets are < 2^31);
-    //  * X rows whose tap leaves the sample window (at most |dt| <= 2 rows per 64-row stage, Tlen >= 64) are zeroed
-    //    in LDS after they landed (SGV_TW_FIX), only in the stages that contain a sample boundary.
+    //  * X rows whose tap leaves the sample window (at most |dt| <= 2 rows per boundary) are zeroed in LDS after they
+    //    landed (SGV_T2_FIX), only in the stages that contain a sample boundary.
     const int la_row = lane >> 4;
-    const int la_chunk = (lane & 15) ^ (la_row << 2);                 // (16w + 4q) % 4 == 0
+    const int la_chunk = (lane & 15) ^ (la_row << 2);
     const uint32_t a_col = (i0 + la_chunk * 8) < p.N1 ? (uint32_t)((i0 + la_chunk * 8) * ESZ) : OOB_OFF;
     const int lx_row = lane >> 5;
-    const int lx_chunk0 = (lane & 31) ^ (lx_row << 2);                // q even: (2q + lx_row) & 3 = lx_row
-    const int lx_chunk1 = (lane & 31) ^ ((2 + lx_row) << 2);          // q odd
+    const int lx_chunk0 = (lane & 31) ^ (lx_row << 2);
+    const int lx_chunk1 = (lane & 31) ^ ((2 + lx_row) << 2);
     const uint32_t x_col0 = (j0 + lx_chunk0 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk0 * 8) * ESZ) : OOB_OFF;
     const uint32_t x_col1 = (j0 + lx_chunk1 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk1 * 8) * ESZ) : OOB_OFF;
-    uint32_t aoffs[4], xoffs[8];
+    uint32_t aoffs[2], xoffs[4];
 #pragma unroll
-    for (int q = 0; q < 4; ++q) aoffs[q] = (uint32_t)(wave * 16 + q * 4 + la_row) * (uint32_t)lda_b + a_col;
+    for (int q = 0; q < 2; ++q) aoffs[q] = (uint32_t)(wave * 8 + q * 4 + la_row) * (uint32_t)lda_b + a_col;
 #pragma unroll
-    for (int q = 0; q < 8; ++q)
-        xoffs[q] = (uint32_t)(wave * 16 + q * 2 + lx_row + dt) * (uint32_t)ldx_b + ((q & 1) ? x_col1 : x_col0);
-    unsigned char* const dmaA = smem + wave * 16 * ROWA;
-    unsigned char* const dmaX = smem + TILEA + wave * 16 * ROWX;
-    uint32_t ld_a = (uint32_t)(s_begin * KR) * (uint32_t)lda_b;      // byte offset of the next stage's first row
+    for (int q = 0; q < 4; ++q)
+        xoffs[q] = (uint32_t)(wave * 8 + q * 2 + lx_row + dt) * (uint32_t)ldx_b + ((q & 1) ? x_col1 : x_col0);
+    unsigned char* const dmaA = smem + wave * 8 * ROWA;
+    unsigned char* const dmaX = smem + TILEA + wave * 8 * ROWX;
+    uint32_t ld_a = (uint32_t)(s_begin * KR) * (uint32_t)lda_b;
     uint32_t ld_x = (uint32_t)(s_begin * KR) * (uint32_t)ldx_b;
-    int rd_t = (s_begin * KR) % p.Tlen;                               // time index of the first row of the next stage to READ
+    int rd_t = (s_begin * KR) % p.Tlen;
     const uint32_t zero_base = (uint32_t)(uintptr_t)(lds_void*)smem + TILEA + (tid & 31) * 16;
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
-#define SGV_TW_A(Q, STAGE)                                                                                    \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) * STAGEB + (Q) * 1024), 16,      \
+#define SGV_T2_A(Q, STAGE)                                                                                    \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) + (Q) * 1024), 16,      \
                                              aoffs[Q] + ld_a, 0, 0, 0);
-#define SGV_TW_X(Q, STAGE)                                                                                    \
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(dmaX + (STAGE) * STAGEB + (Q) * 1024), 16,      \
+#define SGV_T2_X(Q, STAGE)                                                                                    \
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(dmaX + (STAGE) + (Q) * 1024), 16,      \
                                              xoffs[Q] + ld_x, 0, 0, 0);
-#define SGV_TW_ISSUE(STAGE)                                                                                   \
+#define SGV_T2_ISSUE(STAGE)                                                                                   \
     {                                                                                                         \
-        SGV_TW_A(0, STAGE) SGV_TW_A(1, STAGE) SGV_TW_A(2, STAGE) SGV_TW_A(3, STAGE)                           \
-        SGV_TW_X(0, STAGE) SGV_TW_X(1, STAGE) SGV_TW_X(2, STAGE) SGV_TW_X(3, STAGE)                           \
-        SGV_TW_X(4, STAGE) SGV_TW_X(5, STAGE) SGV_TW_X(6, STAGE) SGV_TW_X(7, STAGE)                           \
+        SGV_T2_A(0, STAGE) SGV_T2_A(1, STAGE)                                                                 \
+        SGV_T2_X(0, STAGE) SGV_T2_X(1, STAGE) SGV_T2_X(2, STAGE) SGV_T2_X(3, STAGE)                           \
         ld_a += (uint32_t)(KR * lda_b); ld_x += (uint32_t)(KR * ldx_b);                                       \
     }
     // X rows of stage STAGE (just landed, barrier passed) whose tap leaves the sample window are zeroed in LDS.  Bad rows
     // sit within |dt| <= 2 rows of a sample boundary; candidates: rows 0,1 (run continuing from the previous stage), the
-    // four rows around the boundary inside the window, rows 62,63 (run leading into a boundary at row 64/65).  Each of the
+    // four rows around a boundary inside the window, rows 30,31 (run leading into a boundary at row 32/33).  Each of the
     // 8 x 32 threads tests one candidate row and clears one 16-byte chunk of it.  Skipped (no extra barrier) when no
     // boundary is near the window.
-#define SGV_TW_FIX(STAGE)                                                                                     \
+#define SGV_T2_FIX(STAGE)                                                                                     \
     {                                                                                                         \
         const bool near_ = dt != 0 && (rd_t < 2 || rd_t + KR + 2 > p.Tlen);                                   \
         if (near_) {                                                                                          \
             const int rb_ = rd_t == 0 ? 0 : p.Tlen - rd_t;                                                    \
             const int c_ = tid >> 5;                                                                          \
-            const int r_ = c_ < 2 ? c_ : (c_ < 6 ? rb_ - 4 + c_ : 56 + c_);                                   \
+            const int r_ = c_ < 2 ? c_ : (c_ < 6 ? rb_ - 4 + c_ : 24 + c_);                                   \
             int t_ = rd_t + r_;                                                                               \
             if (t_ >= p.Tlen) t_ -= p.Tlen;                                                                   \
             if (r_ >= 0 && r_ < KR && (unsigned)(t_ + dt) >= (unsigned)p.Tlen) {                              \
-                /* inline asm: a C++ store to LDS makes the compiler drain every in-flight LDS-DMA (vmcnt(0)) */ \
-                const uint32_t za_ = zero_base + (uint32_t)((STAGE) * STAGEB + r_ * ROWX);                    \
+                const uint32_t za_ = zero_base + (uint32_t)((STAGE) + r_ * ROWX);                    \
                 asm volatile("ds_write_b128 %0, %1" :: "v"(za_), "v"(zero4) : "memory");                      \
             }                                                                                                 \
             asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                   \
@@ -924,28 +926,21 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_wide_kernel(const GemmTN p) {
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    // ds_read_b64_tr_b16 roles: 16-lane group g, lane 4*qq + pp of it addresses row qq, 8 bytes at column 4*pp.
-    // The reads are INLINE ASM: the compiler treats the ds_read_tr builtin as possibly aliasing the in-flight LDS-DMA
-    // writes and puts s_waitcnt vmcnt(0) in front of it, which serialises the whole ring.  Consequently their
-    // lgkmcnt is tracked by hand: SGV_TW_WAIT ties the fragment registers to an explicit s_waitcnt.
     const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int rowpart = 8 * (g >> 1) + qq;                                        // + 16*ks (+4 for the upper half)
-    const uint32_t smem_b = (uint32_t)(uintptr_t)(lds_void*)smem;                 // LDS byte address of the ring
-    const uint32_t a_base = smem_b + rowpart * ROWA + 32 * (g & 1) + 8 * pp;      // + ((a ^ qq) * 64)
+    const int rowpart = 8 * (g >> 1) + qq;
+    const uint32_t smem_b = (uint32_t)(uintptr_t)(lds_void*)smem;
+    const uint32_t a_base = smem_b + rowpart * ROWA + 32 * (g & 1) + 8 * pp;
     const uint32_t fa0 = a_base + ((0 ^ qq) << 6), fa1 = a_base + ((1 ^ qq) << 6);
     const uint32_t fa2 = a_base + ((2 ^ qq) << 6), fa3 = a_base + ((3 ^ qq) << 6);
-    const uint32_t fa0h = fa0 + 2 * STAGEB, fa1h = fa1 + 2 * STAGEB, fa2h = fa2 + 2 * STAGEB, fa3h = fa3 + 2 * STAGEB;
     const int xc0 = (8 * wave + 0 + 2 * (g & 1) + (pp >> 1)) ^ (qq << 2);
     const int xc1 = (8 * wave + 4 + 2 * (g & 1) + (pp >> 1)) ^ (qq << 2);
-    const uint32_t fx0s0 = smem_b + TILEA + rowpart * ROWX + xc0 * 16 + 8 * (pp & 1);
-    const uint32_t fx1s0 = smem_b + TILEA + rowpart * ROWX + xc1 * 16 + 8 * (pp & 1);
-    const uint32_t fx0s1 = fx0s0 + STAGEB, fx1s1 = fx1s0 + STAGEB, fx0s2 = fx0s0 + 2 * STAGEB, fx1s2 = fx1s0 + 2 * STAGEB;
+    const uint32_t fx0 = smem_b + TILEA + rowpart * ROWX + xc0 * 16 + 8 * (pp & 1);
+    const uint32_t fx1 = smem_b + TILEA + rowpart * ROWX + xc1 * 16 + 8 * (pp & 1);
     typedef long tr64_t;
     typedef long tr64x2_t __attribute__((ext_vector_type(2)));
-    bf16x8 fA0, fA1, fA2, fA3, fB0, fB1;      // fragment set f
-    bf16x8 gA0, gA1, gA2, gA3, gB0, gB1;      // fragment set g
-    // one fragment = rows k..k+3 and k+4..k+7 of a 32-column block: two transposed 64-bit reads off one address register
-#define SGV_TW_TR(DST, ADDR, IMM, PITCH)                                                                      \
+    bf16x8 fA0, fA1, fA2, fA3, fB0, fB1;
+    bf16x8 gA0, gA1, gA2, gA3, gB0, gB1;
+#define SGV_T2_TR(DST, ADDR, IMM, PITCH)                                                                      \
     {                                                                                                         \
         tr64_t lo_, hi_;                                                                                      \
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"           \
@@ -953,25 +948,22 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_wide_kernel(const GemmTN p) {
         tr64x2_t pr_; pr_[0] = lo_; pr_[1] = hi_;                                                             \
         DST = __builtin_bit_cast(bf16x8, pr_);                                                                \
     }
-    // address register + immediate for fragment reads of (STAGE, KS): immediates must stay below 64 KiB
-#define SGV_TW_AADDR(STAGE, LOW, HIGH) ((STAGE) == 2 ? (HIGH) : (LOW))
-#define SGV_TW_AIMM(STAGE, KS) (((STAGE) == 1 ? STAGEB : 0) + (KS) * 16 * ROWA)
-#define SGV_TW_XADDR(STAGE, S0, S1, S2) ((STAGE) == 0 ? (S0) : ((STAGE) == 1 ? (S1) : (S2)))
-#define SGV_TW_LOAD(X, STAGE, KS)                                                                             \
+    // the stage is a run-time (scalar) byte offset, so the main loop is ONE body: a single live copy of the accumulators
+    // (stage-specialised bodies with several loop exits made the allocator hold two, which does not fit 256 registers)
+#define SGV_T2_LOAD(X, KS)                                                                                    \
     {                                                                                                         \
-        SGV_TW_TR(X##B0, SGV_TW_XADDR(STAGE, fx0s0, fx0s1, fx0s2), (KS) * 16 * ROWX, ROWX)                    \
-        SGV_TW_TR(X##B1, SGV_TW_XADDR(STAGE, fx1s0, fx1s1, fx1s2), (KS) * 16 * ROWX, ROWX)                    \
-        SGV_TW_TR(X##A0, SGV_TW_AADDR(STAGE, fa0, fa0h), SGV_TW_AIMM(STAGE, KS), ROWA)                        \
-        SGV_TW_TR(X##A1, SGV_TW_AADDR(STAGE, fa1, fa1h), SGV_TW_AIMM(STAGE, KS), ROWA)                        \
-        SGV_TW_TR(X##A2, SGV_TW_AADDR(STAGE, fa2, fa2h), SGV_TW_AIMM(STAGE, KS), ROWA)                        \
-        SGV_TW_TR(X##A3, SGV_TW_AADDR(STAGE, fa3, fa3h), SGV_TW_AIMM(STAGE, KS), ROWA)                        \
+        SGV_T2_TR(X##B0, ax0, (KS) * 16 * ROWX, ROWX)                                                         \
+        SGV_T2_TR(X##B1, ax1, (KS) * 16 * ROWX, ROWX)                                                         \
+        SGV_T2_TR(X##A0, aa0, (KS) * 16 * ROWA, ROWA)                                                         \
+        SGV_T2_TR(X##A1, aa1, (KS) * 16 * ROWA, ROWA)                                                         \
+        SGV_T2_TR(X##A2, aa2, (KS) * 16 * ROWA, ROWA)                                                         \
+        SGV_T2_TR(X##A3, aa3, (KS) * 16 * ROWA, ROWA)                                                         \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-    // all reads of set X have retired once at most CNT newer LDS operations are outstanding
-#define SGV_TW_WAIT(X, CNT)                                                                                   \
+#define SGV_T2_WAIT(X, CNT)                                                                                   \
     asm volatile("s_waitcnt lgkmcnt(" #CNT ")"                                                                \
                  : "+v"(X##A0), "+v"(X##A1), "+v"(X##A2), "+v"(X##A3), "+v"(X##B0), "+v"(X##B1));
-#define SGV_TW_MMA(X)                                                                                         \
+#define SGV_T2_MMA(X)                                                                                         \
     {                                                                                                         \
         acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##A0, X##B0, acc[0][0], 0, 0, 0);                \
         acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##A0, X##B1, acc[0][1], 0, 0, 0);                \
@@ -983,77 +975,48 @@ __global__ __launch_bounds__(256, 1) void gemm_tn_wide_kernel(const GemmTN p) {
         acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##A3, X##B1, acc[3][1], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-    // one tile: entered with set f = fragments (tile, k0) issued; HANDOFF (may be empty) sits between M(k2) and M(k3);
-    // LASTCNT = LDS reads issued after set g by the time of M(k3): 12 with a hand-off (next tile's k0), else 0
-#define SGV_TW_TILE(CUR, HANDOFF, LASTCNT)                                                                    \
-    {                                                                                                         \
-        SGV_TW_LOAD(g, CUR, 1) SGV_TW_WAIT(f, 12) SGV_TW_MMA(f)                                               \
-        SGV_TW_LOAD(f, CUR, 2) SGV_TW_WAIT(g, 12) SGV_TW_MMA(g)                                               \
-        SGV_TW_LOAD(g, CUR, 3) SGV_TW_WAIT(f, 12) SGV_TW_MMA(f)                                               \
-        HANDOFF                                                                                               \
-        SGV_TW_WAIT(g, LASTCNT) SGV_TW_MMA(g)                                                                 \
-    }
-#define SGV_TW_HAND(CUR, NXT, WAIT, REFILL)                                                                   \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_waitcnt vmcnt(" #WAIT ")\n\ts_barrier" ::: "memory");             \
-    if (REFILL) { SGV_TW_ISSUE(CUR); }                                                                        \
-    asm volatile("" ::: "memory");                                                                            \
-    SGV_TW_FIX(NXT)                                                                                           \
-    SGV_TW_LOAD(f, NXT, 0)
     const int nst = s_end - s_begin;
     if (nst > 0) {
-        SGV_TW_ISSUE(0);
-        if (nst > 1) SGV_TW_ISSUE(1);
-        if (nst > 2) SGV_TW_ISSUE(2);
-        if (nst > 2) asm volatile("s_waitcnt vmcnt(24)\n\ts_barrier" ::: "memory");
-        else if (nst > 1) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        SGV_T2_ISSUE(0);
+        if (nst > 1) SGV_T2_ISSUE(STAGEB);
+        if (nst > 2) SGV_T2_ISSUE(2 * STAGEB);
+        if (nst > 2) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+        else if (nst > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        SGV_TW_FIX(0)
-        SGV_TW_LOAD(f, 0, 0)
-        int i = 0;
-        while (i + 6 <= nst) {
-            SGV_TW_TILE(0, SGV_TW_HAND(0, 1, 12, true), 12)
-            SGV_TW_TILE(1, SGV_TW_HAND(1, 2, 12, true), 12)
-            SGV_TW_TILE(2, SGV_TW_HAND(2, 0, 12, true), 12)
-            i += 3;
-        }
-        const int rem = nst - i;
-        if (rem == 5) {
-            SGV_TW_TILE(0, SGV_TW_HAND(0, 1, 12, true), 12)
-            SGV_TW_TILE(1, SGV_TW_HAND(1, 2, 12, true), 12)
-            SGV_TW_TILE(2, SGV_TW_HAND(2, 0, 12, false), 12)
-            SGV_TW_TILE(0, SGV_TW_HAND(0, 1, 0, false), 12)
-            SGV_TW_TILE(1, , 0)
-        } else if (rem == 4) {
-            SGV_TW_TILE(0, SGV_TW_HAND(0, 1, 12, true), 12)
-            SGV_TW_TILE(1, SGV_TW_HAND(1, 2, 12, false), 12)
-            SGV_TW_TILE(2, SGV_TW_HAND(2, 0, 0, false), 12)
-            SGV_TW_TILE(0, , 0)
-        } else if (rem == 3) {
-            SGV_TW_TILE(0, SGV_TW_HAND(0, 1, 12, false), 12)
-            SGV_TW_TILE(1, SGV_TW_HAND(1, 2, 0, false), 12)
-            SGV_TW_TILE(2, , 0)
-        } else if (rem == 2) {
-            SGV_TW_TILE(0, SGV_TW_HAND(0, 1, 0, false), 12)
-            SGV_TW_TILE(1, , 0)
-        } else {
-            SGV_TW_TILE(0, , 0)
+        SGV_T2_FIX(0)
+        int cur = 0;                                // byte offset of the stage being consumed
+        for (int i = 0; i < nst; ++i) {
+            const uint32_t aa0 = fa0 + cur, aa1 = fa1 + cur, aa2 = fa2 + cur, aa3 = fa3 + cur;
+            const uint32_t ax0 = fx0 + cur, ax1 = fx1 + cur;
+            // both sub-steps' fragments are requested up front; the other block on the CU covers the latency
+            SGV_T2_LOAD(f, 0) SGV_T2_LOAD(g, 1)
+            SGV_T2_WAIT(f, 12) SGV_T2_MMA(f)
+            SGV_T2_WAIT(g, 0) SGV_T2_MMA(g)
+            if (i + 1 < nst) {
+                // my reads of `cur` have retired (lgkmcnt(0) above): wait for my part of the next stage, publish, refill
+                // `cur` with stage i + 3, patch the next stage's tap-boundary rows
+                const int nxt = cur == 2 * STAGEB ? 0 : cur + STAGEB;
+                if (i + 3 < nst) {
+                    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+                    SGV_T2_ISSUE(cur);
+                } else {
+                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                }
+                asm volatile("" ::: "memory");
+                SGV_T2_FIX(nxt)
+                cur = nxt;
+            }
         }
     }
-#undef SGV_TW_A
-#undef SGV_TW_X
-#undef SGV_TW_ISSUE
-#undef SGV_TW_FIX
-#undef SGV_TW_AADDR
-#undef SGV_TW_AIMM
-#undef SGV_TW_XADDR
-#undef SGV_TW_WAIT
-#undef SGV_TW_TR
-#undef SGV_TW_LOAD
-#undef SGV_TW_MMA
-#undef SGV_TW_TILE
-#undef SGV_TW_HAND
+#undef SGV_T2_A
+#undef SGV_T2_X
+#undef SGV_T2_ISSUE
+#undef SGV_T2_FIX
+#undef SGV_T2_TR
+#undef SGV_T2_LOAD
+#undef SGV_T2_WAIT
+#undef SGV_T2_MMA
 
-    // every (tile, tap, z) block owns its output (or slab) region -> plain stores, deterministic
     float* outp = p.out + (long)z * p.out_slab_stride + (long)tap * p.out_tap_stride;
 #pragma unroll
     for (int a = 0; a < 4; ++a) {
@@ -1115,20 +1078,18 @@ int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype) {
     return pick_splitk(tiles, total, (double)M * N * 4.0, 8);
 }
 
-// The 128x256 single-block-per-CU weight-gradient kernel is OPT-IN (SGV_TN_WIDE=1 or GemmTN::force_wide): the
-// reduction dimension of dW is only batch*time = 3200 rows (50 stages), so its prologue/epilogue cannot hide behind
-// other blocks the way they do with three 128x128 blocks per CU; measured on MI355X it is 0-10 % slower than
-// gemm_tn_kernel on the layers of this model (e.g. 3200x1024x95008: 859 vs 802 us).
-static bool gemm_tn_wide_eligible(int dtype, int M, int N1, int N2, int Tlen) {
-    return dtype == 1 && N2 >= 256 && N1 >= 64 && Tlen >= 64 && M >= 512;
+// 128x256 tiles, two blocks per CU (gemm_tn_w2_kernel): the default for bf16 weight gradients with N2 >= 256; SGV_TN_W2=0
+// falls back to the 128x128 register-staged kernel (A/B runs), GemmTN::force_w2 selects it regardless of the env.
+static bool gemm_tn_w2_eligible(int dtype, int M, int N1, int N2, int Tlen) {
+    return dtype == 1 && N2 >= 256 && N1 >= 64 && Tlen >= 32 && M >= 256;
 }
-bool gemm_tn_uses_wide(int dtype, int M, int N1, int N2, int Tlen) {
-    static const int use_wide = getenv("SGV_TN_WIDE") ? atoi(getenv("SGV_TN_WIDE")) : 0;
-    return use_wide && gemm_tn_wide_eligible(dtype, M, N1, N2, Tlen);
+bool gemm_tn_uses_w2(int dtype, int M, int N1, int N2, int Tlen) {
+    static const int use_w2 = getenv("SGV_TN_W2") ? atoi(getenv("SGV_TN_W2")) : 1;
+    return use_w2 && gemm_tn_w2_eligible(dtype, M, N1, N2, Tlen);
 }
 int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype, int Tlen) {
-    if (gemm_tn_uses_wide(dtype, M, N1, N2, Tlen))   // 128x256 tiles, one block per CU, 64-row stages
-        return pick_splitk((long)cdiv(N1, 128) * cdiv(N2, 256) * taps, cdiv(M, 64), (double)taps * N1 * N2 * 4.0, 6, 256.0);
+    if (gemm_tn_uses_w2(dtype, M, N1, N2, Tlen))     // 128x256 tiles, two blocks per CU, 32-row stages
+        return pick_splitk((long)cdiv(N1, 128) * cdiv(N2, 256) * taps, cdiv(M, 32), (double)taps * N1 * N2 * 4.0, 12, 512.0);
     const int kr = dtype == 1 ? 32 : 16;
     const long tiles = (long)cdiv(N1, 128) * cdiv(N2, 128) * taps;
     const long total = cdiv(M, kr);
@@ -1183,10 +1144,9 @@ int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
     q.a_bytes = ((long)(p.M - 1) * p.lda + p.N1) * esz;
     q.b_bytes = ((long)(p.M - 1) * p.ldb + p.N2) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.b_bytes >= 0x7FFFFFF0L) return -1;
-    if (p.use_tr && (gemm_tn_uses_wide(dtype, p.M, p.N1, p.N2, p.Tlen) ||
-                     (p.force_wide && gemm_tn_wide_eligible(dtype, p.M, p.N1, p.N2, p.Tlen)))) {
+    if (p.use_tr && (gemm_tn_uses_w2(dtype, p.M, p.N1, p.N2, p.Tlen) || (p.force_w2 && gemm_tn_w2_eligible(dtype, p.M, p.N1, p.N2, p.Tlen)))) {
         dim3 gridw(cdiv(p.N1, 128) * cdiv(p.N2, 256) * p.taps * p.splitk);
-        hipLaunchKernelGGL(gemm_tn_wide_kernel, gridw, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gemm_tn_w2_kernel, gridw, dim3(256), 0, s, q);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     dim3 grid(cdiv(p.N1, 128) * cdiv(p.N2, 128) * p.taps * p.splitk);

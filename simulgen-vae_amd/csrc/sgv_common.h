@@ -111,7 +111,7 @@ struct GemmTN {
     long out_tap_stride;
     long out_slab_stride;
     int M, N1, N2, taps, pad, Tlen, splitk, use_tr;
-    int force_wide;                 // tests: take gemm_tn_wide_kernel whenever the shape is eligible
+    int force_w2;                   // tests: take gemm_tn_w2_kernel whenever the shape is eligible (ignores SGV_TN_W2)
     long a_bytes, b_bytes;          // filled by launch_gemm_tn
 };
 
@@ -121,4 +121,4 @@ int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype);
 void gemm_nt_main_done_event(hipEvent_t ev);
 bool gemm_nt_uses_wide(int dtype, int N, int K, int taps);   // 128x256 software-pipelined kernel vs the 128x128 one
 int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype, int Tlen = 0);
-bool gemm_tn_uses_wide(int dtype, int M, int N1, int N2, int Tlen);   // 128x256 LDS-DMA kernel vs the 128x128 one
+bool gemm_tn_uses_w2(int dtype, int M, int N1, int N2, int Tlen);   // 128x256 LDS-DMA kernel (2 blocks/CU) vs the 128x128 one

@@ -26,8 +26,9 @@ else:
     dY = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
     X = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
     out = torch.empty(taps, N1, N2, device="cuda", dtype=torch.float32)
+    use_tr, sk = int(os.environ.get("USE_TR", "1")), int(os.environ.get("SPLITK", "1"))   # 2 = force the w2 kernel
     def run():
-        rc = lib.sgv_test_gemm_tn(1, dY.data_ptr(), X.data_ptr(), out.data_ptr(), M, N1, N2, taps, T, 1, 1, None)
+        rc = lib.sgv_test_gemm_tn(1, dY.data_ptr(), X.data_ptr(), out.data_ptr(), M, N1, N2, taps, T, sk, use_tr, None)
         assert rc == 0, lib.sgv_last_error()
     flops = 2.0 * M * N1 * N2 * taps
 run(); torch.cuda.synchronize()

@@ -139,25 +139,28 @@ def test_gemm_tn(dtype, use_tr, case):
     assert err < 2e-5, err
 
 
-TN_WIDE_CASES = [
-    # M, N1, N2, taps, Tlen, splitk  -- all eligible for the (opt-in) 128x256 LDS-DMA weight-gradient kernel (bf16, N2 >= 256, Tlen >= 64)
+TN_W2_CASES = [
+    # M, N1, N2, taps, Tlen, splitk  -- all eligible for the 128x256 LDS-DMA weight-gradient kernel (bf16, N2 >= 256, Tlen >= 32)
     (1600, 192, 520, 5, 200, 1),      # ragged N1/N2 tiles, taps across sample boundaries
-    (1000, 136, 256, 3, 100, 3),      # M not a multiple of 64, split-K slabs
+    (1000, 136, 256, 3, 100, 3),      # M not a multiple of 32, split-K slabs
     (3200, 1024, 768, 1, 200, 2),
-    (777, 64, 264, 5, 64, 1),         # M not a multiple of Tlen, smallest allowed Tlen
+    (777, 64, 264, 5, 64, 1),         # M not a multiple of Tlen
     (4000, 320, 1280, 3, 200, 5),
-    (512, 128, 256, 1, 512, 1),       # 8 stages: the shortest loop the launcher selects it for
+    (512, 128, 256, 1, 512, 1),
+    (640, 72, 296, 5, 32, 1),         # smallest allowed Tlen: every 32-row stage starts on a sample boundary
+    (990, 128, 256, 5, 33, 2),        # Tlen = 33: the boundary walks through every row of the stage
+    (1360, 200, 512, 3, 34, 1),
+    (288, 64, 256, 5, 48, 1),         # 9 stages
 ]
 
 
-@pytest.mark.parametrize("case", TN_WIDE_CASES)
-def test_gemm_tn_wide(case):
-    """gemm_tn_wide_kernel vs numpy on bf16-exact inputs, each shape repeated 8x (the counted-vmcnt ring must give
-    the same answer every time)."""
+@pytest.mark.parametrize("case", TN_W2_CASES)
+def test_gemm_tn_w2(case):
+    """gemm_tn_w2_kernel (128x256 tile, 32-row stages, two blocks per CU) vs numpy on bf16-exact inputs, 8x per shape."""
     import torch
     lib = E.load_library()
     M, N1, N2, taps, Tlen, splitk = case
-    rng = np.random.default_rng(11)
+    rng = np.random.default_rng(13)
     dY = _bf16_round(rng.standard_normal((M, N1)).astype(np.float32))
     X = _bf16_round(rng.standard_normal((M, N2)).astype(np.float32))
     ddY, dX = _dev(dY, 1), _dev(X, 1)
@@ -165,7 +168,7 @@ def test_gemm_tn_wide(case):
     scale = np.abs(ref).max()
     for rep in range(8):
         out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
-        # use_tr = 2: force the (opt-in) wide kernel for every eligible shape
+        # use_tr = 2: force the two-blocks-per-CU kernel for every eligible shape (whatever SGV_TN_W2 says)
         rc = lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk, 2, None)
         assert rc == 0, lib.sgv_last_error()
         got = out.cpu().numpy()
