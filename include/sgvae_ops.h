@@ -80,6 +80,12 @@ int sgv_op_batchnorm_bwd(const float* x, const float* gamma, const float* stat, 
 int sgv_op_mask_scale(const float* a, const float* mask, float scale, float* out, long n, void* stream);
 int sgv_op_addf(const float* a, const float* b, float* out, long n, void* stream);
 int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* dpred, float gscale, long n, void* stream);
+/* End-to-end conditioner loop (latent_conditioner_e2e.py:66-92,244-256,374): the value (mean reduction, double, no
+ * gradient -- the reference detaches this term through numpy) of kind 0 nn.MSELoss, 1 nn.L1Loss, 2 nn.HuberLoss(delta),
+ * 3 nn.SmoothL1Loss(beta = delta) between two fp32 arrays; and sklearn MinMaxScaler.inverse_transform on a
+ * [rows][cols] fp32 array, y = (x - min_[c]) / scale_[c]. */
+int sgv_op_loss_value(int kind, const float* a, const float* b, double* loss_dev, float delta, long n, void* stream);
+int sgv_op_cols_sub_div(const float* x, const float* col_min, const float* col_scale, float* y, long rows, int cols, void* stream);
 /* Input augmentation of the training loop (latent_conditioner.py:107-159,261-279) on [B][H][W] fp32 images, random
  * draws made by the caller: flip_roll = torch.flip(dims=[2]) where flip[b] then torch.roll by (shift_x[b], shift_y[b]);
  * affine_sample = F.affine_grid(theta [B][2][3], align_corners=False) + F.grid_sample(bilinear, 'border', False)

@@ -18,6 +18,6 @@ def install_reference_api():
     pkg = importlib.import_module(__name__ + ".modules")
     sys.modules["modules"] = pkg
     for sub in ("VAE_network", "train", "utils", "augmentation", "losses", "data_preprocess", "latent_conditioner_model_cnn",
-                "latent_conditioner"):
+                "latent_conditioner", "latent_conditioner_e2e", "reconstruction_evaluator"):
         sys.modules["modules." + sub] = importlib.import_module(__name__ + ".modules." + sub)
     return pkg

@@ -343,6 +343,41 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
     a = wave_sum(a);
     if ((threadIdx.x & 63) == 0) atomicAdd(loss, (double)a / (double)n);
 }
+// value of nn.MSELoss / L1Loss / HuberLoss(delta) / SmoothL1Loss(beta) with mean reduction (no gradient): the
+// reconstruction term of the end-to-end conditioner loop, which the reference cuts off from the graph
+template <int KIND>
+__global__ __launch_bounds__(256) void loss_value_kernel(const float* a, const float* b, double* loss, float delta, long n) {
+    __shared__ double sm[4];
+    double acc = 0.0;
+    const long n4 = n >> 2;
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    auto term = [&](float d) -> float {
+        const float ad = fabsf(d);
+        if (KIND == 0) return d * d;
+        if (KIND == 1) return ad;
+        if (KIND == 2) return ad <= delta ? 0.5f * d * d : delta * (ad - 0.5f * delta);
+        return ad < delta ? 0.5f * d * d / delta : ad - 0.5f * delta;
+    };
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const float4 x = a4[i], y = b4[i];
+        acc += (double)(term(x.x - y.x) + term(x.y - y.y) + term(x.z - y.z) + term(x.w - y.w));
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) acc += (double)term(a[n4 * 4 + threadIdx.x] - b[n4 * 4 + threadIdx.x]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(loss, (sm[0] + sm[1] + sm[2] + sm[3]) / (double)n);
+}
+// sklearn MinMaxScaler.inverse_transform on [rows][cols]: (x - min_[c]) / scale_[c]
+__global__ __launch_bounds__(256) void cols_sub_div_kernel(const float* x, const float* mn, const float* sc, float* y, long rows, int cols) {
+    const long n = rows * cols;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const int c = (int)(i % cols);
+        y[i] = (x[i] - mn[c]) / sc[c];
+    }
+}
 // dtype conversion / layout: [B][C][P] fp32 (reference NCHW with P = H*W) <-> [B][P][C] compute dtype is ew_transpose
 
 // ------------------------------------------------------------------------------------------------------------
@@ -680,6 +715,26 @@ int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* 
     OPCHK(pred && target && loss_dev && n > 0, "sgv_op_mse: bad argument");
     if (hipMemsetAsync(loss_dev, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     hipLaunchKernelGGL(mse_kernel, grid1(n), dim3(256), 0, ST(stream), pred, target, loss_dev, dpred, gscale, n);
+    return OPLAUNCH_OK();
+}
+int sgv_op_loss_value(int kind, const float* a, const float* b, double* loss_dev, float delta, long n, void* stream) {
+    OPCHK(a && b && loss_dev && n > 0 && kind >= 0 && kind <= 3, "sgv_op_loss_value: bad argument");
+    OPCHK((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "sgv_op_loss_value: operands must be 16-byte aligned");
+    OPCHK(kind < 2 || delta > 0.f, "sgv_op_loss_value: delta / beta must be positive");
+    if (hipMemsetAsync(loss_dev, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+    long blocks = ((n >> 2) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
+    const dim3 g((unsigned)blocks);
+    if (kind == 0) hipLaunchKernelGGL(loss_value_kernel<0>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
+    else if (kind == 1) hipLaunchKernelGGL(loss_value_kernel<1>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
+    else if (kind == 2) hipLaunchKernelGGL(loss_value_kernel<2>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
+    else hipLaunchKernelGGL(loss_value_kernel<3>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
+    return OPLAUNCH_OK();
+}
+int sgv_op_cols_sub_div(const float* x, const float* col_min, const float* col_scale, float* y, long rows, int cols, void* stream) {
+    OPCHK(x && col_min && col_scale && y && rows > 0 && cols > 0, "sgv_op_cols_sub_div: bad argument");
+    hipLaunchKernelGGL(cols_sub_div_kernel, grid1(rows * cols), dim3(256), 0, ST(stream), x, col_min, col_scale, y, rows, cols);
     return OPLAUNCH_OK();
 }
 // C[M][N] = scale * A[M][K] . W[N][K]^T (+ bias[N]) (+ addend[M][N]); K, N multiples of 8; out_f32: fp32 output

@@ -328,7 +328,10 @@ typedef __attribute__((address_space(3))) void lds_void;
 //     i.e. the reads of sub-step k+1 are issued before the MFMAs of k, and the stage hand-off sits in front of the last
 //     MFMA group.  The refill targets the stage just read (all waves have retired their reads: lgkmcnt(0) + barrier).
 // History (profiles/r01_summary.md): 128x128 register-staged 520 TFLOP/s on 5120^2 k5 -> 128x128 LDS-DMA 620 -> 128x256
-// K-step 32 760 -> K-step 64 930 -> software-pipelined 1030.  The intermediate kernels were removed.
+// K-step 32 760 -> K-step 64 930 -> software-pipelined 1030.  The intermediate kernels were removed.  Two
+// two-waves-per-SIMD forms were tried after the weight-gradient kernel gained 30 % from that recipe and both lost here
+// (same box, 5120^2 k5: this kernel 932-942): K-step 32 with two independent blocks per CU 791-820 (64-byte source rows);
+// eight waves in two K-groups half a stage out of phase, partial sums joined through LDS, 878.
 // =========================================================================================
 __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p) {
     typedef bf16_t T;

@@ -190,3 +190,26 @@ def data_scaler(FOM_data_aug, FOM_data, num_time, num_node, directory, chunk_siz
         new_x_train = out
         print(f"   Final data shape: {new_x_train.shape}, dtype: {new_x_train.dtype}")
     return new_x_train, DATA_shape, scaler
+
+
+def latent_conditioner_scaler(data, name):
+    """data_preprocess.py:167-195: MinMaxScaler(-0.7, 0.7) over the rows of a [P, ...] array (3-D arrays are flattened
+    per sample), pickled to `name`; returns (scaled_data, scaler).  The arrays here are the exported latents
+    ([P, 32] and [P, 24] at preset 1): the host fit is the reference's own and costs microseconds, the scaler object
+    is sklearn's so `latent_vectors_scaler.pkl` / `xs_scaler.pkl` stay loadable by the reference's loops."""
+    from pickle import dump
+    from sklearn.preprocessing import MinMaxScaler
+    scaler = MinMaxScaler(feature_range=FEATURE_RANGE)
+    original_shape = data.shape
+    if original_shape[0] == 0:
+        raise ValueError(f"Empty data array detected with shape {original_shape}. "
+                         "Please check your data loading configuration. "
+                         "If using 'input_type image', ensure PNG files exist in the specified directory.")
+    data_reshaped = data.reshape(original_shape[0], -1) if len(original_shape) == 3 else data
+    scaler.fit(data_reshaped)
+    scaled_data = scaler.transform(data_reshaped)
+    if len(original_shape) == 3:
+        scaled_data = scaled_data.reshape(original_shape)
+    with open(name, "wb") as f:
+        dump(scaler, f)
+    return scaled_data, scaler

@@ -193,9 +193,28 @@ class LatentConditionerImg:
         return self
 
     def apply(self, fn):
-        """latent_conditioner.apply(safe_initialize_weights_He) (latent_conditioner.py:223): on the spectrally normalised
-        layers the reference's hook recomputes `.weight` from `weight_orig` at the next forward, so that call only
-        re-initialises the non-normalised Linear layers; accepted as a no-op here (parity runs load a state)."""
+        """latent_conditioner.apply(safe_initialize_weights_He) (latent_conditioner.py:169-177,223) and
+        latent_conditioner.apply(init_weights) (latent_conditioner_e2e.py:267-287).  On the spectrally normalised layers
+        the reference's hook recomputes `.weight` from `weight_orig` at the next forward, so those calls only re-initialise
+        the plain Linear layers (SE, skip projections, the two output layers): kaiming_uniform(relu) -- or, for
+        `init_weights`, normal(0, 0.1) when out_features <= 64 -- and zero biases; norm layers get ones / zeros (their
+        state at that point anyway; BatchNorm1d is not in `init_weights`' list).  Values come from numpy's generator (same
+        distributions, different stream)."""
+        e2e = getattr(fn, "__name__", "") == "init_weights"
+        rng = np.random.default_rng(int(torch.randint(0, 2 ** 31 - 1, (1,)).item()))
+        spec = {n: (sh, k) for n, sh, k in self._spec()}
+        for n, (sh, k) in spec.items():
+            if k != "w" or not n.endswith(".weight") or len(sh) != 2:
+                continue                                    # only plain nn.Linear weights ([out, in], not weight_orig)
+            if e2e and sh[0] <= 64:
+                w = rng.normal(0.0, 0.1, sh)
+            else:
+                bound = math.sqrt(6.0 / sh[1])
+                w = rng.uniform(-bound, bound, sh)
+            self.P[n].copy_(torch.from_numpy(w.astype(np.float32)))
+            bn_ = n[:-len("weight")] + "bias"
+            if bn_ in self.P:
+                self.P[bn_].zero_()
         return self
 
     # ---- fused parameter passes -----------------------------------------------------------------------------------
@@ -471,14 +490,16 @@ class LatentConditionerImg:
         self._tape = None
         return g
 
-    def loss_backward(self, x, y1, y2, dropout_masks=None):
-        """latent_conditioner.py:285-301: forward, A = MSE(y_pred1, y1), B = MSE(y_pred2, y2), loss = 10*A + B, backward.
+    def loss_backward(self, x, y1, y2, dropout_masks=None, w1=10.0, w2=1.0, preds=None):
+        """latent_conditioner.py:285-301: forward, A = MSE(y_pred1, y1), B = MSE(y_pred2, y2), loss = w1*A + w2*B
+        (10 and 1 there; the end-to-end loop uses reg_weight*0.9 and reg_weight*0.1), backward.  `preds` = the outputs of a
+        forward already run on this input in training mode (its tape is still current).
         Returns (loss, A, B) as floats; gradients are left in `self.grads` keyed by parameter name."""
-        p1, p2 = self.forward(x, dropout_masks)
+        p1, p2 = preds if preds is not None else self.forward(x, dropout_masks)
         y1 = torch.as_tensor(y1).to(device="cuda", dtype=torch.float32).contiguous()
         y2 = torch.as_tensor(y2).to(device="cuda", dtype=torch.float32).contiguous()
-        la, d1 = ops.mse(p1, y1, gscale=10.0)
-        lb, d2 = ops.mse(p2.reshape(p2.shape[0], -1), y2.reshape(y2.shape[0], -1), gscale=1.0)
+        la, d1 = ops.mse(p1, y1, gscale=float(w1))
+        lb, d2 = ops.mse(p2.reshape(p2.shape[0], -1), y2.reshape(y2.shape[0], -1), gscale=float(w2))
         self.backward(d1, d2)
         A, Bv = float(la), float(lb)
-        return 10.0 * A + Bv, A, Bv
+        return float(w1) * A + float(w2) * Bv, A, Bv

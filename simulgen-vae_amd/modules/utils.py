@@ -135,6 +135,57 @@ class Dataset(torch.utils.data.Dataset):
         return len(self.x_data)
 
 
+def _to_dev(a):
+    return torch.as_tensor(np.asarray(a), dtype=torch.float32).cuda().contiguous()
+
+
+class LatentConditionerDataset(torch.utils.data.Dataset):
+    """utils.LatentConditionerDataset (utils.py:120-173): (condition input, main latent, hierarchical latents) triples
+    preloaded to the device; NaNs are replaced by zeros with the reference's warnings."""
+
+    def __init__(self, input_data, output_data1, output_data2, load_all=True):
+        arrs = []
+        for nm, a in (("input_data", input_data), ("output_data1", output_data1), ("output_data2", output_data2)):
+            a = np.asarray(a)
+            if np.isnan(a).any():
+                print(f"Warning: NaN values detected in {nm}, replacing with zeros")
+                a = np.nan_to_num(a, nan=0.0)
+            arrs.append(a)
+        self.input_data, self.output_data1, self.output_data2 = (_to_dev(a) for a in arrs)
+        self.on_gpu = True
+
+    def __len__(self):
+        return len(self.input_data)
+
+    def __getitem__(self, idx):
+        return self.input_data[idx], self.output_data1[idx], self.output_data2[idx]
+
+
+class E2ELatentConditionerDataset(torch.utils.data.Dataset):
+    """utils.E2ELatentConditionerDataset (utils.py:602-671): (condition, main latent, hierarchical latents,
+    reconstruction target [num_node, num_time]) per sample.  With load_all everything is resident in HBM; otherwise the
+    reconstruction targets (the big array) stay in host memory and are uploaded per batch."""
+
+    def __init__(self, condition_data, latent_main_data, latent_hier_data, target_reconstruction_data, load_all=False):
+        self.length = len(condition_data)
+        self.load_all = bool(load_all)
+        self.condition_data, self.latent_main_data, self.latent_hier_data = (_to_dev(a) for a in (condition_data, latent_main_data, latent_hier_data))
+        if hasattr(target_reconstruction_data, "buf") and hasattr(target_reconstruction_data, "num_node"):
+            self.target_reconstruction_data = target_reconstruction_data         # data_preprocess.DeviceDataset
+        elif self.load_all:
+            self.target_reconstruction_data = _to_dev(target_reconstruction_data)
+            print(f"E2E Dataset loaded to GPU: {self.length} samples")
+        else:
+            self.target_reconstruction_data = torch.from_numpy(np.ascontiguousarray(target_reconstruction_data, dtype=np.float32))
+            print(f"E2E Dataset loaded to CPU with pin_memory: {self.length} samples")
+
+    def __len__(self):
+        return self.length
+
+    def __getitem__(self, idx):
+        return self.condition_data[idx], self.latent_main_data[idx], self.latent_hier_data[idx], self.target_reconstruction_data[idx]
+
+
 def shard_indices(indices, rank, world, batch_size):
     """Data-parallel sharding (SURVEY 8(e)): rank r takes indices r::world of the (already shuffled) list,
     trimmed so that every rank sees the same number of full-or-partial batches."""

@@ -17,7 +17,7 @@ OPS_SYMBOLS = [
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
     "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
-    "sgv_op_mse", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
+    "sgv_op_mse", "sgv_op_loss_value", "sgv_op_cols_sub_div", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
     "sgv_op_conv_weight_unpack", "sgv_op_sumsq", "sgv_op_clip_coef", "sgv_op_adamw", "sgv_op_flip_roll", "sgv_op_affine_sample",
     "sgv_op_mixup_rows", "sgv_pset_create", "sgv_pset_destroy", "sgv_pset_power_iteration", "sgv_pset_sigma", "sgv_pset_step",
 ]
@@ -63,6 +63,8 @@ def lib():
             "sgv_op_mask_scale": [vp, vp, f, vp, lg, vp],
             "sgv_op_addf": [vp, vp, vp, lg, vp],
             "sgv_op_mse": [vp, vp, vp, vp, f, lg, vp],
+            "sgv_op_loss_value": [i, vp, vp, vp, f, lg, vp],
+            "sgv_op_cols_sub_div": [vp, vp, vp, vp, lg, i, vp],
             "sgv_op_transpose": [i, i, vp, vp, i, i, i, vp],
             "sgv_op_l2_normalize": [vp, vp, lg, f, vp],
             "sgv_op_dot": [vp, vp, vp, lg, vp],
@@ -321,6 +323,24 @@ def mse(pred, target, gscale=1.0, need_grad=True):
     dp = torch.empty_like(pred) if need_grad else None
     _ck(lib().sgv_op_mse(_p(pred), _p(target), _p(loss), _p(dp), float(gscale), pred.numel(), _stream()), "sgv_op_mse")
     return loss, dp
+
+
+LOSS_KINDS = {"MSE": 0, "MAE": 1, "Huber": 2, "SmoothL1": 3}
+
+
+def loss_value(kind, a, b, delta=0.1):
+    """Mean-reduced loss value (fp64 [1] on the device) of nn.MSELoss / L1Loss / HuberLoss(delta) / SmoothL1Loss(beta)."""
+    loss = torch.empty(1, dtype=torch.float64, device=a.device)
+    _ck(lib().sgv_op_loss_value(LOSS_KINDS[kind] if isinstance(kind, str) else int(kind), _p(a), _p(b), _p(loss), float(delta),
+                                a.numel(), _stream()), "sgv_op_loss_value")
+    return loss
+
+
+def cols_sub_div(x, col_min, col_scale):
+    """MinMaxScaler.inverse_transform on fp32 [rows, cols]."""
+    y = torch.empty_like(x)
+    _ck(lib().sgv_op_cols_sub_div(_p(x), _p(col_min), _p(col_scale), _p(y), x.shape[0], x.shape[1], _stream()), "sgv_op_cols_sub_div")
+    return y
 
 
 def transpose(src, dst_dtype, Bn, I, J):

@@ -217,3 +217,34 @@ def test_latent_conditioner_lr_schedule_matches_torch_schedulers():
             assert abs(opt.param_groups[0]["lr"] - lc_learning_rate(base, epochs, epoch)) <= 1e-9 * base + 1e-15, (epochs, epoch)
             opt.step()
             (warm if epoch < 100 else main).step()
+
+
+def test_e2e_cosine_schedule_and_latent_scaler(tmp_path):
+    """SURVEY 8(f) N4 host side: cosine_lr (closed form) vs CosineAnnealingLR(T_max = epochs, eta_min = 1e-8) stepped once
+    per epoch (latent_conditioner_e2e.py:141-146,516); latent_conditioner_scaler vs sklearn's MinMaxScaler on 2-D and 3-D
+    arrays, the pickle it leaves behind, and its empty-input error (data_preprocess.py:167-195)."""
+    import pickle
+    import torch
+    from sklearn.preprocessing import MinMaxScaler
+    from simulgen_vae_amd.modules.latent_conditioner_e2e import cosine_lr, load_scaler
+    from simulgen_vae_amd.modules.data_preprocess import latent_conditioner_scaler
+    for epochs, base in ((7, 1e-3), (120, 3e-4)):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=base)
+        sch = torch.optim.lr_scheduler.CosineAnnealingLR(opt, T_max=epochs, eta_min=1e-8)
+        for epoch in range(epochs + 1):
+            assert abs(opt.param_groups[0]["lr"] - cosine_lr(base, epochs, epoch)) <= 1e-9 * base + 1e-15, (epochs, epoch)
+            opt.step()
+            sch.step()
+    rng = np.random.default_rng(4)
+    a2, a3 = rng.standard_normal((11, 5)) * 3, rng.standard_normal((11, 3, 4))
+    s2, sc2 = latent_conditioner_scaler(a2, str(tmp_path / "a.pkl"))
+    s3, sc3 = latent_conditioner_scaler(a3, str(tmp_path / "b.pkl"))
+    ref = MinMaxScaler(feature_range=(-0.7, 0.7)).fit(a2)
+    np.testing.assert_allclose(s2, ref.transform(a2), rtol=1e-12, atol=1e-12)
+    assert s3.shape == a3.shape and abs(s3.min() + 0.7) < 1e-12 and abs(s3.max() - 0.7) < 1e-12
+    with open(tmp_path / "b.pkl", "rb") as f:
+        np.testing.assert_allclose(pickle.load(f).scale_, sc3.scale_)
+    assert load_scaler(str(tmp_path / "missing.pkl")) is None
+    with pytest.raises(ValueError, match="Empty data array"):
+        latent_conditioner_scaler(np.zeros((0, 4)), str(tmp_path / "c.pkl"))
