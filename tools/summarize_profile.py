@@ -64,10 +64,12 @@ def traffic(fetch_csv, write_csv):
         corr = 2.0 if name == "FETCH_SIZE" else 1.0
         for x in step:
             k = x["Kernel_Name"]
-            fam = next((n for n in ("gemm_nt_wide64p_kernel", "gemm_nt_reduce_kernel", "gemm_nt_kernel", "gemm_tn_kernel",
+            fam = next((n for n in ("gemm_nt_wide64p_kernel", "gemm_nt_reduce_kernel", "gemm_nt_kernel", "gemm_tn_w2_kernel", "gemm_tn_kernel",
                                     "sum_slabs_kernel", "adamw_sn_kernel") if n in k), None)
             if fam is None:
                 continue
+            if fam == "gemm_tn_kernel":
+                fam = "gemm_tn_w2_kernel"      # one weight-gradient class (bench.py's roofline_gemm_tn covers both kernels)
             d = out.setdefault(fam, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
             d["fetch_bytes" if name == "FETCH_SIZE" else "write_bytes"] += float(x["Counter_Value"]) * 1024 * corr
             if name == "FETCH_SIZE":
