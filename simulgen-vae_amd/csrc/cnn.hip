@@ -631,9 +631,8 @@ int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, in
     OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_fwd: C %% 8 == 0, 1 <= G <= %d, C %% G == 0 required", SGV_GN_MAX_GROUPS);
     if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
-    ew_gn_stats(dtype, p, ST(stream));
     p.out = out; p.ldout = C;
-    ew_gn_apply(dtype, act, p, ST(stream));
+    ew_gn_fwd(dtype, act, p, ST(stream));
     return OPLAUNCH_OK();
 }
 size_t sgv_op_gn_workspace_floats(int B, int P, int C) { return ew_gn_part_floats(B, P, C); }
@@ -646,9 +645,8 @@ int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy,
     if (hipMemsetAsync(sums2, 0, sizeof(double) * 2 * B * G, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
     p.sums2 = sums2; p.dout = dout; p.lddout = C; p.rscale = 1.f; p.dgamma = dgamma; p.dbeta = dbeta; p.part = part;
-    ew_gn_bwd_reduce_act(dtype, act, p, ST(stream));
     p.out = dy; p.ldout = C;
-    ew_gn_bwd_apply_act(dtype, act, p, ST(stream));
+    ew_gn_bwd(dtype, act, p, ST(stream));
     return OPLAUNCH_OK();
 }
 

@@ -858,10 +858,9 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
             const GNLayer& g = e->gns[S.gn];
             GNParams p = gn_base(e, g, B);
             p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
-            ew_gn_stats(e->dt, p, e->stream);
             p.out = S.a.p; p.ldout = S.a.ld;
             if (b.residual && s + 1 == b.st.size()) { p.res = in.p; p.ldres = in.ld; p.rscale = 0.1f; }
-            ew_gn_apply(e->dt, S.act, p, e->stream);
+            ew_gn_fwd(e->dt, S.act, p, e->stream);
         } else if (S.act) {
             GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.out = S.a.p; p.ldout = S.a.ld; p.B = B; p.T = e->T; p.C = L.cout;
             ew_act(e->dt, 0, p, e->stream);
@@ -892,10 +891,9 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
             p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
             p.dgamma = e->grads + g.ggamma; p.dbeta = e->grads + g.gbeta;
             p.dbias = e->grads + L.gb; p.part = e->colpart;
-            ew_gn_bwd_reduce(e->dt, p, e->stream);       // + finalize: sums2, dgamma, dbeta, dbias
             p.out = S.dy.p; p.ldout = S.dy.ld;
             p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;   // <G,W_eff> = sum dY*(y - bias)
-            ew_gn_bwd_apply(e->dt, p, e->stream);
+            ew_gn_bwd(e->dt, 1, p, e->stream);           // sums2, dgamma, dbeta, dbias, dY (GELU)
             dY = S.dy;
         } else if (S.act) {
             GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;

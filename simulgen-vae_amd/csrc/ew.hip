@@ -438,6 +438,239 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
     if (p.cdot) block_atomic_add(dotacc, p.cdot);
 }
 
+// ------------------------------------------------------------------------------------------
+// Small layers: ONE block per (group, sample) owns the whole T x Cg slab and keeps it in registers (every thread at
+// most GN_FUSED_ITERS rows of one 8-wide column vector), so statistics + normalise (forward) and reduce + finalize +
+// dY (backward) are one launch and one pass over memory each instead of two and three launches: these layers move a
+// few MB and were bound by launch latency and dependent-load latency, not by bandwidth.  All loads of a thread are
+// issued before the first use.  Thread layout: tx = column vector inside the group (CVg = next power of two >= Cg/8),
+// ty = row lane.  Results match the multi-kernel path up to summation order (float partials per thread, fp64 across).
+// ------------------------------------------------------------------------------------------
+constexpr int GN_FUSED_ITERS = 16;
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { bf16x8 v; };
+template <> struct Raw8<float> { float4 a, b; };
+__device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.v = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float v[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float v[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+struct GNSlab {
+    int g, b, nv, CVg, RL, tx, ty, c0;
+    bool col_ok;
+};
+__device__ __forceinline__ GNSlab gn_slab(const GNParams& p) {
+    GNSlab c;
+    c.g = blockIdx.x; c.b = blockIdx.y;
+    c.nv = p.Cg >> 3;
+    c.CVg = p.CV;                       // host: next power of two >= Cg / 8 (<= 256)
+    c.RL = 256 / c.CVg;
+    c.tx = threadIdx.x % c.CVg; c.ty = threadIdx.x / c.CVg;
+    c.col_ok = c.tx < c.nv;
+    c.c0 = c.g * p.Cg + c.tx * 8;
+    return c;
+}
+// sum of one double per thread over the block, result broadcast to every thread (all 256 threads call)
+__device__ __forceinline__ double block_sum_f64(double v, double* sm4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm4[0] + sm4[1] + sm4[2] + sm4[3];
+}
+
+// out = [res + rscale *] act(gn(y)), statistics included; p.sums[(b*G+g)*2 + {0,1}] = sum, sum of squares (stored)
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const GNParams p) {
+    __shared__ double sm4[4];
+    const GNSlab c = gn_slab(p);
+    const T* y = reinterpret_cast<const T*>(p.y) + (long)c.b * p.T * p.ldy + c.c0;
+    const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (long)c.b * p.T * p.ldres + c.c0 : nullptr;
+    Raw8<T> ry[GN_FUSED_ITERS], rr[GN_FUSED_ITERS];
+#pragma unroll
+    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+        const int t = c.ty + i * c.RL;
+        if (c.col_ok && t < p.T) {
+            raw_load(y + (long)t * p.ldy, ry[i]);
+            if (res) raw_load(res + (long)t * p.ldres, rr[i]);
+        }
+    }
+    float a = 0.f, q = 0.f;
+#pragma unroll
+    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+        const int t = c.ty + i * c.RL;
+        if (c.col_ok && t < p.T) {
+            float v[8];
+            raw_unpack(ry[i], v);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { a += v[e]; q += v[e] * v[e]; }
+        }
+    }
+    const double S = block_sum_f64((double)a, sm4);
+    const double SS = block_sum_f64((double)q, sm4);
+    if (threadIdx.x == 0) {
+        p.sums[((long)c.b * p.G + c.g) * 2 + 0] = S;
+        p.sums[((long)c.b * p.G + c.g) * 2 + 1] = SS;
+    }
+    const double n = (double)p.Cg * (double)p.T;
+    const double md = S / n;
+    double var = SS / n - md * md;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)md, rstd = (float)(1.0 / sqrt(var + 1e-5));
+    if (!c.col_ok) return;
+    float ka[8], kb[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        const float g = p.gamma[c.c0 + e];
+        ka[e] = rstd * g;
+        kb[e] = p.beta[c.c0 + e] - mean * rstd * g;
+    }
+    T* out = reinterpret_cast<T*>(p.out) + (long)c.b * p.T * p.ldout + c.c0;
+#pragma unroll
+    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+        const int t = c.ty + i * c.RL;
+        if (t < p.T) {
+            float v[8], r[8];
+            raw_unpack(ry[i], v);
+            if (res) raw_unpack(rr[i], r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = act_apply(ACT, v[e] * ka[e] + kb[e]);
+                v[e] = res ? r[e] + p.rscale * f : f;
+            }
+            store8(out + (long)t * p.ldout, v);
+        }
+    }
+}
+
+// gn_bwd_reduce + gn_bwd_finalize + gn_bwd_apply of one (group, sample) slab (stored incoming gradient, ACT in {0,1,3})
+template <typename T, int ACT>
+__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const GNParams p) {
+    __shared__ float smc[3][2048];
+    __shared__ float smw[8];
+    __shared__ float smk[4];
+    const GNSlab c = gn_slab(p);
+    const T* y = reinterpret_cast<const T*>(p.y) + (long)c.b * p.T * p.ldy + c.c0;
+    const T* dout = reinterpret_cast<const T*>(p.dout) + (long)c.b * p.T * p.lddout + c.c0;
+    Raw8<T> ry[GN_FUSED_ITERS], rd[GN_FUSED_ITERS];
+#pragma unroll
+    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+        const int t = c.ty + i * c.RL;
+        if (c.col_ok && t < p.T) {
+            raw_load(y + (long)t * p.ldy, ry[i]);
+            raw_load(dout + (long)t * p.lddout, rd[i]);
+        }
+    }
+    const double n = (double)p.Cg * (double)p.T;
+    if (threadIdx.x == 0) {
+        const double s = p.sums[((long)c.b * p.G + c.g) * 2 + 0], ss = p.sums[((long)c.b * p.G + c.g) * 2 + 1];
+        const double m = s / n;
+        double var = ss / n - m * m;
+        if (var < 0.0) var = 0.0;
+        smk[0] = (float)m;
+        smk[1] = (float)(1.0 / sqrt(var + 1e-5));
+    }
+    __syncthreads();
+    const float mean = smk[0], rstd = smk[1];
+    float gam[8], bet[8];
+    float col[3][8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) { col[0][e] = 0.f; col[1][e] = 0.f; col[2][e] = 0.f; gam[e] = 0.f; bet[e] = 0.f; }
+    if (c.col_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c.c0 + e]; bet[e] = p.beta[c.c0 + e]; }
+    }
+#pragma unroll
+    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+        const int t = c.ty + i * c.RL;
+        if (c.col_ok && t < p.T) {
+            float v[8], d[8];
+            raw_unpack(ry[i], v);
+            raw_unpack(rd[i], d);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float xh = (v[e] - mean) * rstd;
+                const float z = xh * gam[e] + bet[e];
+                const float dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
+                col[0][e] += dz;
+                col[1][e] += dz * xh;
+                col[2][e] += xh;
+            }
+        }
+    }
+    // column sums over the row lanes, then the two group sums
+    if (c.RL > 1) {
+#pragma unroll
+        for (int k = 0; k < 3; ++k)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) smc[k][(c.ty * c.CVg + c.tx) * 8 + e] = col[k][e];
+        __syncthreads();
+    }
+    float s1 = 0.f, s2 = 0.f;
+    if (c.ty == 0 && c.col_ok) {
+        for (int r = 1; r < c.RL; ++r)
+#pragma unroll
+            for (int k = 0; k < 3; ++k)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) col[k][e] += smc[k][(r * c.CVg + c.tx) * 8 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { s1 += gam[e] * col[0][e]; s2 += gam[e] * col[1][e]; }
+    }
+    const float w1 = wave_sum(s1), w2 = wave_sum(s2);
+    if ((threadIdx.x & 63) == 0) { smw[(threadIdx.x >> 6) * 2] = w1; smw[(threadIdx.x >> 6) * 2 + 1] = w2; }
+    __syncthreads();
+    s1 = smw[0] + smw[2] + smw[4] + smw[6];
+    s2 = smw[1] + smw[3] + smw[5] + smw[7];
+    if (threadIdx.x == 0) {
+        p.sums2[((long)c.b * p.G + c.g) * 2 + 0] = (double)s1;
+        p.sums2[((long)c.b * p.G + c.g) * 2 + 1] = (double)s2;
+    }
+    const float m1 = (float)((double)s1 / n), m2 = (float)((double)s2 / n);
+    if (c.ty == 0 && c.col_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            atomicAdd(p.dbeta + c.c0 + e, col[0][e]);
+            atomicAdd(p.dgamma + c.c0 + e, col[1][e]);
+            if (p.dbias) atomicAdd(p.dbias + c.c0 + e, p.gscale * rstd * (gam[e] * col[0][e] - (float)p.T * m1 - m2 * col[2][e]));
+        }
+    }
+    // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) * gscale, and <G, W_eff> += sum dY * (y - conv bias)
+    float dotacc = 0.f;
+    if (c.col_ok) {
+        float cb[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) cb[e] = p.cbias ? p.cbias[c.c0 + e] : 0.f;
+        T* dy = reinterpret_cast<T*>(p.out) + (long)c.b * p.T * p.ldout + c.c0;
+#pragma unroll
+        for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+            const int t = c.ty + i * c.RL;
+            if (t < p.T) {
+                float v[8], d[8];
+                raw_unpack(ry[i], v);
+                raw_unpack(rd[i], d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (v[e] - mean) * rstd;
+                    const float z = xh * gam[e] + bet[e];
+                    const float dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
+                    const float r = rstd * (gam[e] * dz - m1 - xh * m2) * p.gscale;
+                    dotacc += r * (v[e] - cb[e]);
+                    v[e] = r;
+                }
+                store8(dy + (long)t * p.ldout, v);
+            }
+        }
+    }
+    if (p.cdot) block_atomic_add(dotacc, p.cdot);
+}
+
 // activation without GroupNorm: MODE 0: out = gelu(y); MODE 1: out = dout*rscale*gelu'(y) (+ colsum -> dbias)
 //                               MODE 2: column sums of y only (-> dbias)
 template <typename T, int MODE>
@@ -558,6 +791,63 @@ int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s) {   // gelu, stored g
     if (dtype == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);
     else GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 1, false, true>), p, s);
     gn_finalize(p, s);
+    return 0;
+}
+// one launch per direction for small slabs (SGV_GN_FUSED=0 restores the multi-kernel path for A/B runs)
+static bool gn_fused_ok(const GNParams& p) {
+    static const int on = getenv("SGV_GN_FUSED") ? atoi(getenv("SGV_GN_FUSED")) : 1;
+    if (!on || p.Cg % 8 || p.Cg / 8 > 256 || p.G > SGV_GN_MAX_GROUPS) return false;
+    int cv = 1;
+    while (cv < p.Cg / 8) cv <<= 1;
+    return (p.T + 256 / cv - 1) / (256 / cv) <= GN_FUSED_ITERS;      // rows per thread
+}
+static int gn_fused_cv(const GNParams& p) {
+    int cv = 1;
+    while (cv < p.Cg / 8) cv <<= 1;
+    return cv;
+}
+#define GN_FUSED_LAUNCH(KERN, P, S)                                                          \
+    do {                                                                                     \
+        (P).CV = gn_fused_cv(P);                                                             \
+        hipLaunchKernelGGL(KERN, dim3((P).G, (P).B), dim3(256), 0, S, P);                    \
+    } while (0)
+// statistics + normalise: p.sums must be zero on entry for the multi-kernel path (the fused one overwrites it)
+int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s) {
+    if (!gn_fused_ok(p) || !p.out) {
+        GNParams q = p;
+        ew_gn_stats(dtype, q, s);
+        return p.out ? ew_gn_apply(dtype, act, p, s) : 0;
+    }
+    if (dtype == 1) {
+        if (act == 1) GN_FUSED_LAUNCH((gn_fwd_fused_kernel<bf16_t, 1>), p, s);
+        else if (act == 2) GN_FUSED_LAUNCH((gn_fwd_fused_kernel<bf16_t, 2>), p, s);
+        else if (act == 3) GN_FUSED_LAUNCH((gn_fwd_fused_kernel<bf16_t, 3>), p, s);
+        else GN_FUSED_LAUNCH((gn_fwd_fused_kernel<bf16_t, 0>), p, s);
+    } else {
+        if (act == 1) GN_FUSED_LAUNCH((gn_fwd_fused_kernel<float, 1>), p, s);
+        else if (act == 2) GN_FUSED_LAUNCH((gn_fwd_fused_kernel<float, 2>), p, s);
+        else if (act == 3) GN_FUSED_LAUNCH((gn_fwd_fused_kernel<float, 3>), p, s);
+        else GN_FUSED_LAUNCH((gn_fwd_fused_kernel<float, 0>), p, s);
+    }
+    return 0;
+}
+// reduce + finalize + dY for act in {0 none, 1 gelu, 3 relu}; p carries both the reduce and the apply arguments
+int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s) {
+    if (!gn_fused_ok(p)) {
+        GNParams q = p;
+        q.out = nullptr; q.cdot = nullptr; q.cbias = nullptr;
+        ew_gn_bwd_reduce_act(dtype, act, q, s);
+        return ew_gn_bwd_apply_act(dtype, act, p, s);
+    }
+    if (dtype == 1) {
+        if (act == 1) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<bf16_t, 1>), p, s);
+        else if (act == 3) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<bf16_t, 3>), p, s);
+        else GN_FUSED_LAUNCH((gn_bwd_fused_kernel<bf16_t, 0>), p, s);
+    } else {
+        if (act == 1) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<float, 1>), p, s);
+        else if (act == 3) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<float, 3>), p, s);
+        else GN_FUSED_LAUNCH((gn_bwd_fused_kernel<float, 0>), p, s);
+    }
     return 0;
 }
 size_t ew_gn_part_floats(int B, int T, int C) {

@@ -27,6 +27,9 @@ struct GNParams {
 
 constexpr int SGV_GN_MAX_GROUPS = 32;
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s);
+// whole GroupNorm passes: one fused launch when a (sample, group) slab is small, else the multi-kernel path
+int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s);   // stats (p.sums zeroed by the caller) + apply
+int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s);   // reduce + finalize + dY; act in {0, 1 gelu, 3 relu}
 int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // act: 0 none, 1 gelu, 3 relu
 int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
