@@ -550,27 +550,35 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const GNParams p) {
     }
 }
 
-// gn_bwd_reduce + gn_bwd_finalize + gn_bwd_apply of one (group, sample) slab (stored incoming gradient, ACT in {0,1,3})
+// gn_bwd_reduce + gn_bwd_finalize + gn_bwd_apply of one (group, sample) slab (stored incoming gradient, ACT in {0,1,3}).
+// 512 threads (the pass is VALU-heavy: erf/exp of the GELU derivative, computed once and kept in registers as dz);
+// column sums: butterfly over the lanes of a wave that share a column vector, then across the 8 waves through LDS.
+constexpr int GN_BWD_THREADS = 512, GN_BWD_ITERS = 8, GN_BWD_MAX_CV = 32;
 template <typename T, int ACT>
-__global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const GNParams p) {
-    __shared__ float smc[3][2048];
-    __shared__ float smw[8];
+__global__ __launch_bounds__(GN_BWD_THREADS) void gn_bwd_fused_kernel(const GNParams p) {
+    constexpr int NW = GN_BWD_THREADS / 64;
+    __shared__ float smc[3][NW][GN_BWD_MAX_CV * 8];
+    __shared__ float smw[2 * NW];
     __shared__ float smk[4];
-    const GNSlab c = gn_slab(p);
-    const T* y = reinterpret_cast<const T*>(p.y) + (long)c.b * p.T * p.ldy + c.c0;
-    const T* dout = reinterpret_cast<const T*>(p.dout) + (long)c.b * p.T * p.lddout + c.c0;
-    Raw8<T> ry[GN_FUSED_ITERS], rd[GN_FUSED_ITERS];
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int nv = p.Cg >> 3, CVg = p.CV, RL = GN_BWD_THREADS / CVg;
+    const int tx = threadIdx.x % CVg, ty = threadIdx.x / CVg, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const bool col_ok = tx < nv;
+    const int c0 = g * p.Cg + tx * 8;
+    const T* y = reinterpret_cast<const T*>(p.y) + (long)b * p.T * p.ldy + c0;
+    const T* dout = reinterpret_cast<const T*>(p.dout) + (long)b * p.T * p.lddout + c0;
+    Raw8<T> ry[GN_BWD_ITERS], rd[GN_BWD_ITERS];
 #pragma unroll
-    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
-        const int t = c.ty + i * c.RL;
-        if (c.col_ok && t < p.T) {
+    for (int i = 0; i < GN_BWD_ITERS; ++i) {
+        const int t = ty + i * RL;
+        if (col_ok && t < p.T) {
             raw_load(y + (long)t * p.ldy, ry[i]);
             raw_load(dout + (long)t * p.lddout, rd[i]);
         }
     }
     const double n = (double)p.Cg * (double)p.T;
     if (threadIdx.x == 0) {
-        const double s = p.sums[((long)c.b * p.G + c.g) * 2 + 0], ss = p.sums[((long)c.b * p.G + c.g) * 2 + 1];
+        const double s = p.sums[((long)b * p.G + g) * 2 + 0], ss = p.sums[((long)b * p.G + g) * 2 + 1];
         const double m = s / n;
         double var = ss / n - m * m;
         if (var < 0.0) var = 0.0;
@@ -581,16 +589,17 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const GNParams p) {
     const float mean = smk[0], rstd = smk[1];
     float gam[8], bet[8];
     float col[3][8];
+    float dz[GN_BWD_ITERS][8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) { col[0][e] = 0.f; col[1][e] = 0.f; col[2][e] = 0.f; gam[e] = 0.f; bet[e] = 0.f; }
-    if (c.col_ok) {
+    if (col_ok) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c.c0 + e]; bet[e] = p.beta[c.c0 + e]; }
+        for (int e = 0; e < 8; ++e) { gam[e] = p.gamma[c0 + e]; bet[e] = p.beta[c0 + e]; }
     }
 #pragma unroll
-    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
-        const int t = c.ty + i * c.RL;
-        if (c.col_ok && t < p.T) {
+    for (int i = 0; i < GN_BWD_ITERS; ++i) {
+        const int t = ty + i * RL;
+        if (col_ok && t < p.T) {
             float v[8], d[8];
             raw_unpack(ry[i], v);
             raw_unpack(rd[i], d);
@@ -598,69 +607,81 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const GNParams p) {
             for (int e = 0; e < 8; ++e) {
                 const float xh = (v[e] - mean) * rstd;
                 const float z = xh * gam[e] + bet[e];
-                const float dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
-                col[0][e] += dz;
-                col[1][e] += dz * xh;
+                const float q = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
+                dz[i][e] = q;
+                col[0][e] += q;
+                col[1][e] += q * xh;
                 col[2][e] += xh;
             }
         }
     }
-    // column sums over the row lanes, then the two group sums
-    if (c.RL > 1) {
+    // column sums: lanes l, l + CVg, l + 2 CVg ... of a wave hold the same column vector
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            float v = col[k][e];
+            for (int o = 32; o >= CVg; o >>= 1) v += __shfl_xor(v, o, 64);
+            col[k][e] = v;
+        }
+    if (lane < CVg) {
 #pragma unroll
         for (int k = 0; k < 3; ++k)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) smc[k][(c.ty * c.CVg + c.tx) * 8 + e] = col[k][e];
-        __syncthreads();
+            for (int e = 0; e < 8; ++e) smc[k][wave][lane * 8 + e] = col[k][e];
     }
+    __syncthreads();
     float s1 = 0.f, s2 = 0.f;
-    if (c.ty == 0 && c.col_ok) {
-        for (int r = 1; r < c.RL; ++r)
+    const bool owner = threadIdx.x < CVg && col_ok;          // wave 0, one lane per column vector (tx == lane)
+    if (owner) {
 #pragma unroll
-            for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 3; ++k)
 #pragma unroll
-                for (int e = 0; e < 8; ++e) col[k][e] += smc[k][(r * c.CVg + c.tx) * 8 + e];
+            for (int e = 0; e < 8; ++e) {
+                float v = 0.f;
+                for (int w = 0; w < NW; ++w) v += smc[k][w][lane * 8 + e];
+                col[k][e] = v;
+            }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { s1 += gam[e] * col[0][e]; s2 += gam[e] * col[1][e]; }
     }
-    const float w1 = wave_sum(s1), w2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) { smw[(threadIdx.x >> 6) * 2] = w1; smw[(threadIdx.x >> 6) * 2 + 1] = w2; }
+    if (wave == 0) {
+        const float w1 = wave_sum(s1), w2 = wave_sum(s2);
+        if (lane == 0) { smw[0] = w1; smw[1] = w2; }
+    }
     __syncthreads();
-    s1 = smw[0] + smw[2] + smw[4] + smw[6];
-    s2 = smw[1] + smw[3] + smw[5] + smw[7];
+    s1 = smw[0];
+    s2 = smw[1];
     if (threadIdx.x == 0) {
-        p.sums2[((long)c.b * p.G + c.g) * 2 + 0] = (double)s1;
-        p.sums2[((long)c.b * p.G + c.g) * 2 + 1] = (double)s2;
+        p.sums2[((long)b * p.G + g) * 2 + 0] = (double)s1;
+        p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
     }
     const float m1 = (float)((double)s1 / n), m2 = (float)((double)s2 / n);
-    if (c.ty == 0 && c.col_ok) {
+    if (owner) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-            atomicAdd(p.dbeta + c.c0 + e, col[0][e]);
-            atomicAdd(p.dgamma + c.c0 + e, col[1][e]);
-            if (p.dbias) atomicAdd(p.dbias + c.c0 + e, p.gscale * rstd * (gam[e] * col[0][e] - (float)p.T * m1 - m2 * col[2][e]));
+            atomicAdd(p.dbeta + c0 + e, col[0][e]);
+            atomicAdd(p.dgamma + c0 + e, col[1][e]);
+            if (p.dbias) atomicAdd(p.dbias + c0 + e, p.gscale * rstd * (gam[e] * col[0][e] - (float)p.T * m1 - m2 * col[2][e]));
         }
     }
     // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) * gscale, and <G, W_eff> += sum dY * (y - conv bias)
     float dotacc = 0.f;
-    if (c.col_ok) {
+    if (col_ok) {
         float cb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) cb[e] = p.cbias ? p.cbias[c.c0 + e] : 0.f;
-        T* dy = reinterpret_cast<T*>(p.out) + (long)c.b * p.T * p.ldout + c.c0;
+        for (int e = 0; e < 8; ++e) cb[e] = p.cbias ? p.cbias[c0 + e] : 0.f;
+        T* dy = reinterpret_cast<T*>(p.out) + (long)b * p.T * p.ldout + c0;
 #pragma unroll
-        for (int i = 0; i < GN_FUSED_ITERS; ++i) {
-            const int t = c.ty + i * c.RL;
+        for (int i = 0; i < GN_BWD_ITERS; ++i) {
+            const int t = ty + i * RL;
             if (t < p.T) {
-                float v[8], d[8];
+                float v[8];
                 raw_unpack(ry[i], v);
-                raw_unpack(rd[i], d);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const float xh = (v[e] - mean) * rstd;
-                    const float z = xh * gam[e] + bet[e];
-                    const float dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
-                    const float r = rstd * (gam[e] * dz - m1 - xh * m2) * p.gscale;
+                    const float r = rstd * (gam[e] * dz[i][e] - m1 - xh * m2) * p.gscale;
                     dotacc += r * (v[e] - cb[e]);
                     v[e] = r;
                 }
@@ -668,7 +689,17 @@ __global__ __launch_bounds__(256) void gn_bwd_fused_kernel(const GNParams p) {
             }
         }
     }
-    if (p.cdot) block_atomic_add(dotacc, p.cdot);
+    if (p.cdot) {
+        const float w = wave_sum(dotacc);
+        __syncthreads();
+        if (lane == 0) smw[wave] = w;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            float tot = 0.f;
+            for (int k = 0; k < NW; ++k) tot += smw[k];
+            atomicAdd(p.cdot + ((blockIdx.x + blockIdx.y * gridDim.x) & (SGV_DOT_SLOTS - 1)), tot);
+        }
+    }
 }
 
 // activation without GroupNorm: MODE 0: out = gelu(y); MODE 1: out = dout*rscale*gelu'(y) (+ colsum -> dbias)
@@ -806,11 +837,18 @@ static int gn_fused_cv(const GNParams& p) {
     while (cv < p.Cg / 8) cv <<= 1;
     return cv;
 }
-#define GN_FUSED_LAUNCH(KERN, P, S)                                                          \
+static bool gn_fused_bwd_ok(const GNParams& p) {
+    static const int on = getenv("SGV_GN_FUSED") ? atoi(getenv("SGV_GN_FUSED")) : 1;
+    if (!on || p.Cg % 8 || p.G > SGV_GN_MAX_GROUPS) return false;
+    const int cv = gn_fused_cv(p);
+    return cv <= GN_BWD_MAX_CV && (p.T + GN_BWD_THREADS / cv - 1) / (GN_BWD_THREADS / cv) <= GN_BWD_ITERS;
+}
+#define GN_FUSED_LAUNCH_N(KERN, NT, P, S)                                                    \
     do {                                                                                     \
         (P).CV = gn_fused_cv(P);                                                             \
-        hipLaunchKernelGGL(KERN, dim3((P).G, (P).B), dim3(256), 0, S, P);                    \
+        hipLaunchKernelGGL(KERN, dim3((P).G, (P).B), dim3(NT), 0, S, P);                     \
     } while (0)
+#define GN_FUSED_LAUNCH(KERN, P, S) GN_FUSED_LAUNCH_N(KERN, 256, P, S)
 // statistics + normalise: p.sums must be zero on entry for the multi-kernel path (the fused one overwrites it)
 int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s) {
     if (!gn_fused_ok(p) || !p.out) {
@@ -833,20 +871,20 @@ int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s) {
 }
 // reduce + finalize + dY for act in {0 none, 1 gelu, 3 relu}; p carries both the reduce and the apply arguments
 int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s) {
-    if (!gn_fused_ok(p)) {
+    if (!gn_fused_bwd_ok(p)) {
         GNParams q = p;
         q.out = nullptr; q.cdot = nullptr; q.cbias = nullptr;
         ew_gn_bwd_reduce_act(dtype, act, q, s);
         return ew_gn_bwd_apply_act(dtype, act, p, s);
     }
     if (dtype == 1) {
-        if (act == 1) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<bf16_t, 1>), p, s);
-        else if (act == 3) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<bf16_t, 3>), p, s);
-        else GN_FUSED_LAUNCH((gn_bwd_fused_kernel<bf16_t, 0>), p, s);
+        if (act == 1) GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<bf16_t, 1>), GN_BWD_THREADS, p, s);
+        else if (act == 3) GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<bf16_t, 3>), GN_BWD_THREADS, p, s);
+        else GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<bf16_t, 0>), GN_BWD_THREADS, p, s);
     } else {
-        if (act == 1) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<float, 1>), p, s);
-        else if (act == 3) GN_FUSED_LAUNCH((gn_bwd_fused_kernel<float, 3>), p, s);
-        else GN_FUSED_LAUNCH((gn_bwd_fused_kernel<float, 0>), p, s);
+        if (act == 1) GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<float, 1>), GN_BWD_THREADS, p, s);
+        else if (act == 3) GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<float, 3>), GN_BWD_THREADS, p, s);
+        else GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<float, 0>), GN_BWD_THREADS, p, s);
     }
     return 0;
 }
