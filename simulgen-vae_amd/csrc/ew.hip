@@ -1168,19 +1168,23 @@ int ew_stage_bwd(int dtype, const float* pz, const float* qz, const float* eps, 
 template <typename TX>
 __global__ __launch_bounds__(256) void linear_head_fwd_kernel(const TX* X, const float* W, const float* bias,
                                                              const float* scale, float* Y, int B, int K, int O) {
+    // block = (output o, K slice kz); a thread's W vector meets 8 batch rows at a time, all loads of a round independent
+    constexpr int BG = 8;
     const int o = blockIdx.x;
     const int ks = gridDim.y, kz = blockIdx.y;
     const int nv = K / 8;
     const int v_lo = (int)((long)nv * kz / ks), v_hi = (int)((long)nv * (kz + 1) / ks);
     const float sc = scale ? *scale : 1.f;
-    __shared__ float sm[4];
-    for (int b0 = 0; b0 < B; b0 += 4) {
-        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    __shared__ float sm[4][BG];
+    for (int b0 = 0; b0 < B; b0 += BG) {
+        float acc[BG];
+#pragma unroll
+        for (int bb = 0; bb < BG; ++bb) acc[bb] = 0.f;
         for (int v = v_lo + threadIdx.x; v < v_hi; v += 256) {
             float w[8];
             load8(W + (long)o * K + v * 8, w);
 #pragma unroll
-            for (int bb = 0; bb < 4; ++bb) {
+            for (int bb = 0; bb < BG; ++bb) {
                 if (b0 + bb < B) {
                     float x[8];
                     load8(X + (long)(b0 + bb) * K + v * 8, x);
@@ -1189,17 +1193,17 @@ __global__ __launch_bounds__(256) void linear_head_fwd_kernel(const TX* X, const
                 }
             }
         }
+        __syncthreads();
 #pragma unroll
-        for (int bb = 0; bb < 4; ++bb) {
+        for (int bb = 0; bb < BG; ++bb) {
             const float wsum = wave_sum(acc[bb]);
-            __syncthreads();
-            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = wsum;
-            __syncthreads();
-            if (threadIdx.x == 0 && b0 + bb < B) {
-                float t = (sm[0] + sm[1] + sm[2] + sm[3]) * sc;
-                if (kz == 0 && bias) t += bias[o];
-                atomicAdd(&Y[(long)(b0 + bb) * O + o], t);
-            }
+            if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6][bb] = wsum;
+        }
+        __syncthreads();
+        if (threadIdx.x < BG && b0 + (int)threadIdx.x < B) {
+            float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) * sc;
+            if (kz == 0 && bias) t += bias[o];
+            atomicAdd(&Y[(long)(b0 + threadIdx.x) * O + o], t);
         }
     }
 }
@@ -1256,9 +1260,9 @@ __global__ __launch_bounds__(256) void linear_head_bwd_dw_kernel(const float* dY
 int ew_linear_head_fwd(int xdtype, const void* X, const float* W, const float* bias, const float* scale, float* Y, int B,
                        int K, int O, hipStream_t s) {
     hipMemsetAsync(Y, 0, sizeof(float) * (size_t)B * O, s);
-    int ks = cdiv_i(K / 8, 2048);
+    int ks = cdiv_i(K / 8, 512);       // two vectors per thread: the pass is latency-bound, not bandwidth-bound
     if (ks < 1) ks = 1;
-    if (ks > 64) ks = 64;
+    if (ks > 128) ks = 128;
     dim3 grid(O, ks);
     if (xdtype == 1) hipLaunchKernelGGL((linear_head_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, W, bias, scale, Y, B, K, O);
     else hipLaunchKernelGGL((linear_head_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)X, W, bias, scale, Y, B, K, O);
