@@ -1303,6 +1303,7 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
     if (train) {
         HIPCHK(hipMemsetAsync(e->recon_unit, 0, 3L * e->N * 4, e->stream));
         p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
+        HIPCHK(hipMemsetAsync(p.sums2, 0, sizeof(double) * 2 * B * g.G, e->stream));   // the reduce pass accumulates into it
         p.dbias = e->recon_unit + 2L * e->N; p.part = e->colpart; p.gscale = 1.0f;
     }
     ew_recon_loss(e->dt, train, p, e->stream);

@@ -305,74 +305,64 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
             atomicAdd(&p.loss_sums[1], (double)(sml[1] + sml[3] + sml[5] + sml[7]));
         }
     }
-    if constexpr (TRAIN) gn_block_colsums<3>(p, c, col);
+    if constexpr (TRAIN) {
+        gn_block_colsums<3>(p, c, col);          // ty == 0 threads now hold the block's column sums
+        // group sums s1 = sum gamma*A, s2 = sum gamma*B of this block's columns -> p.sums2 (fp64 atomics; zeroed per step)
+        __shared__ float smG[2 * SGV_GN_MAX_GROUPS];
+        if (threadIdx.x < 2 * SGV_GN_MAX_GROUPS) smG[threadIdx.x] = 0.f;
+        __syncthreads();
+        if (c.ty == 0 && c.col_ok) {
+            int gprev = c.c0 / p.Cg;
+            float ga = 0.f, gb = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int g = (c.c0 + e) / p.Cg;
+                if (g != gprev) {
+                    atomicAdd(&smG[gprev * 2], ga);
+                    atomicAdd(&smG[gprev * 2 + 1], gb);
+                    ga = 0.f; gb = 0.f; gprev = g;
+                }
+                const float gm = p.gamma[c.c0 + e];
+                ga += gm * col[0][e];
+                gb += gm * col[1][e];
+            }
+            atomicAdd(&smG[gprev * 2], ga);
+            atomicAdd(&smG[gprev * 2 + 1], gb);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < p.G * 2) {
+            const float v = smG[threadIdx.x];
+            if (v != 0.f) atomicAdd(&p.sums2[(long)c.b * p.G * 2 + threadIdx.x], (double)v);
+        }
+    }
 }
 
-// One block per (group, sample): combine the row-block partials of gn_bwd_reduce_kernel into
-//   sums2[b][g] = (s1, s2) = (sum gamma*A, sum gamma*B)            (consumed by gn_bwd_apply_kernel)
+// One thread per (sample, column): combine the row-block partials of gn_bwd_reduce_kernel (A = sum dz, B = sum dz*xhat,
+// X = sum xhat) with the group sums that kernel accumulated in p.sums2 = (s1, s2) = (sum gamma*A, sum gamma*B):
 //   dbeta_c += A_c, dgamma_c += B_c                                  (atomics across the B samples only)
 //   dbias_c += gscale * rstd * (gamma_c*A_c - T*s1/n - (s2/n)*X_c)   (= column sum of dY, analytically)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, int RS) {
-    const int g = blockIdx.x, b = blockIdx.y;
-    const int c_lo = g * p.Cg, c_hi = c_lo + p.Cg;
+    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+    if (c >= p.C) return;
+    const int g = min(c / p.Cg, p.G - 1);
     const float* part = p.part + ((long)b * RS * 3) * p.C;
-    // thread = (column lane cl, row lane rl): narrow groups use the spare threads to split the RS partial rows
-    int CP = 256;
-    while (CP >= 2 * p.Cg && CP > 1) CP >>= 1;
-    const int RLn = 256 / CP;
-    const int cl = threadIdx.x % CP, rl = threadIdx.x / CP;
-    const bool single = p.Cg <= CP;          // one column per thread: the sums stay in registers for the second half
-    __shared__ float smr[3][256];
-    __shared__ float sm[8];
     float A = 0.f, Bv = 0.f, X = 0.f;
-    float s1 = 0.f, s2 = 0.f;
-    for (int c0 = c_lo; c0 < c_hi; c0 += CP) {
-        const int c = c0 + cl;
-        A = 0.f; Bv = 0.f; X = 0.f;
-        if (c < c_hi)
-            for (int r = rl; r < RS; r += RLn) {
-                A += part[((long)r * 3 + 0) * p.C + c];
-                Bv += part[((long)r * 3 + 1) * p.C + c];
-                X += part[((long)r * 3 + 2) * p.C + c];
-            }
-        if (RLn > 1) {
-            smr[0][threadIdx.x] = A; smr[1][threadIdx.x] = Bv; smr[2][threadIdx.x] = X;
-            __syncthreads();
-            if (rl == 0)
-                for (int k = 1; k < RLn; ++k) { A += smr[0][k * CP + cl]; Bv += smr[1][k * CP + cl]; X += smr[2][k * CP + cl]; }
-            __syncthreads();
-        }
-        if (rl == 0 && c < c_hi) { const float gm = p.gamma[c]; s1 += gm * A; s2 += gm * Bv; }
+    for (int r = 0; r < RS; ++r) {
+        A += part[((long)r * 3 + 0) * p.C + c];
+        Bv += part[((long)r * 3 + 1) * p.C + c];
+        X += part[((long)r * 3 + 2) * p.C + c];
     }
-    const float w1 = wave_sum(s1), w2 = wave_sum(s2);
-    if ((threadIdx.x & 63) == 0) { sm[(threadIdx.x >> 6) * 2] = w1; sm[(threadIdx.x >> 6) * 2 + 1] = w2; }
-    __syncthreads();
-    s1 = sm[0] + sm[2] + sm[4] + sm[6];
-    s2 = sm[1] + sm[3] + sm[5] + sm[7];
-    if (threadIdx.x == 0) {
-        p.sums2[((long)b * p.G + g) * 2 + 0] = (double)s1;
-        p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
-    }
-    if (rl != 0) return;
-    const double n = (double)p.Cg * (double)p.T;
-    const double sm_ = p.sums[((long)b * p.G + g) * 2 + 0], ss_ = p.sums[((long)b * p.G + g) * 2 + 1];
-    const double mean = sm_ / n;
-    double var = ss_ / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-    const float m1 = (float)((double)s1 / n), m2 = (float)((double)s2 / n);
-    for (int c = c_lo + cl; c < c_hi; c += CP) {
-        if (!single) {
-            A = 0.f; Bv = 0.f; X = 0.f;
-            for (int r = 0; r < RS; ++r) {
-                A += part[((long)r * 3 + 0) * p.C + c];
-                Bv += part[((long)r * 3 + 1) * p.C + c];
-                X += part[((long)r * 3 + 2) * p.C + c];
-            }
-        }
-        atomicAdd(p.dbeta + c, A);
-        atomicAdd(p.dgamma + c, Bv);
-        if (p.dbias) atomicAdd(p.dbias + c, p.gscale * rstd * (p.gamma[c] * A - (float)p.T * m1 - m2 * X));
+    atomicAdd(p.dbeta + c, A);
+    atomicAdd(p.dgamma + c, Bv);
+    if (p.dbias) {
+        const double n = (double)p.Cg * (double)p.T;
+        const double sm_ = p.sums[((long)b * p.G + g) * 2 + 0], ss_ = p.sums[((long)b * p.G + g) * 2 + 1];
+        const double mean = sm_ / n;
+        double var = ss_ / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+        const float m1 = (float)(p.sums2[((long)b * p.G + g) * 2 + 0] / n), m2 = (float)(p.sums2[((long)b * p.G + g) * 2 + 1] / n);
+        atomicAdd(p.dbias + c, p.gscale * rstd * (p.gamma[c] * A - (float)p.T * m1 - m2 * X));
     }
 }
 
@@ -771,7 +761,7 @@ constexpr int GN_REDUCE_TARGET = 768;
 
 static void gn_finalize(GNParams p, hipStream_t s) {
     GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, s, p, g_.rowsplit);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv_i(p.C, 256), p.B), dim3(256), 0, s, p, g_.rowsplit);
 }
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
     if (dtype == 1) GN_LAUNCH((gn_stats_kernel<bf16_t>), p, s);
