@@ -31,20 +31,43 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const SNDesc* descs, const
 }
 
 // ---- pass 2: v = t / max(||t||, 1e-12) ------------------------------------------------------------
+// sum of squares / dot of one vector by one 1024-thread block: 16-byte loads when the base is 16-byte aligned, float
+// partials per thread (<= ~100 terms), fp64 across threads
+__device__ __forceinline__ double block1024_dot(const float* a, const float* b, long n) {
+    __shared__ double smd[16];
+    float acc = 0.f;
+    const bool vec = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+        const float4 x = reinterpret_cast<const float4*>(a)[i], y = reinterpret_cast<const float4*>(b)[i];
+        acc += x.x * y.x + x.y * y.y + x.z * y.z + x.w * y.w;
+    }
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 1024) acc += a[i] * b[i];
+    const double w = wave_sum_d((double)acc);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smd[threadIdx.x >> 6] = w;
+    __syncthreads();
+    double tot = 0.0;
+    for (int i = 0; i < 16; ++i) tot += smd[i];
+    return tot;
+}
+__device__ __forceinline__ void block1024_scale(const float* src, float* dst, float f, long n) {
+    const bool vec = ((((uintptr_t)src) | ((uintptr_t)dst)) & 15) == 0;
+    const long n4 = vec ? n >> 2 : 0;
+    for (long i = threadIdx.x; i < n4; i += 1024) {
+        float4 x = reinterpret_cast<const float4*>(src)[i];
+        x.x *= f; x.y *= f; x.z *= f; x.w *= f;
+        reinterpret_cast<float4*>(dst)[i] = x;
+    }
+    for (long i = n4 * 4 + threadIdx.x; i < n; i += 1024) dst[i] = src[i] * f;
+}
 __global__ __launch_bounds__(1024) void sn_norm_v_kernel(const SNDesc* descs, int ndesc) {
     const SNDesc d = descs[blockIdx.x];
     if (!d.active) return;
     const long n = (long)d.taps * d.cols;
-    double acc = 0.0;
-    for (long i = threadIdx.x; i < n; i += 1024) { const double t = d.tmp_t[i]; acc += t * t; }
-    __shared__ double sm[16];
-    const double w = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
-    __syncthreads();
-    double tot = 0.0;
-    for (int i = 0; i < 16; ++i) tot += sm[i];
+    const double tot = block1024_dot(d.tmp_t, d.tmp_t, n);
     const float inv = 1.0f / fmaxf((float)sqrt(tot), 1e-12f);
-    for (long i = threadIdx.x; i < n; i += 1024) d.v[i] = d.tmp_t[i] * inv;
+    block1024_scale(d.tmp_t, d.v, inv, n);
 }
 
 // ---- pass 3: tmp_s[r] += sum_c W[tap][r][c] * v[tap][c]; one wave per row ---------------------------
@@ -78,23 +101,11 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const 
 __global__ __launch_bounds__(1024) void sn_norm_u_kernel(const SNDesc* descs, int train) {
     const SNDesc d = descs[blockIdx.x];
     if (!d.active) return;
-    __shared__ double sm[16];
-    double acc = 0.0;
-    if (train) {
-        for (int i = threadIdx.x; i < d.rows; i += 1024) { const double t = d.tmp_s[i]; acc += t * t; }
-    } else {
-        for (int i = threadIdx.x; i < d.rows; i += 1024) acc += (double)d.u[i] * (double)d.tmp_s[i];
-    }
-    const double w = wave_sum_d(acc);
-    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
-    __syncthreads();
-    double tot = 0.0;
-    for (int i = 0; i < 16; ++i) tot += sm[i];
+    const double tot = train ? block1024_dot(d.tmp_s, d.tmp_s, d.rows) : block1024_dot(d.u, d.tmp_s, d.rows);
     float sigma;
     if (train) {
         const float nrm = fmaxf((float)sqrt(tot), 1e-12f);
-        const float inv = 1.0f / nrm;
-        for (int i = threadIdx.x; i < d.rows; i += 1024) d.u[i] = d.tmp_s[i] * inv;
+        block1024_scale(d.tmp_s, d.u, 1.0f / nrm, d.rows);
         sigma = (float)(tot / (double)nrm);   // u . s with u = s/nrm
     } else {
         sigma = (float)tot;
