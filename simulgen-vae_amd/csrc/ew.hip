@@ -738,12 +738,6 @@ __global__ __launch_bounds__(256) void act_kernel(const GNParams p) {
     }
 }
 
-template <typename T>
-static void gn_dispatch_fill(GNParams& p, int B, int T_, int C) {
-    GNGeom g = gn_geom(B, T_, C);
-    p.CV = g.CV;
-}
-
 #define GN_LAUNCH(KERN, P, S)                                              \
     do {                                                                   \
         GNGeom g_ = gn_geom((P).B, (P).T, (P).C);                          \
@@ -806,12 +800,6 @@ int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s) {
         else if (act == 3) GN_LAUNCH((gn_bwd_apply_kernel<float, 3, false>), p, s);
         else GN_LAUNCH((gn_bwd_apply_kernel<float, 0, false>), p, s);
     }
-    return 0;
-}
-int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s) {   // gelu, stored gradient; + finalize
-    if (dtype == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 1, false, true>), p, s);
-    else GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 1, false, true>), p, s);
-    gn_finalize(p, s);
     return 0;
 }
 // one launch per direction for small slabs (SGV_GN_FUSED=0 restores the multi-kernel path for A/B runs)
@@ -881,11 +869,6 @@ int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s) {
 size_t ew_gn_part_floats(int B, int T, int C) {
     GNGeom g_ = gn_geom(B, T, C, GN_REDUCE_TARGET);
     return (size_t)B * g_.rowsplit * 3 * C;
-}
-int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s) {
-    if (dtype == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 1, false>), p, s);
-    else GN_LAUNCH((gn_bwd_apply_kernel<float, 1, false>), p, s);
-    return 0;
 }
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + loss (+ bwd reduce)
     if (dtype == 1) {

@@ -33,9 +33,7 @@ int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s);   // reduce + fina
 int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // act: 0 none, 1 gelu, 3 relu
 int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
-int ew_gn_bwd_reduce(int dtype, GNParams p, hipStream_t s);
 size_t ew_gn_part_floats(int B, int T, int C);
-int ew_gn_bwd_apply(int dtype, GNParams p, hipStream_t s);
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s);
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s);
 int ew_act(int dtype, int mode, GNParams p, hipStream_t s);
