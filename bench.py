@@ -182,7 +182,7 @@ def main():
     from simulgen_vae_amd import engine as E
     from simulgen_vae_amd.init import init_state
     from simulgen_vae_amd.spec import VAEConfig
-    from simulgen_vae_amd.modules.train import GradAllReduce
+    from simulgen_vae_amd.modules.train import make_allreduce
 
     cfg = VAEConfig(LATENT, HIER, ENC, ENC[::-1], N_NODE, N_TIME, "MSE", args.size == "small")
     B = args.batch
@@ -209,7 +209,7 @@ def main():
 
     ddp = world > 1 or (os.environ.get("SGV_FORCE_DDP") == "1" and dist.is_initialized())   # forced: plumbing test at N=1
     # bucketed mean all-reduce over RCCL, overlapped with backward and with AdamW (modules/train.py GradAllReduce)
-    allreduce = GradAllReduce(eng) if ddp else None
+    allreduce = make_allreduce(eng) if ddp else None
 
     rng = random.Random(99 + rank)
     nprng = np.random.RandomState(5 + rank)

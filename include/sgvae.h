@@ -144,6 +144,24 @@ int sgv_set_bucket_callback(sgv_engine* e, sgv_bucket_cb cb, void* user);
 int sgv_grad_buffer(sgv_engine* e, float** dev_ptr, size_t* count_elems);
 int sgv_scale_grads(sgv_engine* e, float factor);
 
+/* Native RCCL path (sgv_allreduce_grads(rcclComm_t); 8(e): one collective per step, overlapped with the
+ * decoder backward).  RCCL is resolved at run time (dlopen of librccl.so.1, i.e. the copy already loaded in the process
+ * if there is one), so the library has no link-time dependency on it.
+ *  - sgv_rccl_unique_id / sgv_rccl_comm_init / sgv_rccl_comm_destroy: ncclGetUniqueId (128 bytes, rank 0; the caller
+ *    broadcasts them), ncclCommInitRank, ncclCommDestroy -- so a host needs no RCCL binding of its own.
+ *  - sgv_allreduce_grads: mean all-reduce (ncclAvg, fp32) of the whole gradient arena, bucket by bucket in backward
+ *    order, on comm_stream after everything enqueued so far on the engine stream; the engine stream then waits for it.
+ *  - sgv_set_rccl: register (comm, comm_stream) with the engine (NULL comm unregisters).  While registered,
+ *    sgv_backward issues each bucket's all-reduce itself as soon as the kernels producing it are enqueued (no host
+ *    callback), sgv_adamw_step / sgv_adamw_step_range make the engine stream wait for exactly the buckets they touch, and
+ *    sgv_adamw_step updates every layer whose bucket has arrived while the last (first-encoder-layer) bucket is in flight;
+ *    sgv_backward_step = sgv_backward + that sgv_adamw_step.  Mutually exclusive with sgv_set_bucket_callback. */
+int sgv_rccl_unique_id(void* id128);
+int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank);
+int sgv_rccl_comm_destroy(void* comm);
+int sgv_allreduce_grads(sgv_engine* e, void* rccl_comm, void* comm_stream);
+int sgv_set_rccl(sgv_engine* e, void* rccl_comm, void* comm_stream);
+
 /* Gradient 2-norm as train.py:156-161 computes it.  [sync] */
 int sgv_grad_norm(sgv_engine* e, double* out);
 /* torch.optim.AdamW(lr).step() with its defaults (train.py:92,168): betas (0.9, 0.999),

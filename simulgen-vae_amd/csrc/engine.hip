@@ -6,6 +6,7 @@
 //   Decoder modules/decoder.py:84-223 ; blocks modules/common.py:78-162 ; losses modules/losses.py:8-48 ;
 //   training step modules/train.py:139-168.
 // The backward pass is written out by hand (the reference uses autograd).
+#include <dlfcn.h>
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -128,6 +129,8 @@ struct sgv_engine {
     // the big ones there too loses 2.5 %: they fill every CU on their own and co-running kernels evict each other's
     // L2 tiles.  Option "dw_side_stream" / SGV_DW_SIDE=0 turns it off; kernel-timing passes always run on one stream.
     hipStream_t side = nullptr;
+    void* comm = nullptr; hipStream_t comm_stream = nullptr;          // native RCCL path (sgv_set_rccl)
+    std::vector<hipEvent_t> bucket_done; std::vector<char> bucket_pending;
     float* partial_tn = nullptr; size_t partial_tn_floats = 0;
     std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
     bool use_side = true, side_dirty = false;
@@ -1434,8 +1437,107 @@ int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t coun
     return fail(SGV_ERR_NAME, "unknown activation '%s'", name);
 }
 
+// ---- RCCL, resolved at run time --------------------------------------------------------------------------------
+namespace {
+struct RcclApi {
+    struct Id128 { char b[128]; };             // ncclUniqueId: 128 opaque bytes, passed by value
+    void* h = nullptr;
+    int (*GetUniqueId)(void*) = nullptr;
+    int (*CommInitRank)(void**, int, Id128, int) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+const int kNcclFloat32 = 7, kNcclAvg = 4;      // ncclDataType_t / ncclRedOp_t values of rccl.h (NCCL >= 2.10 ABI)
+int rccl_load() {
+    if (g_rccl.h) return 0;
+    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    void* h = nullptr;
+    for (const char* n : names) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+    if (!h) return fail(SGV_ERR_STATE, "RCCL not found (dlopen librccl.so.1): %s", dlerror());
+    g_rccl.GetUniqueId = (decltype(g_rccl.GetUniqueId))dlsym(h, "ncclGetUniqueId");
+    g_rccl.CommInitRank = (decltype(g_rccl.CommInitRank))dlsym(h, "ncclCommInitRank");
+    g_rccl.CommDestroy = (decltype(g_rccl.CommDestroy))dlsym(h, "ncclCommDestroy");
+    g_rccl.AllReduce = (decltype(g_rccl.AllReduce))dlsym(h, "ncclAllReduce");
+    g_rccl.GetErrorString = (decltype(g_rccl.GetErrorString))dlsym(h, "ncclGetErrorString");
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.CommDestroy || !g_rccl.AllReduce)
+        return fail(SGV_ERR_STATE, "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce");
+    g_rccl.h = h;
+    return 0;
+}
+int rccl_fail(const char* what, int rc) {
+    return fail(SGV_ERR_HIP, "%s failed: %s", what, g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error");
+}
+}  // namespace
+
+int sgv_rccl_unique_id(void* id128) {
+    if (!id128) return fail(SGV_ERR_ARG, "null argument");
+    CHK(rccl_load());
+    const int rc = g_rccl.GetUniqueId(id128);
+    return rc ? rccl_fail("ncclGetUniqueId", rc) : SGV_OK;
+}
+int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank) {
+    if (!comm_out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(SGV_ERR_ARG, "bad argument");
+    CHK(rccl_load());
+    RcclApi::Id128 id;
+    memcpy(id.b, id128, 128);
+    const int rc = g_rccl.CommInitRank(comm_out, nranks, id, rank);
+    return rc ? rccl_fail("ncclCommInitRank", rc) : SGV_OK;
+}
+int sgv_rccl_comm_destroy(void* comm) {
+    if (!comm) return SGV_OK;
+    CHK(rccl_load());
+    const int rc = g_rccl.CommDestroy(comm);
+    return rc ? rccl_fail("ncclCommDestroy", rc) : SGV_OK;
+}
+// bucket b: wait (on the communication stream) for what the engine stream holds so far, average it over the ranks
+static int rccl_bucket(sgv_engine* e, void* comm, hipStream_t cs, int b, hipEvent_t done) {
+    hipEvent_t ev = next_event(e);
+    if (!ev) return fail(SGV_ERR_HIP, "event creation failed");
+    HIPCHK(hipEventRecord(ev, e->stream));
+    HIPCHK(hipStreamWaitEvent(cs, ev, 0));
+    float* g = e->grads + e->buckets[b].first;
+    const int rc = g_rccl.AllReduce(g, g, e->buckets[b].second, kNcclFloat32, kNcclAvg, comm, cs);
+    if (rc) return rccl_fail("ncclAllReduce", rc);
+    if (done) HIPCHK(hipEventRecord(done, cs));
+    return 0;
+}
+int sgv_allreduce_grads(sgv_engine* e, void* rccl_comm, void* comm_stream) {
+    if (!e || !rccl_comm) return fail(SGV_ERR_ARG, "null argument");
+    CHK(rccl_load());
+    CHK(join_side(e));
+    const hipStream_t cs = comm_stream ? (hipStream_t)comm_stream : e->stream;
+    for (int b = 0; b < (int)e->buckets.size(); ++b) CHK(rccl_bucket(e, rccl_comm, cs, b, nullptr));
+    if (cs != e->stream) {
+        hipEvent_t ev = next_event(e);
+        if (!ev) return fail(SGV_ERR_HIP, "event creation failed");
+        HIPCHK(hipEventRecord(ev, cs));
+        HIPCHK(hipStreamWaitEvent(e->stream, ev, 0));
+    }
+    return SGV_OK;
+}
+int sgv_set_rccl(sgv_engine* e, void* rccl_comm, void* comm_stream) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (rccl_comm && e->cb) return fail(SGV_ERR_STATE, "a bucket callback is registered: use one of the two data-parallel paths");
+    if (rccl_comm) {
+        if (!comm_stream) return fail(SGV_ERR_ARG, "sgv_set_rccl needs a communication stream of its own");
+        CHK(rccl_load());
+        while (e->bucket_done.size() < e->buckets.size()) {
+            hipEvent_t ev = nullptr;
+            HIPCHK(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+            e->bucket_done.push_back(ev);
+        }
+        e->bucket_pending.assign(e->buckets.size(), 0);
+    }
+    e->comm = rccl_comm;
+    e->comm_stream = (hipStream_t)comm_stream;
+    return SGV_OK;
+}
+
 int sgv_set_bucket_callback(sgv_engine* e, sgv_bucket_cb cb, void* user) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (cb && e->comm) return fail(SGV_ERR_STATE, "an RCCL communicator is registered: use one of the two data-parallel paths");
     e->cb = cb; e->cb_user = user;
     return SGV_OK;
 }
@@ -1461,7 +1563,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     if (!e->have_fwd || !e->fwd_train) return fail(SGV_ERR_STATE, "sgv_backward needs a preceding sgv_forward(train=1)");
     const bool fuse = fuse_lr >= 0.f;
     static const int early_on = getenv("SGV_EARLY_ADAM") ? atoi(getenv("SGV_EARLY_ADAM")) : 1;
-    const bool early = early_on && fuse && !e->cb && e->side && e->use_side && !e->timing;
+    const bool early = early_on && fuse && !e->cb && !e->comm && e->side && e->use_side && !e->timing;
     if (early) CHK(adamw_begin(e));
     const int B = e->batch, n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
@@ -1471,7 +1573,10 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     int early_err = 0;
     auto fire_at = [&](int b) {
         if (b < 0 || b >= (int)e->buckets.size()) return;
-        if (e->cb) {
+        if (e->comm) {
+            if (join_side(e) || rccl_bucket(e, e->comm, e->comm_stream, b, e->bucket_done[b])) { early_err = 1; return; }
+            e->bucket_pending[b] = 1;
+        } else if (e->cb) {
             join_side(e);     // the bucket's weight gradients come from the side stream
             e->cb(e->cb_user, b, e->buckets[b].first, e->buckets[b].second);
         } else if (early && b < (int)e->buckets.size() - 2) {
@@ -1620,6 +1725,14 @@ static int adamw_begin(sgv_engine* e) {
     return 0;
 }
 static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int which, hipStream_t st) {
+    // native RCCL path: the all-reduce of every bucket touched here must have landed, and so must the small bucket's
+    // (last index): it carries the <G,W> scalars every conv weight's update reads
+    const int n_pend = (int)e->bucket_pending.size();
+    for (int b = bucket_lo; b < n_pend; b = (b + 1 < bucket_hi ? b + 1 : (b < n_pend - 1 ? n_pend - 1 : n_pend)))
+        if (e->bucket_pending[b]) {
+            HIPCHK(hipStreamWaitEvent(st, e->bucket_done[b], 0));
+            e->bucket_pending[b] = 0;
+        }
     const double b1 = 0.9, b2 = 0.999;
     const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
     const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
@@ -1647,7 +1760,15 @@ int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, 
 }
 int sgv_adamw_step(sgv_engine* e, float lr) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
-    return sgv_adamw_step_range(e, lr, 0, (int)e->buckets.size(), 1, 1);
+    const int nbk = (int)e->buckets.size();
+    if (e->comm && nbk >= 3) {
+        // every layer whose bucket has arrived, then the small bucket's tensors, while the last weight bucket (first
+        // encoder layer, index nbk - 2) is still in flight; that layer last
+        CHK(sgv_adamw_step_range(e, lr, 0, nbk - 2, 1, 0));
+        CHK(sgv_adamw_step_range(e, lr, nbk - 1, nbk, 0, 0));
+        return sgv_adamw_step_range(e, lr, nbk - 2, nbk - 1, 0, 1);
+    }
+    return sgv_adamw_step_range(e, lr, 0, nbk, 1, 1);
 }
 int sgv_bucket_count(const sgv_engine* e) { return e ? (int)e->buckets.size() : 0; }
 int sgv_last_grad_norm(sgv_engine* e, double* out) {

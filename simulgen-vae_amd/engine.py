@@ -29,6 +29,7 @@ ABI_SYMBOLS = [
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
     "sgv_adamw_step_range", "sgv_bucket_count", "sgv_last_grad_norm", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
+    "sgv_rccl_unique_id", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_tn",
 ]
 
@@ -87,6 +88,11 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_backward_step.argtypes = [vp, f32, f32, f32]
     lib.sgv_adamw_step_range.argtypes = [vp, f32, i32, i32, i32, i32]
     lib.sgv_bucket_count.argtypes = [vp]
+    lib.sgv_rccl_unique_id.argtypes = [vp]
+    lib.sgv_rccl_comm_init.argtypes = [C.POINTER(vp), i32, vp, i32]
+    lib.sgv_rccl_comm_destroy.argtypes = [vp]
+    lib.sgv_allreduce_grads.argtypes = [vp, vp, vp]
+    lib.sgv_set_rccl.argtypes = [vp, vp, vp]
     lib.sgv_last_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
     lib.sgv_augment_collate.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
     lib.sgv_dataset_convert.argtypes = [vp, vp, vp, i32]
@@ -308,6 +314,16 @@ class Engine:
         else:
             self._cb = BUCKET_CB(lambda user, b, off, cnt: fn(b, off, cnt))
         _check(self.lib, self.lib.sgv_set_bucket_callback(self.h, self._cb, None), "sgv_set_bucket_callback")
+
+    def set_rccl(self, comm, comm_stream):
+        """Register an RCCL communicator (sgv_rccl_comm_init) + communication stream: backward() then issues the bucket
+        all-reduces itself and adamw_step() / backward_step() wait for them bucket by bucket.  comm=None unregisters."""
+        _check(self.lib, self.lib.sgv_set_rccl(self.h, C.c_void_p(comm), C.c_void_p(comm_stream) if comm else None), "sgv_set_rccl")
+
+    def allreduce_grads(self, comm, comm_stream=None):
+        """Mean all-reduce of the whole gradient arena (stream-ordered, not overlapped)."""
+        _check(self.lib, self.lib.sgv_allreduce_grads(self.h, C.c_void_p(comm), C.c_void_p(comm_stream) if comm_stream else None),
+               "sgv_allreduce_grads")
 
     # ---- data ----
     def sample_bytes(self) -> int:

@@ -102,6 +102,49 @@ class GradAllReduce:
         self.pending.clear()
 
 
+class NativeAllReduce:
+    """The same data-parallel step with the collective issued by the engine itself (include/sgvae.h: sgv_set_rccl): an
+    RCCL communicator of the library's own (unique id from rank 0, broadcast over the existing torch.distributed group),
+    a dedicated communication stream, bucket all-reduces launched from inside sgv_backward without a host callback, and
+    sgv_adamw_step ordering the waits (first-encoder-layer bucket last).  Opt-in: SGV_DDP_NATIVE=1."""
+
+    def __init__(self, engine, group=None):
+        import ctypes as C
+        self.engine, lib = engine, engine.lib
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        ident = (C.c_char * 128)()
+        if rank == 0:
+            if lib.sgv_rccl_unique_id(ident) != 0:
+                raise RuntimeError(lib.sgv_last_error().decode())
+        t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
+        dev = t.cuda() if dist.get_backend(group) == "nccl" else t
+        dist.broadcast(dev, src=0, group=group)
+        ident = (C.c_char * 128).from_buffer_copy(bytes(dev.cpu().numpy().tobytes()))
+        comm = C.c_void_p()
+        if lib.sgv_rccl_comm_init(C.byref(comm), world, ident, rank) != 0:
+            raise RuntimeError(lib.sgv_last_error().decode())
+        self.comm = comm.value
+        self.stream = torch.cuda.Stream()
+        engine.set_rccl(self.comm, self.stream.cuda_stream)
+
+    def step(self, engine, lr):
+        engine.adamw_step(lr)           # waits for the buckets in the overlapped order (sgv_adamw_step with a communicator)
+
+    def __call__(self, engine):
+        pass                            # gradients are final once the optimiser's stream-side waits have passed
+
+    def close(self):
+        if self.comm:
+            self.engine.set_rccl(None, None)
+            self.engine.lib.sgv_rccl_comm_destroy(self.comm)
+            self.comm = None
+
+
+def make_allreduce(engine, group=None):
+    """GradAllReduce (torch.distributed issues the bucket collectives) or, with SGV_DDP_NATIVE=1, NativeAllReduce."""
+    return NativeAllReduce(engine, group) if os.environ.get("SGV_DDP_NATIVE") == "1" else GradAllReduce(engine, group)
+
+
 def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_enc, num_filter_dec, num_node, latent_dim,
           hierarchical_dim, num_time, alpha, lossfun, small, load_all, debug_mode=0, compute_dtype="bf16"):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
@@ -118,7 +161,7 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
     eng = model._eng(batch_size)
     eng.set_option("write_xhat", 0)
     warmup_kl = WarmupKLLoss(epochs, 1e-4, int(epochs * 0.3), int(epochs * 0.8), 1)   # init_beta hard-coded
-    allreduce = GradAllReduce(eng) if world > 1 else None
+    allreduce = make_allreduce(eng) if world > 1 else None
     fused = hasattr(train_dataloader, "batch_plans")
     data = train_dataloader.resident(eng) if fused else None
 
