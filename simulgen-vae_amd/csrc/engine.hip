@@ -129,6 +129,7 @@ struct sgv_engine {
     // the big ones there too loses 2.5 %: they fill every CU on their own and co-running kernels evict each other's
     // L2 tiles.  Option "dw_side_stream" / SGV_DW_SIDE=0 turns it off; kernel-timing passes always run on one stream.
     hipStream_t side = nullptr;
+    std::vector<char> aug_host[4]; int aug_turn = 0;                  // staging of sgv_augment_collate's control arrays
     void* comm = nullptr; hipStream_t comm_stream = nullptr;          // native RCCL path (sgv_set_rccl)
     std::vector<hipEvent_t> bucket_done; std::vector<char> bucket_pending;
     float* partial_tn = nullptr; size_t partial_tn_floats = 0;
@@ -1824,11 +1825,15 @@ int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const
     int* d_idx = (int*)scratch; int* d_mix = d_idx + batch;
     float* d_scale = (float*)(d_mix + batch); float* d_lam = d_scale + batch;
     unsigned long long* d_seed = (unsigned long long*)(scratch + align_up((size_t)batch * 16, 8));
-    HIPCHK(hipMemcpyAsync(d_idx, idx, batch * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d_mix, mix_idx, batch * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d_scale, scale, batch * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d_lam, lam, batch * 4, hipMemcpyHostToDevice, e->stream));
-    HIPCHK(hipMemcpyAsync(d_seed, noise_seed, batch * 8, hipMemcpyHostToDevice, e->stream));
+    // one host->device copy of the five arrays in the device layout (pageable source: staged before the call returns)
+    const size_t seed_off = align_up((size_t)batch * 16, 8), total = seed_off + (size_t)batch * 8;
+    std::vector<char>& hb = e->aug_host[e->aug_turn++ & 3];           // a buffer is reused four steps later
+    hb.resize(total);
+    char* h = hb.data();
+    memcpy(h, idx, batch * 4); memcpy(h + batch * 4, mix_idx, batch * 4);
+    memcpy(h + batch * 8, scale, batch * 4); memcpy(h + batch * 12, lam, batch * 4);
+    memcpy(h + seed_off, noise_seed, batch * 8);
+    HIPCHK(hipMemcpyAsync(scratch, h, total, hipMemcpyHostToDevice, e->stream));
     ew_augment(e->dt, dataset_dev, e->x_in.p, (long)e->N * e->T, batch, d_idx, d_seed, d_scale, d_mix, d_lam, e->stream);
     e->batch = batch;
     e->have_fwd = false;
