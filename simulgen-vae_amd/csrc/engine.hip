@@ -740,9 +740,7 @@ static const void* wc_ptr(sgv_engine* e, const Layer& l) {
 static const void* wct_ptr(sgv_engine* e, const Layer& l) { return e->copies + l.wct * e->esz; }
 
 // Y = conv(X) * (1/sigma) + bias
-// deferred_k (optional): the caller's next kernel combines the split-K slabs itself (fused GroupNorm); receives the slab
-// count (1 = the output was written normally)
-static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, int* deferred_k = nullptr) {
+static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M) {
     GemmNT p; memset(&p, 0, sizeof(p));
     p.A = x.p; p.lda = x.ld;
     p.W = wc_ptr(e, l); p.ldw = l.cin; p.w_tap_stride = (long)l.cout * l.cin;
@@ -753,8 +751,6 @@ static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor
     p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
     if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    p.defer_reduce = (deferred_k && p.splitk > 1) ? 1 : 0;
-    if (deferred_k) *deferred_k = p.splitk;
     ScopedTimer tm(e, gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
     int r = launch_gemm_nt(e->dt, p, e->stream);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d)", l.prefix.c_str(), p.M, p.N, p.K);
@@ -861,27 +857,17 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
             ew_act(e->dt, 0, p, e->stream);
             cin = S.pre;
         }
+        CHK(conv_fwd(e, L, cin, S.y, M));
         if (S.gn >= 0) {
             const GNLayer& g = e->gns[S.gn];
             GNParams p = gn_base(e, g, B);
             p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
             p.out = S.a.p; p.ldout = S.a.ld;
             if (b.residual && s + 1 == b.st.size()) { p.res = in.p; p.ldres = in.ld; p.rscale = 0.1f; }
-            // small layers: the fused GroupNorm launch also combines the GEMM's split-K slabs (no separate reduce pass)
-            int sk = 1;
-            const bool fuse_reduce = ew_gn_fwd_is_fused(p) && !S.y.f32;
-            CHK(conv_fwd(e, L, cin, S.y, M, fuse_reduce ? &sk : nullptr));
-            if (sk > 1) {
-                p.part_in = e->partial; p.part_k = sk; p.part_stride = M * (long)L.cout;
-                p.part_scale = e->sn_sigma + 2 * L.sn + 1; p.part_bias = e->params + L.b;
-            }
-            if (ew_gn_fwd(e->dt, S.act, p, e->stream)) return fail(SGV_ERR_STATE, "GroupNorm forward rejected its arguments (%s)", L.prefix.c_str());
+            ew_gn_fwd(e->dt, S.act, p, e->stream);
         } else if (S.act) {
-            CHK(conv_fwd(e, L, cin, S.y, M));
             GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.out = S.a.p; p.ldout = S.a.ld; p.B = B; p.T = e->T; p.C = L.cout;
             ew_act(e->dt, 0, p, e->stream);
-        } else {
-            CHK(conv_fwd(e, L, cin, S.y, M));
         }
         x = S.a;
     }

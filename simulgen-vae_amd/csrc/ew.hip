@@ -444,13 +444,6 @@ __device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.v
 __device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
     r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
 }
-__device__ __forceinline__ void raw_pack(const float v[8], Raw8<bf16_t>& r) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) r.v[i] = (bf16_t)v[i];
-}
-__device__ __forceinline__ void raw_pack(const float v[8], Raw8<float>& r) {
-    r.a = make_float4(v[0], v[1], v[2], v[3]); r.b = make_float4(v[4], v[5], v[6], v[7]);
-}
 __device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float v[8]) {
 #pragma unroll
     for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
@@ -491,43 +484,12 @@ __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const GNParams p) {
     const T* y = reinterpret_cast<const T*>(p.y) + (long)c.b * p.T * p.ldy + c.c0;
     const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (long)c.b * p.T * p.ldres + c.c0 : nullptr;
     Raw8<T> ry[GN_FUSED_ITERS], rr[GN_FUSED_ITERS];
-    if (p.part_in) {
-        // the producing GEMM left split-K slabs: combine them here (what gemm_nt_reduce_kernel would do), store y in the
-        // compute dtype for the backward pass and keep the ROUNDED values, so statistics see exactly what backward reads
-        const float sc = p.part_scale ? *p.part_scale : 1.f;
-        float pb[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) pb[e] = (c.col_ok && p.part_bias) ? p.part_bias[c.c0 + e] : 0.f;
-        const float* pin = p.part_in + (long)c.b * p.T * p.C + c.c0;
-        T* yo = const_cast<T*>(y);
-#pragma unroll
-        for (int i = 0; i < GN_FUSED_ITERS; ++i) {
-            const int t = c.ty + i * c.RL;
-            if (c.col_ok && t < p.T) {
-                float v[8];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = 0.f;
-                for (int z = 0; z < p.part_k; ++z) {
-                    float w[8];
-                    load8(pin + (long)z * p.part_stride + (long)t * p.C, w);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) v[e] += w[e];
-                }
-#pragma unroll
-                for (int e = 0; e < 8; ++e) v[e] = v[e] * sc + pb[e];
-                store8(yo + (long)t * p.ldy, v);
-                raw_pack(v, ry[i]);
-                if (res) raw_load(res + (long)t * p.ldres, rr[i]);
-            }
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < GN_FUSED_ITERS; ++i) {
-            const int t = c.ty + i * c.RL;
-            if (c.col_ok && t < p.T) {
-                raw_load(y + (long)t * p.ldy, ry[i]);
-                if (res) raw_load(res + (long)t * p.ldres, rr[i]);
-            }
+    for (int i = 0; i < GN_FUSED_ITERS; ++i) {
+        const int t = c.ty + i * c.RL;
+        if (c.col_ok && t < p.T) {
+            raw_load(y + (long)t * p.ldy, ry[i]);
+            if (res) raw_load(res + (long)t * p.ldres, rr[i]);
         }
     }
     float a = 0.f, q = 0.f;
@@ -865,11 +827,9 @@ static bool gn_fused_bwd_ok(const GNParams& p) {
         hipLaunchKernelGGL(KERN, dim3((P).G, (P).B), dim3(NT), 0, S, P);                     \
     } while (0)
 #define GN_FUSED_LAUNCH(KERN, P, S) GN_FUSED_LAUNCH_N(KERN, 256, P, S)
-bool ew_gn_fwd_is_fused(const GNParams& p) { return gn_fused_ok(p) && p.out != nullptr; }
 // statistics + normalise: p.sums must be zero on entry for the multi-kernel path (the fused one overwrites it)
 int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s) {
     if (!gn_fused_ok(p) || !p.out) {
-        if (p.part_in) return -1;       // slabs are only understood by the fused kernel: callers check ew_gn_fwd_is_fused
         GNParams q = p;
         ew_gn_stats(dtype, q, s);
         return p.out ? ew_gn_apply(dtype, act, p, s) : 0;

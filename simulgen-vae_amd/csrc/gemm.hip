@@ -1126,7 +1126,7 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
     }
     if (main_done) hipEventRecord(main_done, s);
-    if (p.splitk > 1 && !p.defer_reduce) {
+    if (p.splitk > 1) {
         long total = (long)p.M * p.N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;

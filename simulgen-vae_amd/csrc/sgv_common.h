@@ -102,7 +102,6 @@ struct GemmNT {
     const float* scale;             // optional device scalar (1/sigma)
     float* partial;                 // split-K slabs [splitk][M][N] fp32
     int M, N, K, taps, pad, Tlen, splitk, out_f32;
-    int defer_reduce;               // splitk > 1: leave the slabs in `partial`; the caller's next kernel combines them
     long a_bytes, w_bytes;          // filled by launch_gemm_nt: extents for the buffer descriptors
 };
 struct GemmTN {

@@ -19,10 +19,6 @@ struct GNParams {
     double* sums = nullptr;                        // [B*G][2] sum, sum of squares
     double* sums2 = nullptr;                       // [B*G][2] backward group sums
     double* loss_sums = nullptr;                   // [2]
-    // fused forward only: the conv output still lies in split-K slabs part_in[z][B*T][C] (fp32); the kernel forms
-    // y = part_scale * sum_z + part_bias, writes it to `y` (backward needs it) and normalises from registers
-    const float* part_in = nullptr; int part_k = 0; long part_stride = 0;
-    const float* part_scale = nullptr; const float* part_bias = nullptr;
     int B = 0, T = 0, C = 0, G = 1, Cg = 1, CV = 1;
     float rscale = 1.f;                            // residual / incoming-gradient scale
     float gscale = 1.f;                            // output gradient scale (loss weight)
@@ -33,7 +29,6 @@ constexpr int SGV_GN_MAX_GROUPS = 32;
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s);
 // whole GroupNorm passes: one fused launch when a (sample, group) slab is small, else the multi-kernel path
 int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s);   // stats (p.sums zeroed by the caller) + apply
-bool ew_gn_fwd_is_fused(const GNParams& p);                     // true: one launch, and p.part_in (split-K slabs) is accepted
 int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s);   // reduce + finalize + dY; act in {0, 1 gelu, 3 relu}
 int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // act: 0 none, 1 gelu, 3 relu
 int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
