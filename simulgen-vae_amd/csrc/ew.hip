@@ -758,8 +758,8 @@ static void gn_finalize(GNParams p, hipStream_t s) {
     hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv_i(p.C, 256), p.B), dim3(256), 0, s, p, g_.rowsplit);
 }
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
-    if (dtype == 1) GN_LAUNCH((gn_stats_kernel<bf16_t>), p, s);
-    else GN_LAUNCH((gn_stats_kernel<float>), p, s);
+    if (dtype == 1) GN_LAUNCH_R((gn_stats_kernel<bf16_t>), p, s);
+    else GN_LAUNCH_R((gn_stats_kernel<float>), p, s);
     return 0;
 }
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s) {
