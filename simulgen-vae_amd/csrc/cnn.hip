@@ -113,6 +113,70 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, unsi
         if (idx) idx[i] = (unsigned char)((bh - (oh * 2 - 1)) * 3 + (bw - (ow * 2 - 1)));      // window position of the arg-max
     }
 }
+// 8 channels per lane (C % 8 == 0): same results, 16-byte loads / stores and one 8-byte arg-max store per lane
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const T* x, T* y, unsigned char* idx, ConvGeom g) {
+    const int cv = g.C / 8;
+    const long total = (long)g.B * g.Ho * g.Wo * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * 8;
+        const long m = i / cv;
+        const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+        float best[8]; int pos[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; pos[e] = -1; }
+#pragma unroll
+        for (int kh = 0; kh < 3; ++kh) {
+            const int h = oh * 2 - 1 + kh;
+            if ((unsigned)h >= (unsigned)g.H) continue;
+#pragma unroll
+            for (int kw = 0; kw < 3; ++kw) {
+                const int w = ow * 2 - 1 + kw;
+                if ((unsigned)w >= (unsigned)g.W) continue;
+                float v[8];
+                load8(x + (((long)b * g.H + h) * g.W + w) * g.C + c0, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (v[e] > best[e] || pos[e] < 0) { best[e] = v[e]; pos[e] = kh * 3 + kw; }
+            }
+        }
+        store8(y + m * g.C + c0, best);
+        if (idx) {
+            unsigned long long pk = 0;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pk |= (unsigned long long)(unsigned char)pos[e] << (8 * e);
+            *reinterpret_cast<unsigned long long*>(idx + m * g.C + c0) = pk;
+        }
+    }
+}
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_vec_kernel(const unsigned char* idx, const T* dy, T* dx, ConvGeom g) {
+    const int cv = g.C / 8;
+    const long total = (long)g.B * g.H * g.W * cv;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * 8;
+        const long pix = i / cv;
+        const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int oh = (h + 1) / 2 - ((h + 1) % 2 == 0 ? 1 : 0); oh <= (h + 1) / 2; ++oh) {
+            if (oh < 0 || oh >= g.Ho) continue;
+            for (int ow = (w + 1) / 2 - ((w + 1) % 2 == 0 ? 1 : 0); ow <= (w + 1) / 2; ++ow) {
+                if (ow < 0 || ow >= g.Wo) continue;
+                const long o = (((long)b * g.Ho + oh) * g.Wo + ow) * g.C + c0;
+                const unsigned long long pk = *reinterpret_cast<const unsigned long long*>(idx + o);
+                const int want = (h - (oh * 2 - 1)) * 3 + (w - (ow * 2 - 1));
+                float d[8];
+                load8(dy + o, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if ((int)((pk >> (8 * e)) & 0xFF) == want) acc[e] += d[e];
+            }
+        }
+        store8(dx + pix * g.C + c0, acc);
+    }
+}
 // gather: an input pixel receives dy of every window whose stored arg-max points at it
 template <typename T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* idx, const T* dy, T* dx, ConvGeom g) {
@@ -138,20 +202,26 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const unsigned char* i
 // elementwise / per-channel helpers on [B][P][C] maps (P = H*W)
 // ------------------------------------------------------------------------------------------------------------
 // out = relu(a + b) ; backward: d = dout * (out > 0)
-template <typename T>
-__global__ __launch_bounds__(256) void add_relu_fwd_kernel(const T* a, const T* b, T* out, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        out[i] = from_f32<T>(fmaxf(to_f32(a[i]) + to_f32(b[i]), 0.f));
+// Flat element-wise passes on feature maps: 8 elements per lane (16-byte accesses for bf16) when the length and the
+// pointers allow it (n8 = n / 8 vectors), scalar otherwise.  MODE 0: relu(a + b); 1: relu backward (a = output, b = dout);
+// 2: a + b
+template <typename T, int MODE>
+__global__ __launch_bounds__(256) void ew2_kernel(const T* a, const T* b, T* out, long n, long n8) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        float x[8], y[8];
+        load8(a + i * 8, x);
+        load8(b + i * 8, y);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = MODE == 0 ? fmaxf(x[e] + y[e], 0.f) : (MODE == 1 ? (x[e] > 0.f ? y[e] : 0.f) : x[e] + y[e]);
+        store8(out + i * 8, x);
+    }
+    for (long i = n8 * 8 + (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+        const float x = to_f32(a[i]), y = to_f32(b[i]);
+        out[i] = from_f32<T>(MODE == 0 ? fmaxf(x + y, 0.f) : (MODE == 1 ? (x > 0.f ? y : 0.f) : x + y));
+    }
 }
-template <typename T>
-__global__ __launch_bounds__(256) void relu_bwd_kernel(const T* out, const T* dout, T* d, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        d[i] = to_f32(out[i]) > 0.f ? dout[i] : from_f32<T>(0.f);
-}
-template <typename T>
-__global__ __launch_bounds__(256) void add_kernel(const T* a, const T* b, T* out, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
-        out[i] = from_f32<T>(to_f32(a[i]) + to_f32(b[i]));
+static inline long vec8_count(long n, const void* a, const void* b, const void* c) {
+    return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 31) == 0) ? n / 8 : 0;      // 32-byte alignment covers fp32 too
 }
 // y[b][c] += (1/P) sum_{p in chunk} x[b][p][c]   (grid (C/64, B, chunks); 64 channels x 4 row lanes; y zeroed by the launcher)
 template <typename T>
@@ -167,6 +237,20 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, float* y, 
 }
 // dx[b][p][c] (+)= dy[b][c] / P
 template <typename T>
+__global__ __launch_bounds__(256) void avgpool_bwd_vec_kernel(const float* dy, T* dx, int P, int C, long n8, int accumulate) {
+    const int cv = C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * 8;
+        const int b = (int)(i / ((long)P * cv));
+        float v[8], o[8];
+        load8(dy + (long)b * C + c0, v);
+        if (accumulate) load8(dx + i * 8, o);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = accumulate ? o[e] + v[e] / (float)P : v[e] / (float)P;
+        store8(dx + i * 8, v);
+    }
+}
+template <typename T>
 __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* dy, T* dx, int P, int C, long n, int accumulate) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const int c = (int)(i % C);
@@ -176,6 +260,20 @@ __global__ __launch_bounds__(256) void avgpool_bwd_kernel(const float* dy, T* dx
     }
 }
 // out[b][p][c] = x[b][p][c] * s[b][c]
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scale_fwd_vec_kernel(const T* x, const float* s, T* out, int P, int C, long n8) {
+    const int cv = C / 8;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long)gridDim.x * 256) {
+        const int c0 = (int)(i % cv) * 8;
+        const int b = (int)(i / ((long)P * cv));
+        float v[8], sc[8];
+        load8(x + i * 8, v);
+        load8(s + (long)b * C + c0, sc);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] *= sc[e];
+        store8(out + i * 8, v);
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void chan_scale_fwd_kernel(const T* x, const float* s, T* out, int P, int C, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
@@ -232,18 +330,32 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const floa
 }
 // dx[b][k] = scale * sum_o dz[b][o] W[o][k]; grid (ceil(K/64), B): 64 columns x 4 row lanes per block
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* dz, const float* W, const float* scale, float* dx, int K, int O,
-                                                           int accumulate) {
+                                                           int B, int ochunk) {
+    // block = 64 columns k x 8 batch rows x one chunk of outputs: every W element is read once per 8 rows, the chunks run
+    // in parallel and meet in dx through float atomics (dx holds zeros or the value to accumulate onto)
+    constexpr int BG = 8;
     const int kl = threadIdx.x & 63, ol = threadIdx.x >> 6;
-    const int k = blockIdx.x * 64 + kl, b = blockIdx.y;
-    float a = 0.f;
+    const int k = blockIdx.x * 64 + kl, b0 = blockIdx.y * BG;
+    const int o_lo = blockIdx.z * ochunk, o_hi = min(O, o_lo + ochunk);
+    float a[BG];
+#pragma unroll
+    for (int j = 0; j < BG; ++j) a[j] = 0.f;
     if (k < K)
-        for (int o = ol; o < O; o += 4) a += dz[(long)b * O + o] * W[(long)o * K + k];
-    __shared__ float sm[4][64];
-    sm[ol][kl] = a;
+        for (int o = o_lo + ol; o < o_hi; o += 4) {
+            const float w = W[(long)o * K + k];
+#pragma unroll
+            for (int j = 0; j < BG; ++j)
+                if (b0 + j < B) a[j] += dz[(long)(b0 + j) * O + o] * w;
+        }
+    __shared__ float sm[4][BG][64];
+#pragma unroll
+    for (int j = 0; j < BG; ++j) sm[ol][j][kl] = a[j];
     __syncthreads();
     if (ol == 0 && k < K) {
-        a = (sm[0][kl] + sm[1][kl] + sm[2][kl] + sm[3][kl]) * (scale ? *scale : 1.f);
-        dx[(long)b * K + k] = accumulate ? dx[(long)b * K + k] + a : a;
+        const float sc = scale ? *scale : 1.f;
+#pragma unroll
+        for (int j = 0; j < BG; ++j)
+            if (b0 + j < B) atomicAdd(dx + (long)(b0 + j) * K + k, (sm[0][j][kl] + sm[1][j][kl] + sm[2][j][kl] + sm[3][j][kl]) * sc);
     }
 }
 // dW[o][k] = scale * sum_b dz[b][o] x[b][k]; db[o] = sum_b dz[b][o]; grid (ceil(K/256), O)
@@ -573,28 +685,39 @@ int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, in
 int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, void* stream) {
     OPCHK(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_fwd: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
+    if (C % 8 == 0 && vec8_count(8, x, y, argmax)) {
+        ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_vec_kernel<T>, grid1((long)B * g.Ho * g.Wo * (C / 8)), dim3(256), 0, ST(stream), CPT(x), PT(y), argmax, g));
+        return OPLAUNCH_OK();
+    }
     ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, grid1((long)B * g.Ho * g.Wo * C), dim3(256), 0, ST(stream), CPT(x), PT(y), argmax, g));
     return OPLAUNCH_OK();
 }
 int sgv_op_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
     OPCHK(argmax && dy && dx && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_bwd: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
+    if (C % 8 == 0 && vec8_count(8, argmax, dy, dx)) {
+        ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_vec_kernel<T>, grid1((long)B * H * W * (C / 8)), dim3(256), 0, ST(stream), argmax, CPT(dy), PT(dx), g));
+        return OPLAUNCH_OK();
+    }
     ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_bwd_kernel<T>, grid1((long)B * H * W * C), dim3(256), 0, ST(stream), argmax, CPT(dy), PT(dx), g));
     return OPLAUNCH_OK();
 }
 int sgv_op_add_relu_fwd(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
     OPCHK(a && b && out && n > 0, "sgv_op_add_relu_fwd: bad argument");
-    ON_DTYPE(dtype, hipLaunchKernelGGL(add_relu_fwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(a), CPT(b), PT(out), n));
+    const long n8 = vec8_count(n, a, b, out);
+    ON_DTYPE(dtype, hipLaunchKernelGGL((ew2_kernel<T, 0>), grid1(n8 ? n8 : n), dim3(256), 0, ST(stream), CPT(a), CPT(b), PT(out), n, n8));
     return OPLAUNCH_OK();
 }
 int sgv_op_relu_bwd(int dtype, const void* out, const void* dout, void* d, long n, void* stream) {
     OPCHK(out && dout && d && n > 0, "sgv_op_relu_bwd: bad argument");
-    ON_DTYPE(dtype, hipLaunchKernelGGL(relu_bwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(out), CPT(dout), PT(d), n));
+    const long n8 = vec8_count(n, out, dout, d);
+    ON_DTYPE(dtype, hipLaunchKernelGGL((ew2_kernel<T, 1>), grid1(n8 ? n8 : n), dim3(256), 0, ST(stream), CPT(out), CPT(dout), PT(d), n, n8));
     return OPLAUNCH_OK();
 }
 int sgv_op_add(int dtype, const void* a, const void* b, void* out, long n, void* stream) {
     OPCHK(a && b && out && n > 0, "sgv_op_add: bad argument");
-    ON_DTYPE(dtype, hipLaunchKernelGGL(add_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(a), CPT(b), PT(out), n));
+    const long n8 = vec8_count(n, a, b, out);
+    ON_DTYPE(dtype, hipLaunchKernelGGL((ew2_kernel<T, 2>), grid1(n8 ? n8 : n), dim3(256), 0, ST(stream), CPT(a), CPT(b), PT(out), n, n8));
     return OPLAUNCH_OK();
 }
 int sgv_op_avgpool_fwd(int dtype, const void* x, float* y, int B, int P, int C, void* stream) {
@@ -607,12 +730,20 @@ int sgv_op_avgpool_fwd(int dtype, const void* x, float* y, int B, int P, int C, 
 int sgv_op_avgpool_bwd(int dtype, const float* dy, void* dx, int B, int P, int C, int accumulate, void* stream) {
     OPCHK(dy && dx && B > 0 && P > 0 && C > 0, "sgv_op_avgpool_bwd: bad argument");
     const long n = (long)B * P * C;
+    if (C % 8 == 0 && vec8_count(n, dy, dx, dx)) {
+        ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_bwd_vec_kernel<T>, grid1(n / 8), dim3(256), 0, ST(stream), dy, PT(dx), P, C, n / 8, accumulate));
+        return OPLAUNCH_OK();
+    }
     ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_bwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), dy, PT(dx), P, C, n, accumulate));
     return OPLAUNCH_OK();
 }
 int sgv_op_chan_scale_fwd(int dtype, const void* x, const float* s, void* out, int B, int P, int C, void* stream) {
     OPCHK(x && s && out && B > 0 && P > 0 && C > 0, "sgv_op_chan_scale_fwd: bad argument");
     const long n = (long)B * P * C;
+    if (C % 8 == 0 && vec8_count(n, x, s, out)) {
+        ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_fwd_vec_kernel<T>, grid1(n / 8), dim3(256), 0, ST(stream), CPT(x), s, PT(out), P, C, n / 8));
+        return OPLAUNCH_OK();
+    }
     ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_fwd_kernel<T>, grid1(n), dim3(256), 0, ST(stream), CPT(x), s, PT(out), P, C, n));
     return OPLAUNCH_OK();
 }
@@ -669,7 +800,16 @@ int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, 
 int sgv_op_linear_bwd(const float* dz, const float* x, const float* W, const float* scale, float* dx, int accumulate_dx, float* dW, float* db,
                       int B, int K, int O, void* stream) {
     OPCHK(dz && x && W && dW && B > 0 && K > 0 && O > 0, "sgv_op_linear_bwd: bad argument");
-    if (dx) hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(cdivi(K, 64), B), dim3(256), 0, ST(stream), dz, W, scale, dx, K, O, accumulate_dx);
+    if (dx) {
+        if (!accumulate_dx && hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * K, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
+        // enough output chunks for ~1000 blocks, at least 32 outputs each
+        const int kb = cdivi(K, 64), bb = cdivi(B, 8);
+        int chunks = cdivi(1024, kb * bb);
+        if (chunks > cdivi(O, 32)) chunks = cdivi(O, 32);
+        if (chunks < 1) chunks = 1;
+        const int ochunk = cdivi(cdivi(O, chunks), 4) * 4;
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(kb, bb, cdivi(O, ochunk)), dim3(256), 0, ST(stream), dz, W, scale, dx, K, O, B, ochunk);
+    }
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdivi(K, 256), O), dim3(256), 0, ST(stream), dz, x, scale, dW, db, B, K, O);
     return OPLAUNCH_OK();
 }
