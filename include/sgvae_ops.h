@@ -84,6 +84,9 @@ int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* 
  * gradient -- the reference detaches this term through numpy) of kind 0 nn.MSELoss, 1 nn.L1Loss, 2 nn.HuberLoss(delta),
  * 3 nn.SmoothL1Loss(beta = delta) between two fp32 arrays; and sklearn MinMaxScaler.inverse_transform on a
  * [rows][cols] fp32 array, y = (x - min_[c]) / scale_[c]. */
+/* Host-model plumbing: table_dev = n_rows x {const float* src, float* dst, int64 count} on the device; copies every row
+ * (one launch for all parameter gradients of a step). */
+int sgv_op_multi_copy(const void* table_dev, int n_rows, void* stream);
 int sgv_op_loss_value(int kind, const float* a, const float* b, double* loss_dev, float delta, long n, void* stream);
 int sgv_op_cols_sub_div(const float* x, const float* col_min, const float* col_scale, float* y, long rows, int cols, void* stream);
 /* Input augmentation of the training loop (latent_conditioner.py:107-159,261-279) on [B][H][W] fp32 images, random

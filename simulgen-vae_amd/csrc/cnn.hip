@@ -899,11 +899,20 @@ int sgv_op_gemm_tn_splitk(int dtype, int M, int N1, int N2) {
     if (sk > 256) sk = 256;
     return sk < 1 ? 1 : (int)sk;
 }
+// out[i] = sum_z slabs[z][i]; the conditioner's weight gradients are small matrices cut into up to 256 slabs, so a block
+// takes 64 elements x 4 slab lanes (4 independent chains per element instead of one long one)
 __global__ __launch_bounds__(256) void op_sum_slabs_kernel(float* out, const float* slabs, int splitk, long n) {
-    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    __shared__ float sm[4][64];
+    const int el = threadIdx.x & 63, zl = threadIdx.x >> 6;
+    for (long i0 = (long)blockIdx.x * 64; i0 < n; i0 += (long)gridDim.x * 64) {
+        const long i = i0 + el;
         float v = 0.f;
-        for (int z = 0; z < splitk; ++z) v += slabs[(long)z * n + i];
-        out[i] = v;
+        if (i < n)
+            for (int z = zl; z < splitk; z += 4) v += slabs[(long)z * n + i];
+        sm[zl][el] = v;
+        __syncthreads();
+        if (zl == 0 && i < n) out[i] = sm[0][el] + sm[1][el] + sm[2][el] + sm[3][el];
+        __syncthreads();
     }
 }
 int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, float* slabs, int splitk, void* stream) {
@@ -918,7 +927,23 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
     const int r = launch_gemm_tn(dtype, p, ST(stream));
     if (r) return sgv_set_error(-1, "sgv_op_gemm_tn: launch rejected (%d) for M=%d N1=%d N2=%d", r, M, N1, N2);
     if (p.splitk > 1)
-        hipLaunchKernelGGL(op_sum_slabs_kernel, grid1((long)N1 * N2), dim3(256), 0, ST(stream), dW, slabs, p.splitk, (long)N1 * N2);
+        hipLaunchKernelGGL(op_sum_slabs_kernel, grid1((long)N1 * N2 * 4), dim3(256), 0, ST(stream), dW, slabs, p.splitk, (long)N1 * N2);
+    return OPLAUNCH_OK();
+}
+// dst_k[0..count_k) = src_k[0..count_k) for every row k of a device table {src, dst, count} (fp32 tensors): the host model
+// files ~110 freshly computed gradients into its flat arena with one launch instead of one copy each
+struct CopyRow { const float* src; float* dst; long count; };
+__global__ __launch_bounds__(256) void multi_copy_kernel(const CopyRow* rows) {
+    const CopyRow r = rows[blockIdx.y];
+    const bool vec = ((((uintptr_t)r.src) | ((uintptr_t)r.dst)) & 15) == 0;
+    const long n4 = vec ? r.count >> 2 : 0;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256)
+        reinterpret_cast<float4*>(r.dst)[i] = reinterpret_cast<const float4*>(r.src)[i];
+    for (long i = n4 * 4 + (long)blockIdx.x * 256 + threadIdx.x; i < r.count; i += (long)gridDim.x * 256) r.dst[i] = r.src[i];
+}
+int sgv_op_multi_copy(const void* table_dev, int n_rows, void* stream) {
+    OPCHK(table_dev && n_rows > 0, "sgv_op_multi_copy: bad argument");
+    hipLaunchKernelGGL(multi_copy_kernel, dim3(64, n_rows), dim3(256), 0, ST(stream), reinterpret_cast<const CopyRow*>(table_dev));
     return OPLAUNCH_OK();
 }
 // ---- input augmentation ------------------------------------------------------------------------------------

@@ -164,7 +164,7 @@ class LatentConditionerImg:
     def __getstate__(self):
         d = dict(self.__dict__)
         d["P"] = {k: v.detach().cpu().numpy() for k, v in self.P.items()}
-        d["grads"], d["_tape"], d["pset"] = {}, None, None
+        d["grads"], d["_tape"], d["pset"], d["_pending"] = {}, None, None, None
         d.pop("G", None)
         d.pop("_entry", None)
         return d
@@ -256,7 +256,10 @@ class LatentConditionerImg:
     # ---- layer helpers: each returns (output, backward closure) ---------------------------------------------------
     def _acc(self, name, g):
         if self._fused():
-            self.G[name].copy_(g.view(self.G[name].shape))        # fixed buffer the multi-tensor step reads
+            # fixed buffer the multi-tensor step reads: filed by ONE copy launch at the end of backward (_flush_grads)
+            if getattr(self, "_pending", None) is None:
+                self._pending = []
+            self._pending.append((g.contiguous(), self.G[name]))
             self.grads[name] = self.G[name]
         else:
             self.grads[name] = g if name not in self.grads else ops.addf(self.grads[name], g)
@@ -488,7 +491,13 @@ class LatentConditionerImg:
             raise SgvError("backward() needs a preceding forward()")
         g = self._tape(d_main, d_xs)
         self._tape = None
+        self._flush_grads()
         return g
+
+    def _flush_grads(self):
+        if getattr(self, "_pending", None):
+            ops.multi_copy(self._pending)
+            self._pending = []
 
     def loss_backward(self, x, y1, y2, dropout_masks=None, w1=10.0, w2=1.0, preds=None):
         """latent_conditioner.py:285-301: forward, A = MSE(y_pred1, y1), B = MSE(y_pred2, y2), loss = w1*A + w2*B

@@ -17,7 +17,7 @@ OPS_SYMBOLS = [
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
     "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
-    "sgv_op_mse", "sgv_op_loss_value", "sgv_op_cols_sub_div", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
+    "sgv_op_mse", "sgv_op_loss_value", "sgv_op_cols_sub_div", "sgv_op_multi_copy", "sgv_op_transpose", "sgv_op_l2_normalize", "sgv_op_dot", "sgv_op_sn_grad", "sgv_op_conv_weight_pack",
     "sgv_op_conv_weight_unpack", "sgv_op_sumsq", "sgv_op_clip_coef", "sgv_op_adamw", "sgv_op_flip_roll", "sgv_op_affine_sample",
     "sgv_op_mixup_rows", "sgv_pset_create", "sgv_pset_destroy", "sgv_pset_power_iteration", "sgv_pset_sigma", "sgv_pset_step",
 ]
@@ -64,6 +64,7 @@ def lib():
             "sgv_op_addf": [vp, vp, vp, lg, vp],
             "sgv_op_mse": [vp, vp, vp, vp, f, lg, vp],
             "sgv_op_loss_value": [i, vp, vp, vp, f, lg, vp],
+            "sgv_op_multi_copy": [vp, i, vp],
             "sgv_op_cols_sub_div": [vp, vp, vp, vp, lg, i, vp],
             "sgv_op_transpose": [i, i, vp, vp, i, i, i, vp],
             "sgv_op_l2_normalize": [vp, vp, lg, f, vp],
@@ -341,6 +342,17 @@ def cols_sub_div(x, col_min, col_scale):
     y = torch.empty_like(x)
     _ck(lib().sgv_op_cols_sub_div(_p(x), _p(col_min), _p(col_scale), _p(y), x.shape[0], x.shape[1], _stream()), "sgv_op_cols_sub_div")
     return y
+
+
+def multi_copy(pairs):
+    """pairs: [(src fp32 CUDA tensor, dst fp32 CUDA view of the same numel)]: one launch for all of them."""
+    import numpy as np
+    tab = np.empty((len(pairs), 3), np.int64)
+    for k, (src, dst) in enumerate(pairs):
+        tab[k] = (src.data_ptr(), dst.data_ptr(), src.numel())
+    dev = torch.from_numpy(tab).cuda()
+    _ck(lib().sgv_op_multi_copy(_p(dev), len(pairs), _stream()), "sgv_op_multi_copy")
+    return dev          # keep alive until the launch is enqueued (stream-ordered allocator)
 
 
 def transpose(src, dst_dtype, Bn, I, J):
