@@ -52,6 +52,65 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeo
         while (ow >= g.Wo) { ow -= g.Wo; if (++oh == g.Ho) { oh = 0; ++b; } }
     }
 }
+// C % 8 == 0 (every layer but the 1-channel stem): a lane moves 8 channels (16 bytes for bf16) of one tap; same walk as above
+// with kw_ = min(Kp / 8, 256) vector lanes
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_vec_kernel(const T* x, T* col, ConvGeom g, int kw_) {
+    const int kl = threadIdx.x % kw_, rl = threadIdx.x / kw_, rows_pb = 256 / kw_;
+    const int kv = blockIdx.y * kw_ + kl;
+    if (kv * 8 >= g.Kp || rl >= rows_pb) return;
+    const int k = kv * 8;
+    const bool live = k < g.KH * g.KW * g.C;
+    const int c = live ? k % g.C : 0, t = live ? k / g.C : 0, kw = t % g.KW, kh = t / g.KW;
+    const long M = (long)g.B * g.Ho * g.Wo;
+    long m = (long)blockIdx.x * 32 * rows_pb + rl;
+    if (m >= M) return;
+    int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+    for (int pass = 0; pass < 32 && m < M; ++pass, m += rows_pb) {
+        Raw8<T> v;
+        raw_zero(v);
+        if (live) {
+            const int h = oh * g.S - g.P + kh, w = ow * g.S - g.P + kw;
+            if ((unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) raw_load(x + (((long)b * g.H + h) * g.W + w) * g.C + c, v);
+        }
+        raw_store(col + m * g.Kp + k, v);
+        ow += rows_pb;
+        while (ow >= g.Wo) { ow -= g.Wo; if (++oh == g.Ho) { oh = 0; ++b; } }
+    }
+}
+// gather form of col2im with 8 channels per lane: cw_ = min(C / 8, 256) vector lanes
+template <typename T>
+__global__ __launch_bounds__(256) void col2im_vec_kernel(const T* dcol, T* dx, ConvGeom g, int cw_) {
+    const int cl = threadIdx.x % cw_, pl = threadIdx.x / cw_, pix_pb = 256 / cw_;
+    const int c = (blockIdx.y * cw_ + cl) * 8;
+    if (c >= g.C || pl >= pix_pb) return;
+    const long NP = (long)g.B * g.H * g.W;
+    for (int pass = 0; pass < 4; ++pass) {
+        const long pix = ((long)blockIdx.x * 4 + pass) * pix_pb + pl;
+        if (pix >= NP) return;
+        const int w = (int)(pix % g.W), h = (int)((pix / g.W) % g.H), b = (int)(pix / ((long)g.W * g.H));
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        for (int kh = 0; kh < g.KH; ++kh) {
+            const int hn = h + g.P - kh;
+            if (hn < 0 || hn % g.S) continue;
+            const int oh = hn / g.S;
+            if (oh >= g.Ho) continue;
+            for (int kw = 0; kw < g.KW; ++kw) {
+                const int wn = w + g.P - kw;
+                if (wn < 0 || wn % g.S) continue;
+                const int ow = wn / g.S;
+                if (ow >= g.Wo) continue;
+                float v[8];
+                load8(dcol + (((long)b * g.Ho + oh) * g.Wo + ow) * g.Kp + (kh * g.KW + kw) * g.C + c, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += v[e];
+            }
+        }
+        store8(dx + pix * g.C + c, acc);
+    }
+}
 // dx[b][h][w][c] = sum over the windows that cover (h,w) of dcol (gather form: no atomics, deterministic);
 // thread = (pixel lane, channel lane) with cw_ = min(C, 256) channel lanes
 template <typename T>
@@ -670,6 +729,11 @@ int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int 
     OPCHK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && KH > 0 && KW > 0, "sgv_op_im2col: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
     const long Mrows = (long)B * g.Ho * g.Wo;
+    if (C % 8 == 0 && g.Kp % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)col)) & 31) == 0) {
+        const int kv = g.Kp / 8, kwv = kv < 256 ? kv : 256, rpb = 256 / kwv;
+        ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_vec_kernel<T>, dim3((unsigned)((Mrows + 32L * rpb - 1) / (32L * rpb)), cdivi(kv, kwv)), dim3(256), 0, ST(stream), CPT(x), PT(col), g, kwv));
+        return OPLAUNCH_OK();
+    }
     const int kw_ = g.Kp < 256 ? g.Kp : 256, rows_pb = 256 / kw_;
     ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_kernel<T>, dim3((unsigned)((Mrows + 32L * rows_pb - 1) / (32L * rows_pb)), cdivi(g.Kp, kw_)), dim3(256), 0, ST(stream), CPT(x), PT(col), g, kw_));
     return OPLAUNCH_OK();
@@ -678,6 +742,11 @@ int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, in
     OPCHK(dcol && dx && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0, "sgv_op_col2im: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
     const long NPix = (long)B * H * W;
+    if (C % 8 == 0 && g.Kp % 8 == 0 && ((((uintptr_t)dcol) | ((uintptr_t)dx)) & 31) == 0) {
+        const int cv = C / 8, cwv = cv < 256 ? cv : 256, ppb = 256 / cwv;
+        ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_vec_kernel<T>, dim3((unsigned)((NPix + 4L * ppb - 1) / (4L * ppb)), cdivi(cv, cwv)), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g, cwv));
+        return OPLAUNCH_OK();
+    }
     const int cw_ = C < 256 ? C : 256, pix_pb = 256 / cw_;
     ON_DTYPE(dtype, hipLaunchKernelGGL(col2im_kernel<T>, dim3((unsigned)((NPix + 4L * pix_pb - 1) / (4L * pix_pb)), cdivi(C, cw_)), dim3(256), 0, ST(stream), CPT(dcol), PT(dx), g, cw_));
     return OPLAUNCH_OK();

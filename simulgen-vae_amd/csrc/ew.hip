@@ -437,20 +437,6 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
 // ty = row lane.  Results match the multi-kernel path up to summation order (float partials per thread, fp64 across).
 // ------------------------------------------------------------------------------------------
 constexpr int GN_FUSED_ITERS = 16;
-template <typename T> struct Raw8;
-template <> struct Raw8<bf16_t> { bf16x8 v; };
-template <> struct Raw8<float> { float4 a, b; };
-__device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.v = *reinterpret_cast<const bf16x8*>(p); }
-__device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
-    r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
-}
-__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float v[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
-}
-__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float v[8]) {
-    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
-}
 struct GNSlab {
     int g, b, nv, CVg, RL, tx, ty, c0;
     bool col_ok;

@@ -44,6 +44,31 @@ __device__ __forceinline__ void store8(bf16_t* p, const float v[8]) {
     *reinterpret_cast<bf16x8*>(p) = a;
 }
 
+// 8 consecutive elements as loaded (16 B of bf16 / 32 B of fp32): lets a thread issue several loads before unpacking any
+template <typename T> struct Raw8;
+template <> struct Raw8<bf16_t> { bf16x8 v; };
+template <> struct Raw8<float> { float4 a, b; };
+__device__ __forceinline__ void raw_load(const bf16_t* p, Raw8<bf16_t>& r) { r.v = *reinterpret_cast<const bf16x8*>(p); }
+__device__ __forceinline__ void raw_load(const float* p, Raw8<float>& r) {
+    r.a = *reinterpret_cast<const float4*>(p); r.b = *reinterpret_cast<const float4*>(p + 4);
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<bf16_t>& r, float v[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = (float)r.v[i];
+}
+__device__ __forceinline__ void raw_unpack(const Raw8<float>& r, float v[8]) {
+    v[0] = r.a.x; v[1] = r.a.y; v[2] = r.a.z; v[3] = r.a.w; v[4] = r.b.x; v[5] = r.b.y; v[6] = r.b.z; v[7] = r.b.w;
+}
+__device__ __forceinline__ void raw_zero(Raw8<bf16_t>& r) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r.v[i] = (bf16_t)0.f;
+}
+__device__ __forceinline__ void raw_zero(Raw8<float>& r) { r.a = make_float4(0.f, 0.f, 0.f, 0.f); r.b = r.a; }
+__device__ __forceinline__ void raw_store(bf16_t* p, const Raw8<bf16_t>& r) { *reinterpret_cast<bf16x8*>(p) = r.v; }
+__device__ __forceinline__ void raw_store(float* p, const Raw8<float>& r) {
+    *reinterpret_cast<float4*>(p) = r.a; *reinterpret_cast<float4*>(p + 4) = r.b;
+}
+
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
