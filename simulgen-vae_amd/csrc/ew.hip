@@ -186,11 +186,21 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
     for (int e = 0; e < 8; ++e) { a[e] = 0.f; s[e] = 0.f; w[e] = 1.f; }
     if (c.col_ok) {
         const T* y = reinterpret_cast<const T*>(p.y);
-        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
+        // two rows per round, both loads issued before the first use (streaming pass: latency, not VALU, limits it)
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += 2 * c.RL) {
+            const bool two = t + c.RL < c.t_hi;
+            Raw8<T> r0, r1;
+            raw_load(y + ((long)c.b * p.T + t) * p.ldy + c.c0, r0);
+            raw_load(y + ((long)c.b * p.T + (two ? t + c.RL : t)) * p.ldy + c.c0, r1);
             float v[8];
-            load8(y + ((long)c.b * p.T + t) * p.ldy + c.c0, v);
+            raw_unpack(r0, v);
 #pragma unroll
             for (int e = 0; e < 8; ++e) { a[e] += v[e]; s[e] += v[e] * v[e]; }
+            if (two) {
+                raw_unpack(r1, v);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { a[e] += v[e]; s[e] += v[e] * v[e]; }
+            }
         }
     }
     gn_block_reduce(p, c, a, s, w, nullptr, nullptr, p.sums);
@@ -216,17 +226,26 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     const T* y = reinterpret_cast<const T*>(p.y);
     const T* res = reinterpret_cast<const T*>(p.res);
     T* out = reinterpret_cast<T*>(p.out);
-    for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
-        const long m = (long)c.b * p.T + t;
-        float v[8], r[8];
-        load8(y + m * p.ldy + c.c0, v);
-        if (res) load8(res + m * p.ldres + c.c0, r);
+    for (int t = c.t_lo + c.ty; t < c.t_hi; t += 2 * c.RL) {      // two rows per round, loads first
+        const bool two = t + c.RL < c.t_hi;
+        const long m0 = (long)c.b * p.T + t, m1 = two ? m0 + c.RL : m0;
+        Raw8<T> ry0, ry1, rr0, rr1;
+        raw_load(y + m0 * p.ldy + c.c0, ry0);
+        raw_load(y + m1 * p.ldy + c.c0, ry1);
+        if (res) { raw_load(res + m0 * p.ldres + c.c0, rr0); raw_load(res + m1 * p.ldres + c.c0, rr1); }
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const float f = act_apply(ACT, v[e] * ka[e] + kb[e]);
-            v[e] = res ? r[e] + p.rscale * f : f;
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            float v[8], r[8];
+            raw_unpack(u ? ry1 : ry0, v);
+            if (res) raw_unpack(u ? rr1 : rr0, r);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float f = act_apply(ACT, v[e] * ka[e] + kb[e]);
+                v[e] = res ? r[e] + p.rscale * f : f;
+            }
+            store8(out + (u ? m1 : m0) * p.ldout + c.c0, v);
         }
-        store8(out + m * p.ldout + c.c0, v);
     }
 }
 
@@ -402,27 +421,37 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
         const T* y = reinterpret_cast<const T*>(p.y);
         const T* dout = reinterpret_cast<const T*>(p.dout);
         T* dy = reinterpret_cast<T*>(p.out);
-        for (int t = c.t_lo + c.ty; t < c.t_hi; t += c.RL) {
-            const long m = (long)c.b * p.T + t;
-            float v[8], d[8];
-            load8(y + m * p.ldy + c.c0, v);
-            load8(dout + m * p.lddout + c.c0, d);
+        for (int t = c.t_lo + c.ty; t < c.t_hi; t += 2 * c.RL) {      // two rows per round, all four loads first
+            const bool two = t + c.RL < c.t_hi;
+            const long r0 = (long)c.b * p.T + t, r1 = two ? r0 + c.RL : r0;
+            Raw8<T> ry0, ry1, rd0, rd1;
+            raw_load(y + r0 * p.ldy + c.c0, ry0);
+            raw_load(dout + r0 * p.lddout + c.c0, rd0);
+            raw_load(y + r1 * p.ldy + c.c0, ry1);
+            raw_load(dout + r1 * p.lddout + c.c0, rd1);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const float xh = (v[e] - mean[e]) * rstd[e];
-                const float z = xh * gam[e] + bet[e];
-                float dz;
-                if constexpr (FROM_LOSS) {
-                    const float o = tanh_f(z);
-                    dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
-                } else {
-                    dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
+            for (int u = 0; u < 2; ++u) {
+                if (u == 1 && !two) break;
+                float v[8], d[8];
+                raw_unpack(u ? ry1 : ry0, v);
+                raw_unpack(u ? rd1 : rd0, d);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float xh = (v[e] - mean[e]) * rstd[e];
+                    const float z = xh * gam[e] + bet[e];
+                    float dz;
+                    if constexpr (FROM_LOSS) {
+                        const float o = tanh_f(z);
+                        dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
+                    } else {
+                        dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
+                    }
+                    const float r = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
+                    dotacc += r * (v[e] - cb[e]);          // dY * (conv output without bias) -> <G, W_eff>
+                    v[e] = r;
                 }
-                const float r = rstd[e] * (gam[e] * dz - m1[e] - xh * m2[e]) * p.gscale;
-                dotacc += r * (v[e] - cb[e]);          // dY * (conv output without bias) -> <G, W_eff>
-                v[e] = r;
+                store8(dy + (u ? r1 : r0) * p.ldout + c.c0, v);
             }
-            store8(dy + m * p.ldout + c.c0, v);
         }
     }
     if (p.cdot) block_atomic_add(dotacc, p.cdot);
