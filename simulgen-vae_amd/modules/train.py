@@ -59,21 +59,39 @@ class _DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
 
 
+class _SumThenScale:
+    """Work handle for backends without ReduceOp.AVG (gloo): SUM, then 1/world on the consumer's stream after the wait."""
+
+    def __init__(self, work, seg, inv):
+        self.work, self.seg, self.inv = work, seg, inv
+
+    def wait(self):
+        self.work.wait()
+        self.seg.mul_(self.inv)
+
+
 class GradAllReduce:
     """Bucketed mean all-reduce of the engine's flat gradient arena over RCCL, overlapped with backward (the
     engine calls `_on_bucket` as soon as the kernels producing a bucket are enqueued) and with AdamW (`step`
-    updates every layer whose bucket has arrived while the last, first-encoder-layer bucket is still in flight)."""
+    updates every layer whose bucket has arrived while the last, first-encoder-layer bucket is still in flight).
+    Under a gloo group (tests, debugging) the mean is SUM followed by a scale, same bucket order."""
 
     def __init__(self, engine, group=None):
         ptr, n = engine.grad_buffer()
         self.flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         self.group = group
+        self.native_avg = dist.get_backend(group) == "nccl"
+        self.inv_world = 1.0 / dist.get_world_size(group)
         self.pending = []          # (bucket, work) in issue order == completion order on the RCCL stream
         self.nb = engine.bucket_count()
         engine.set_bucket_callback(self._on_bucket)
 
     def _on_bucket(self, b, off, cnt):
-        w = dist.all_reduce(self.flat[off:off + cnt], op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        seg = self.flat[off:off + cnt]
+        if self.native_avg:
+            w = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        else:
+            w = _SumThenScale(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg, self.inv_world)
         self.pending.append((b, w))
 
     def __call__(self, engine):

@@ -308,6 +308,92 @@ def test_native_rccl_path_equals_plain_step():
             dist.destroy_process_group()
 
 
+def _two_rank_worker(rank, world, port, out_dir):
+    """One data-parallel rank of test_two_rank_data_parallel_steps: real engine on cuda:0, gloo group (RCCL refuses two
+    ranks on one device), modules.train.GradAllReduce exactly as train() uses it."""
+    import torch.distributed as dist
+    from modules.train import GradAllReduce
+    from simulgen_vae_amd.engine import Engine
+    from simulgen_vae_amd.init import init_state
+    from tests.gpu_common import G1
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    cfg = make_cfg(G1)
+    B = 2
+    x = torch.from_numpy(synthetic_samples(5, range(rank * B, (rank + 1) * B), cfg.num_node, cfg.num_time)).cuda()
+    eng = Engine(cfg, max_batch=B, compute_dtype="f32")
+    eng.load_state(init_state(cfg, 11, reference_init=True))
+    eng.seed(100 + rank)
+    ar = GradAllReduce(eng)
+    norms = []
+    for step in range(3):
+        eng.set_input(x)
+        eng.forward(train=True)
+        eng.backward(1e6, 1e-4)
+        ar.step(eng, 1e-3)
+        norms.append(eng.last_grad_norm())
+    torch.cuda.synchronize()
+    sd = eng.state_dict()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), norms=np.asarray(norms), **{k.replace(".", "__"): v for k, v in sd.items()})
+    eng.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_data_parallel_steps(tmp_path):
+    """SURVEY 8(e) with two real ranks: two processes, each with its own engine and its own shard / noise seed, average
+    their gradient buckets through modules.train.GradAllReduce (bucket callbacks during backward, bucket-ranged AdamW).
+    Expected state: the same three steps in ONE process, where the two shards' gradient arenas are averaged by hand
+    before AdamW.  Both ranks must end with the same parameters."""
+    import socket
+    import torch.multiprocessing as mp
+    from simulgen_vae_amd.engine import Engine
+    from simulgen_vae_amd.init import init_state
+    from modules.train import _DevArray
+    from tests.gpu_common import G1
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    got = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(2)]
+
+    cfg = make_cfg(G1)
+    B = 2
+    engs, flats, xs = [], [], []
+    for r in range(2):
+        e = Engine(cfg, max_batch=B, compute_dtype="f32")
+        e.load_state(init_state(cfg, 11, reference_init=True))
+        e.seed(100 + r)
+        ptr, n = e.grad_buffer()
+        engs.append(e)
+        flats.append(torch.as_tensor(_DevArray(ptr, n), device="cuda"))
+        xs.append(torch.from_numpy(synthetic_samples(5, range(r * B, (r + 1) * B), cfg.num_node, cfg.num_time)).cuda())
+    norms = []
+    for step in range(3):
+        for e, x in zip(engs, xs):
+            e.set_input(x)
+            e.forward(train=True)
+            e.backward(1e6, 1e-4)
+        mean = (flats[0] + flats[1]) * 0.5
+        for e, f in zip(engs, flats):
+            f.copy_(mean)
+            e.adamw_step(1e-3)
+        norms.append(engs[0].last_grad_norm())
+    torch.cuda.synchronize()
+    want = engs[0].state_dict()
+    for e in engs:
+        e.close()
+    np.testing.assert_allclose(got[0]["norms"], norms, rtol=1e-4)
+    np.testing.assert_allclose(got[1]["norms"], norms, rtol=1e-4)
+    for k, w in want.items():
+        w = w.astype(np.float64)
+        a, b = got[0][k.replace(".", "__")].astype(np.float64), got[1][k.replace(".", "__")].astype(np.float64)
+        tol = 3e-4 * np.mean(np.abs(w)) + 1e-9
+        assert np.mean(np.abs(a - w)) <= tol and np.mean(np.abs(b - w)) <= tol, k
+        assert np.mean(np.abs(a - b)) <= tol, k
+
+
 def test_fused_backward_step_equals_separate_calls():
     """sgv_backward_step (AdamW of finished buckets started on the side stream under the rest of backward) leaves the
     state of sgv_backward + sgv_adamw_step; gradients stay exportable afterwards.  fp32 compute, compared in the mean
