@@ -613,6 +613,7 @@ static int upload_tables(sgv_engine* e) {
         d.sigma = e->sn_sigma + 2 * i;
         d.dot = l.has_grad ? e->grads + l.gdot : e->sn_dot_dummy;
         d.G = l.has_grad ? e->grads + l.gw : nullptr;
+        d.wc = (e->dt == SGV_DTYPE_BF16 && l.wc != NPOS && l.cin % 8 == 0) ? (const void*)(e->copies + l.wc * e->esz) : nullptr;
         d.taps = l.k; d.rows = l.cout; d.cols = l.cin; d.active = l.used ? 1 : 0;
         e->sn_host[i] = d;
         if (l.used) {

@@ -84,6 +84,24 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const 
     const int r_hi = min(d.rows, r_lo + SN_ROWS_PER_ITEM);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* vv = d.v + (long)tap * d.cols;
+    if (d.wc) {   // bf16 engine: the GEMMs multiply by this copy, and it is half the bytes of the master
+        const unsigned short* Wc = reinterpret_cast<const unsigned short*>(d.wc);
+        for (int r = r_lo + wave; r < r_hi; r += 4) {
+            const unsigned short* W = Wc + ((long)tap * d.rows + r) * d.cols;
+            float acc = 0.f;
+            for (int c = c_lo + lane * 8; c < c_hi; c += 512) {
+                const uint4 q = *reinterpret_cast<const uint4*>(W + c);
+                const float4 x0 = *reinterpret_cast<const float4*>(vv + c), x1 = *reinterpret_cast<const float4*>(vv + c + 4);
+                acc += __uint_as_float(q.x << 16) * x0.x + __uint_as_float(q.x & 0xffff0000u) * x0.y
+                     + __uint_as_float(q.y << 16) * x0.z + __uint_as_float(q.y & 0xffff0000u) * x0.w
+                     + __uint_as_float(q.z << 16) * x1.x + __uint_as_float(q.z & 0xffff0000u) * x1.y
+                     + __uint_as_float(q.w << 16) * x1.z + __uint_as_float(q.w & 0xffff0000u) * x1.w;
+            }
+            acc = wave_sum(acc);
+            if (lane == 0) atomicAdd(d.tmp_s + r, acc);
+        }
+        return;
+    }
     for (int r = r_lo + wave; r < r_hi; r += 4) {
         const float* W = d.W + ((long)tap * d.rows + r) * d.cols;
         float acc = 0.f;

@@ -79,6 +79,7 @@ struct SNDesc {
     float* sigma;      // [2]: sigma, 1/sigma
     float* dot;        // [SGV_DOT_SLOTS] partial <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
     const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
+    const void* wc;    // bf16 copy of W in the same [taps][rows][cols] order (bf16 engines), or null: W v reads it instead of W
     int taps, rows, cols;
     int active;        // participates in this forward
 };
