@@ -268,9 +268,12 @@ __device__ __forceinline__ float loss_val(int lt, float d) {
 //   group sums   s1 = sum gamma*dz, s2 = sum gamma*dz*xhat -> p.sums2
 // FROM_LOSS also accumulates the loss sums (p.loss_sums[0] selected, [1] squared error) and can
 // write xhat.
-template <typename T, int ACT, bool FROM_LOSS, bool TRAIN>
+// LT: the loss kind as a compile-time constant (FROM_LOSS, bf16 engines: without it the selection is four scalar
+// branches per element), or -1 = read p.loss_type.
+template <typename T, int ACT, bool FROM_LOSS, bool TRAIN, int LT = -1>
 __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
+    const int lt = LT >= 0 ? LT : p.loss_type;
     float col[3][8];   // A = sum dz, B = sum dz*xhat, X = sum xhat   (over this block's rows)
     float lsel = 0.f, lsq = 0.f;
 #pragma unroll
@@ -297,9 +300,9 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
                 if constexpr (FROM_LOSS) {
                     const float o = tanh_f(z);
                     const float df = o - d[e];
-                    lsel += loss_val(p.loss_type, df);
+                    lsel += loss_val(lt, df);
                     lsq += df * df;
-                    dz = loss_grad(p.loss_type, df) * (1.f - o * o);
+                    dz = loss_grad(lt, df) * (1.f - o * o);
                     v[e] = o;
                 } else {
                     dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
@@ -404,9 +407,10 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
 }
 
 // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]   (pure streaming pass: read y, dOut; write dY)
-template <typename T, int ACT, bool FROM_LOSS>
+template <typename T, int ACT, bool FROM_LOSS, int LT = -1>
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
+    const int lt = LT >= 0 ? LT : p.loss_type;
     float dotacc = 0.f;
     float mean[8], rstd[8], m1[8], m2[8];
     gn_consts<true>(p, c, mean, rstd, m1, m2);
@@ -442,7 +446,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
                     float dz;
                     if constexpr (FROM_LOSS) {
                         const float o = tanh_f(z);
-                        dz = loss_grad(p.loss_type, o - d[e]) * (1.f - o * o);
+                        dz = loss_grad(lt, o - d[e]) * (1.f - o * o);
                     } else {
                         dz = d[e] * p.rscale * (ACT == 1 ? gelu_grad_f(z) : (ACT == 3 ? (z > 0.f ? 1.f : 0.f) : 1.f));
                     }
@@ -886,9 +890,14 @@ size_t ew_gn_part_floats(int B, int T, int C) {
     return (size_t)B * g_.rowsplit * 3 * C;
 }
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + loss (+ bwd reduce)
-    if (dtype == 1) {
-        if (train) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true>), p, s);
-        else GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, false>), p, s);
+    if (dtype == 1 && train) {
+        if (p.loss_type == 0) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true, 0>), p, s);
+        else if (p.loss_type == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true, 1>), p, s);
+        else GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true, 2>), p, s);
+    } else if (dtype == 1) {
+        if (p.loss_type == 0) GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, false, 0>), p, s);
+        else if (p.loss_type == 1) GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, false, 1>), p, s);
+        else GN_LAUNCH((gn_bwd_reduce_kernel<bf16_t, 2, true, false, 2>), p, s);
     } else {
         if (train) GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 2, true, true>), p, s);
         else GN_LAUNCH((gn_bwd_reduce_kernel<float, 2, true, false>), p, s);
@@ -897,8 +906,11 @@ int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + 
     return 0;
 }
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s) {
-    if (dtype == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true>), p, s);
-    else GN_LAUNCH((gn_bwd_apply_kernel<float, 2, true>), p, s);
+    if (dtype == 1) {
+        if (p.loss_type == 0) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true, 0>), p, s);
+        else if (p.loss_type == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true, 1>), p, s);
+        else GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true, 2>), p, s);
+    } else GN_LAUNCH((gn_bwd_apply_kernel<float, 2, true>), p, s);
     return 0;
 }
 int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {

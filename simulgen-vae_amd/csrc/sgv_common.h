@@ -86,15 +86,16 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // VALU-bound on this function (libm erff + expf were ~2/3 of their instructions).
 __device__ __forceinline__ void gelu_parts(float x, float& Phi, float& dens) {
     const float e = __expf(-0.5f * x * x);
-    const float t = __fdividef(1.0f, 1.0f + 0.3275911f * 0.70710678118654752f * fabsf(x));
+    const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * 0.70710678118654752f * fabsf(x));   // v_rcp_f32 (1 ulp); hipcc
+    // expands __fdividef to the full IEEE sequence (div_scale / fmas / fixup + Newton steps: ~10 VALU ops per element)
     const float poly = ((((1.061405429f * t - 1.453152027f) * t + 1.421413741f) * t - 0.284496736f) * t + 0.254829592f) * t;
     const float h = 0.5f - 0.5f * poly * e;                // 0.5 * erf(|x| / sqrt 2)
     Phi = x >= 0.f ? 0.5f + h : 0.5f - h;
     dens = e * 0.39894228040143268f;
 }
 __device__ __forceinline__ float gelu_f(float x) { float P, d; gelu_parts(x, P, d); return x * P; }
-// tanh through one exp and one fast divide (absolute error ~1e-7; libm tanhf made the recon-head passes VALU-bound)
-__device__ __forceinline__ float tanh_f(float x) { return 1.0f - __fdividef(2.0f, __expf(2.0f * x) + 1.0f); }
+// tanh through one exp and one v_rcp_f32 (absolute error ~2e-7; libm tanhf made the recon-head passes VALU-bound)
+__device__ __forceinline__ float tanh_f(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__expf(2.0f * x) + 1.0f); }
 __device__ __forceinline__ float gelu_grad_f(float x) { float P, d; gelu_parts(x, P, d); return P + x * d; }
 
 // ---- Philox4x32-10 (counter-based RNG; keyed by (seed, stream), counter = element index / 4) ----
