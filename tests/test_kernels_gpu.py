@@ -177,10 +177,12 @@ def test_gemm_tn_w2(case):
         assert err < 2e-5, (case, rep, err)
 
 
-@pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1)])
+@pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1),
+                                  (300, 296, 9008, 1, 100, 2), (256, 512, 4160, 1, 64, 1)])
 def test_gemm_nt_wide_stress(case):
     """The 128x256 LDS-DMA kernel (bf16, N >= 256, >= 64 K-steps) repeated 25x per shape: every run must match
-    (guards the counted-vmcnt / barrier pipeline against intermittent races)."""
+    (guards the counted-vmcnt / barrier pipeline against intermittent races).  The last two shapes are the long one-tap
+    contraction of the K = 95 008 layers in small: ragged M / N, a K tail, 1 and 2 split-K slices."""
     import torch
     lib = E.load_library()
     M, N, K, taps, Tlen, splitk = case
