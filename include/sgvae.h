@@ -219,6 +219,11 @@ int sgv_kernel_time_tag(sgv_engine* e, int index, char* name, size_t cap, float*
 int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale,
                      const void* addend, int M, int N, int K, int taps, int Tlen, int splitk, int out_f32,
                      void* stream);
+/* bf16 128x128 kernel with the GroupNorm-statistics epilogue: sums[(m / Tlen) * (N / Cg) + n / Cg][2] += (sum, sum of squares)
+ * of the stored outputs; sums must be zeroed by the caller.  Rejected unless Tlen >= 128, Cg >= 128 and the shape runs on the
+ * 128x128 kernel (fewer than 64 K-steps of 32, or N < 256). */
+int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* bias, const void* addend, int M, int N, int K,
+                           int taps, int Tlen, int Cg, double* sums, void* stream);
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,
                      int Tlen, int splitk, int use_tr /* 2: force the 128x256 two-blocks-per-CU kernel */, void* stream);
 

@@ -741,8 +741,15 @@ static const void* wc_ptr(sgv_engine* e, const Layer& l) {
 static const void* wct_ptr(sgv_engine* e, const Layer& l) { return e->copies + l.wct * e->esz; }
 
 // Y = conv(X) * (1/sigma) + bias
-static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M) {
+// gn_sums != null: the GEMM epilogue also accumulates the GroupNorm (sum, sum of squares) of the output per (sample,
+// group) -- callers check conv_fwd_fuses_stats first and skip ew_gn_stats
+static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& y, long M, int Cg) {
+    return !y.f32 && gemm_nt_can_fuse_stats(e->dt, (int)M, l.cout, l.cin, l.k, e->T, Cg);   // implies split-K 1
+}
+static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, double* gn_sums = nullptr, int gn_Cg = 0,
+                    int gn_G = 0) {
     GemmNT p; memset(&p, 0, sizeof(p));
+    p.gn_sums = gn_sums; p.gn_Cg = gn_Cg; p.gn_G = gn_G;
     p.A = x.p; p.lda = x.ld;
     p.W = wc_ptr(e, l); p.ldw = l.cin; p.w_tap_stride = (long)l.cout * l.cin;
     p.C = y.p; p.ldc = y.ld; p.out_f32 = y.f32 ? 1 : 0;
@@ -1298,10 +1305,14 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
     Stage& S = e->recon.st[0];
     const Layer& L = e->layers[S.layer];
     const GNLayer& g = e->gns[S.gn];
-    CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M));
     GNParams p = gn_base(e, g, B);
     p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
-    ew_gn_stats(e->dt, p, e->stream);
+    if (conv_fwd_fuses_stats(e, L, S.y, M, p.Cg)) {        // statistics from the GEMM epilogue: one 608 MB pass less
+        CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M, p.sums, p.Cg, p.G));
+    } else {
+        CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M));
+        ew_gn_stats(e->dt, p, e->stream);
+    }
     p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type;
     p.loss_sums = e->scal;
     if (e->write_xhat || !train) { p.out = e->xhat.p; p.ldout = e->xhat.ld; }
@@ -1886,6 +1897,21 @@ int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const flo
     int r = launch_gemm_nt(dtype, p, (hipStream_t)stream);
     hipError_t se = hipStreamSynchronize((hipStream_t)stream);
     if (partial) hipFree(partial);
+    if (r) return fail(SGV_ERR_ARG, "launch_gemm_nt rejected the arguments (%d)", r);
+    if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt failed: %s", hipGetErrorString(se));
+    return SGV_OK;
+}
+
+int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* bias, const void* addend, int M, int N, int K,
+                           int taps, int Tlen, int Cg, double* sums, void* stream) {
+    if (Cg < 1 || N % Cg) return fail(SGV_ERR_ARG, "N must be a multiple of Cg");
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N;
+    p.addend = addend; p.ldadd = N; p.bias = bias;
+    p.M = M; p.N = N; p.K = K; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = 1;
+    p.gn_sums = sums; p.gn_Cg = Cg; p.gn_G = N / Cg;
+    int r = launch_gemm_nt(SGV_DTYPE_BF16, p, (hipStream_t)stream);
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
     if (r) return fail(SGV_ERR_ARG, "launch_gemm_nt rejected the arguments (%d)", r);
     if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt failed: %s", hipGetErrorString(se));
     return SGV_OK;

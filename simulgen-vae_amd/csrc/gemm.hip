@@ -259,6 +259,15 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
             }
             __syncthreads();
             bf16_t* Cg = reinterpret_cast<bf16_t*>(p.C);
+            // GroupNorm statistics of the tile as it is stored (p.gn_sums): a 128-row tile meets at most one sample
+            // boundary (Tlen >= 128) and a 128-column tile at most one group boundary (gn_Cg >= 128).  Per thread:
+            // all / rows of the second sample / columns of the second group / both; the four (sample, group) sums
+            // follow by inclusion-exclusion.
+            const bool st = p.gn_sums != nullptr;
+            const int rb = st ? (m0 / p.Tlen + 1) * p.Tlen : 0x7fffffff;     // first row of the next sample
+            const int cb = st ? (n0 / p.gn_Cg + 1) * p.gn_Cg : 0x7fffffff;   // first column of the next group
+            const bool csplit = cb < n0 + 128;
+            float sA1 = 0.f, sA2 = 0.f, sR1 = 0.f, sR2 = 0.f, sC1 = 0.f, sC2 = 0.f, sB1 = 0.f, sB2 = 0.f;
 #pragma unroll
             for (int i = 0; i < 8; ++i) {
                 const int c = tid + i * 256;          // 2048 chunks of 8 bf16
@@ -272,6 +281,47 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
                         for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
                     }
                     *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
+                    if (st) {
+                        float t1 = 0.f, t2 = 0.f, c1 = 0.f, c2 = 0.f;
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) {
+                            const float f = (float)v[e];
+                            t1 += f; t2 += f * f;
+                            if (csplit && gcol + e >= cb) { c1 += f; c2 += f * f; }
+                        }
+                        const float hi = grow >= rb ? 1.f : 0.f;
+                        sA1 += t1; sA2 += t2; sR1 += hi * t1; sR2 += hi * t2;
+                        sC1 += c1; sC2 += c2; sB1 += hi * c1; sB2 += hi * c2;
+                    }
+                }
+            }
+            if (st) {
+                __shared__ float sst[4][8];
+                float vals[8] = {sA1, sA2, sR1, sR2, sC1, sC2, sB1, sB2};
+#pragma unroll
+                for (int k = 0; k < 8; ++k) {
+                    if (k >= 4 && !csplit) break;       // no group boundary in this tile (block-uniform): the last four are zero
+                    float x = vals[k];
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o);
+                    vals[k] = x;
+                }
+                if (lane == 0) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) sst[wave][k] = vals[k];
+                }
+                __syncthreads();
+                if (tid < 8) {
+                    // tid = (row half << 2) | (column half << 1) | (0: sum, 1: sum of squares)
+                    const int k = tid & 1, ch = (tid >> 1) & 1, rh = tid >> 2;
+                    float a_[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) a_[q] = sst[0][q * 2 + k] + sst[1][q * 2 + k] + sst[2][q * 2 + k] + sst[3][q * 2 + k];
+                    const float A = a_[0], R = a_[1], Cc = a_[2], Bb = a_[3];
+                    const float val = rh ? (ch ? Bb : R - Bb) : (ch ? Cc - Bb : A - R - Cc + Bb);
+                    const int row0 = rh ? rb : m0, col0 = ch ? cb : n0;
+                    if (row0 < p.M && row0 < m0 + 128 && col0 < p.N && col0 < n0 + 128)
+                        atomicAdd(p.gn_sums + ((long)(row0 / p.Tlen) * p.gn_G + col0 / p.gn_Cg) * 2 + k, (double)val);
                 }
             }
             return;
@@ -1069,6 +1119,11 @@ static int pick_splitk(long tiles, long steps, double slab_bytes_per_slice, int 
     return best;
 }
 
+bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg) {
+    static const int on = getenv("SGV_GEMM_STATS") ? atoi(getenv("SGV_GEMM_STATS")) : 1;
+    return on && dtype == 1 && Tlen >= 128 && Cg >= 128 && !gemm_nt_is_wide(dtype, N, (long)taps * cdiv(K, 32)) &&
+           gemm_nt_pick_splitk(M, N, K, taps, dtype) == 1;
+}
 bool gemm_nt_uses_wide(int dtype, int N, int K, int taps) {
     return gemm_nt_is_wide(dtype, N, (long)taps * cdiv(K, dtype == 1 ? 32 : 16));
 }
@@ -1117,6 +1172,9 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
     const long total_steps = (long)p.taps * cdiv(p.K, dtype == 1 ? 32 : 16);
+    if (p.gn_sums && (dtype != 1 || gemm_nt_is_wide(dtype, p.N, total_steps) || p.splitk != 1 || p.out_f32 || p.Tlen < 128 ||
+                      p.gn_Cg < 128 || p.gn_G < 1))
+        return -1;                                   // only the bf16 128x128 epilogue accumulates statistics
     if (gemm_nt_is_wide(dtype, p.N, total_steps)) {
         dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 256) * p.splitk);
         hipLaunchKernelGGL(gemm_nt_wide64p_kernel, grid, dim3(256), 0, s, q);

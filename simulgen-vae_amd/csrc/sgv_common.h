@@ -138,7 +138,12 @@ struct GemmNT {
     float* partial;                 // split-K slabs [splitk][M][N] fp32
     int M, N, K, taps, pad, Tlen, splitk, out_f32;
     long a_bytes, w_bytes;          // filled by launch_gemm_nt: extents for the buffer descriptors
+    // optional: GroupNorm statistics of the output, accumulated by the epilogue of the 128x128 bf16 kernel (splitk 1,
+    // bf16 output, Tlen >= 128, gn_Cg >= 128; see gemm_nt_can_fuse_stats): gn_sums[(m / Tlen) * gn_G + n / gn_Cg][2] +=
+    // (sum, sum of squares) of the stored (bf16-rounded) values, fp64 atomics into a zeroed buffer
+    double* gn_sums; int gn_Cg, gn_G;
 };
+bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);
 struct GemmTN {
     const void* A; long lda;        // dY [M][lda], N1 columns used
     const void* B; long ldb;        // X [M][ldb], N2 columns used, row-shifted by tap

@@ -106,6 +106,60 @@ def test_gemm_nt(dtype, case):
     assert err2 < (6e-3 if dtype == 1 else 2e-5), err2
 
 
+NT_STATS_CASES = [
+    # M, N, K, taps, Tlen, Cg, addend
+    (600, 1024, 96, 1, 200, 256, False),      # sample boundaries inside tiles 1, 3, 4; group boundaries on tile edges
+    (600, 1056, 64, 3, 200, 132, True),       # every 128-column tile holds a group boundary (132 = 4 * 33, not a multiple of 8)
+    (520, 1360, 160, 1, 130, 170, False),     # ragged M / N, boundaries in both directions, last tiles partial
+    (256, 128, 512, 1, 128, 128, False),      # exactly one tile per (sample, group)
+]
+
+
+@pytest.mark.parametrize("case", NT_STATS_CASES)
+def test_gemm_nt_stats_epilogue(case):
+    """GroupNorm statistics accumulated by the 128x128 bf16 GEMM epilogue (sgv_test_gemm_nt_stats) == per-(sample, group)
+    sum and sum of squares of the bf16 output the kernel stored, in fp64; output itself against numpy.  Shapes outside
+    the contract (Tlen < 128, Cg < 128, wide-kernel shapes) are rejected, not silently run without statistics."""
+    import torch
+    lib = E.load_library()
+    M, N, K, taps, Tlen, Cg, use_add = case
+    rng = np.random.default_rng(31)
+    A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = _bf16_round(rng.standard_normal((M, N)).astype(np.float32)) if use_add else None
+    dA, dW = _dev(A, 1), _dev(W, 1)
+    dadd = _dev(add, 1) if use_add else None
+    dbias = torch.from_numpy(bias).cuda()
+    B, G = -(-M // Tlen), N // Cg
+    for rep in range(3):
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        sums = torch.zeros((B, G, 2), dtype=torch.float64, device="cuda")
+        rc = lib.sgv_test_gemm_nt_stats(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), dbias.data_ptr(),
+                                        dadd.data_ptr() if use_add else None, M, N, K, taps, Tlen, Cg, sums.data_ptr(), None)
+        assert rc == 0, lib.sgv_last_error()
+        y = out.float().cpu().numpy().astype(np.float64)
+        ref = ref_conv_nt(A, W, bias, 1.0, None, taps, Tlen)
+        if use_add:
+            ref = _bf16_round(ref.astype(np.float32)).astype(np.float64) + add      # the kernel rounds before adding
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 8e-3
+        want = np.zeros((B, G, 2))
+        for b in range(B):
+            blk = y[b * Tlen:(b + 1) * Tlen]
+            for g in range(G):
+                want[b, g, 0] = blk[:, g * Cg:(g + 1) * Cg].sum()
+                want[b, g, 1] = (blk[:, g * Cg:(g + 1) * Cg] ** 2).sum()
+        got = sums.cpu().numpy()
+        assert np.abs(got[..., 1] - want[..., 1]).max() <= 2e-6 * want[..., 1].max(), (case, rep)
+        assert np.abs(got[..., 0] - want[..., 0]).max() <= 2e-6 * want[..., 1].max(), (case, rep)   # sums cancel: scale by sum sq
+    dummy = torch.zeros(64, dtype=torch.float64, device="cuda")
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    assert lib.sgv_test_gemm_nt_stats(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, M, N, K, taps, 100, Cg,
+                                      dummy.data_ptr(), None) != 0          # Tlen < 128
+    assert lib.sgv_test_gemm_nt_stats(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, M, N, K, taps, Tlen, 2,
+                                      dummy.data_ptr(), None) != 0          # Cg < 128
+
+
 TN_CASES = [
     # M, N1, N2, taps, Tlen, splitk
     (128, 128, 128, 1, 16, 1),

@@ -1,6 +1,7 @@
 #!/bin/bash
-# Per-kernel A/B of two builds on one box: rocprofv3 kernel stats of the single-stream bench with the library named by
-# $1 (SGV_LIB, e.g. tests/micro/_ab/libsgvae_prev.so) and with the in-tree one.  Output: gpurun_out/<tag>/{a,b}.
+# Per-kernel A/B on one box: rocprofv3 kernel stats of the single-stream bench, run A with the library named by $1
+# (SGV_LIB, e.g. tests/micro/_ab/libsgvae_prev.so) or, if $1 is NAME=VALUE, with that switch in the environment; run B
+# with the in-tree library and defaults.  Output: gpurun_out/<tag>/{a,b}.
 set -o pipefail
 prev=$1; tag=${2:-ab}
 R=${GRAFT_REPO_ROOT:-$PWD}
@@ -8,7 +9,9 @@ O=$R/gpurun_out/$tag
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 export SGV_DW_SIDE=0
-SGV_LIB=$R/$prev rocprofv3 --kernel-trace --stats --output-format csv -d $O/a -o a -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-baseline skip --no-kernel-timing > $O/a.log 2>&1 || exit 1
+if [[ "$prev" == *=* ]]; then export "$prev"; else export SGV_LIB=$R/$prev; fi
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/a -o a -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-baseline skip --no-kernel-timing > $O/a.log 2>&1 || exit 1
+if [[ "$prev" == *=* ]]; then unset "${prev%%=*}"; else unset SGV_LIB; fi
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/b -o b -- python3 $R/bench.py --steps 20 --warmup 3 --cpu-baseline skip --no-kernel-timing > $O/b.log 2>&1 || exit 1
 cd $R
 python3 - <<PY
