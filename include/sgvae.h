@@ -103,7 +103,9 @@ int sgv_set_input(sgv_engine* e, const float* x_dev, int batch);
 int sgv_set_eps(sgv_engine* e, int site, const float* eps_dev, int batch);
 int sgv_seed(sgv_engine* e, uint64_t seed);
 /* Engine switches: "write_xhat" (materialise the reconstruction in training forwards; default 1),
- * "use_tr" (weight-gradient GEMM reads LDS with ds_read_b64_tr_b16; default 1). */
+ * "use_tr" (weight-gradient GEMM reads LDS with ds_read_b64_tr_b16; default 1), "dw_side_stream" (small weight-gradient
+ * GEMMs on a second stream; default 1), "vendor_gemm" (plain one-tap bf16 GEMMs the library wins go to hipBLASLt when
+ * libhipblaslt.so.1 can be loaded; default 1, 0 keeps every GEMM on the hand-written kernels). */
 int sgv_set_option(sgv_engine* e, const char* key, int value);
 
 /* VAE.forward (VAE_network.py:79-121) on the current input.  train != 0: spectral-norm power
@@ -219,6 +221,11 @@ int sgv_kernel_time_tag(sgv_engine* e, int index, char* name, size_t cap, float*
 int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale,
                      const void* addend, int M, int N, int K, int taps, int Tlen, int splitk, int out_f32,
                      void* stream);
+/* The hipBLASLt path of plain one-tap bf16 GEMMs (csrc/vendor.hip): C[M][N] = (*scale or 1) * A[M][K] W[N][K]^T + bias
+ * (+ addend[M][N], bf16), bf16 out.  SGV_ERR_ARG for shapes the engine would not hand to the library, SGV_ERR_STATE when
+ * libhipblaslt.so.1 cannot be loaded. */
+int sgv_test_gemm_nt_lib(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
+                         int K, void* stream);
 /* bf16 128x128 kernel with the GroupNorm-statistics epilogue: sums[(m / Tlen) * (N / Cg) + n / Cg][2] += (sum, sum of squares)
  * of the stored outputs; sums must be zeroed by the caller.  Rejected unless Tlen >= 128, Cg >= 128 and the shape runs on the
  * 128x128 kernel (fewer than 64 K-steps of 32, or N < 256). */

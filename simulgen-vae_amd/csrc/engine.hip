@@ -67,6 +67,7 @@ struct Layer {
     size_t w = NPOS, b = NPOS, u = NPOS, v = NPOS;  // param arena (floats)
     size_t gw = NPOS, gb = NPOS, gdot = NPOS;       // grad arena (floats); gdot: <G,W_eff> scalar (small zone)
     size_t wc = NPOS, wct = NPOS;                   // compute-copy arena (elements)
+    size_t alpha = NPOS;                            // [max(cin, cout)] copies of 1/sigma for the library GEMM path (one-tap bf16 layers)
     int sn = -1;
     int splitk_tn = 1;
     long nw() const { return (long)cout * cin * k; }
@@ -120,6 +121,7 @@ struct sgv_engine {
     size_t n_sn_tmp_fused = 0, sn_tmp_s_off = 0;
     bool wtu_fresh = false;                          // tmp_t of the fused layers holds W^T u for the current weights
     float* sn_sigma = nullptr;
+    float* sn_alpha = nullptr; size_t n_sn_alpha = 0;   // per-layer vectors of 1/sigma (Layer::alpha)
     float* sn_dot_dummy = nullptr;
     double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
     float* partial = nullptr; size_t partial_floats = 0;
@@ -158,6 +160,7 @@ struct sgv_engine {
     float *last = nullptr, *d_last = nullptr, *zlat = nullptr, *d_z = nullptr;
     int batch = 0;
     bool have_fwd = false, fwd_train = false, write_xhat = true, copies_fresh = false;
+    int vendor_gemm = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 1;   // plain one-tap GEMMs the library wins go to hipBLASLt (vendor.hip); option "vendor_gemm"
     uint64_t seed = 0x5347564145ull, draw = 0;
     long step = 0;
     float scalars_host[SGV_MAX_SCALARS];
@@ -580,6 +583,10 @@ static int build_tables(sgv_engine* e) {
         if (l.need_wct) { l.wct = nc; nc = align_up(nc + (size_t)l.nw(), 8); }
     }
     e->n_copies = nc;
+    size_t na = 0;
+    for (auto& l : e->layers)
+        if (l.used && l.op != OP_LINEAR && l.k == 1 && e->dt == SGV_DTYPE_BF16) { l.alpha = na; na += align_up((size_t)std::max(l.cin, l.cout), 4); }
+    e->n_sn_alpha = na;
     // SN scratch
     size_t nt = 0;
     int si = 0;
@@ -614,6 +621,7 @@ static int upload_tables(sgv_engine* e) {
         d.dot = l.has_grad ? e->grads + l.gdot : e->sn_dot_dummy;
         d.G = l.has_grad ? e->grads + l.gw : nullptr;
         d.wc = (e->dt == SGV_DTYPE_BF16 && l.wc != NPOS && l.cin % 8 == 0) ? (const void*)(e->copies + l.wc * e->esz) : nullptr;
+        d.alpha_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr; d.alpha_n = l.alpha != NPOS ? std::max(l.cin, l.cout) : 0;
         d.taps = l.k; d.rows = l.cout; d.cols = l.cin; d.active = l.used ? 1 : 0;
         e->sn_host[i] = d;
         if (l.used) {
@@ -744,6 +752,11 @@ static const void* wct_ptr(sgv_engine* e, const Layer& l) { return e->copies + l
 // gn_sums != null: the GEMM epilogue also accumulates the GroupNorm (sum, sum of squares) of the output per (sample,
 // group) -- callers check conv_fwd_fuses_stats first and skip ew_gn_stats
 static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& y, long M, int Cg) {
+    if (e->vendor_gemm && l.alpha != NPOS) {      // the library GEMM + a statistics pass beats the own kernel with fused statistics
+        GemmNT q; memset(&q, 0, sizeof(q));
+        q.M = (int)M; q.N = l.cout; q.K = l.cin; q.taps = l.k; q.vendor = 1; q.scale_vec = e->sn_alpha + l.alpha;
+        if (!y.f32 && gemm_nt_vendor_eligible(e->dt, q)) return false;
+    }
     return !y.f32 && gemm_nt_can_fuse_stats(e->dt, (int)M, l.cout, l.cin, l.k, e->T, Cg);   // implies split-K 1
 }
 static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, double* gn_sums = nullptr, int gn_Cg = 0,
@@ -756,10 +769,13 @@ static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor
     p.bias = e->params + l.b;
     p.scale = e->sn_sigma + 2 * l.sn + 1;
     p.M = (int)M; p.N = l.cout; p.K = l.cin; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
-    p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
+    p.vendor = e->vendor_gemm;
+    p.scale_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr;
+    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
+    p.splitk = lib ? 1 : gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
     if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    ScopedTimer tm(e, gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
+    ScopedTimer tm(e, lib ? "gemm_nt_lib" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
     int r = launch_gemm_nt(e->dt, p, e->stream);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d)", l.prefix.c_str(), p.M, p.N, p.K);
     return 0;
@@ -773,10 +789,13 @@ static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     if (addend) { p.addend = addend->p; p.ldadd = addend->ld; }
     p.scale = e->sn_sigma + 2 * l.sn + 1;
     p.M = (int)M; p.N = l.cin; p.K = l.cout; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
-    p.splitk = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
+    p.vendor = e->vendor_gemm;
+    p.scale_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr;
+    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
+    p.splitk = lib ? 1 : gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
     if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    ScopedTimer tm(e, gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
+    ScopedTimer tm(e, lib ? "gemm_nt_lib" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
     int r = launch_gemm_nt(e->dt, p, e->stream);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt(dX) launch failed for %s", l.prefix.c_str());
     return 0;
@@ -1010,6 +1029,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->stats, e->n_stats * 8);
     ALLOC(e->sn_tmp, e->n_sn_tmp * 4);
     ALLOC(e->sn_sigma, e->layers.size() * 2 * 4);
+    ALLOC(e->sn_alpha, std::max<size_t>(e->n_sn_alpha, 4) * 4);
     ALLOC(e->sn_dot_dummy, SGV_DOT_SLOTS * sizeof(float));
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
@@ -1029,7 +1049,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
 int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
-    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot_dummy,
+    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_alpha, e->sn_dot_dummy,
                     e->scal, e->partial, e->partial_tn, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
                     e->items_sn_unf, e->items_adam_flat, e->items_adam_2d};
     for (void* p : ptrs) if (p) hipFree(p);
@@ -1250,6 +1270,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     if (!strcmp(key, "write_xhat")) e->write_xhat = value != 0;
     else if (!strcmp(key, "use_tr")) e->use_tr = value != 0;
     else if (!strcmp(key, "dw_side_stream")) e->use_side = value != 0 && e->side != nullptr;
+    else if (!strcmp(key, "vendor_gemm")) e->vendor_gemm = value != 0;
     else return fail(SGV_ERR_ARG, "unknown option '%s'", key);
     return SGV_OK;
 }
@@ -1899,6 +1920,28 @@ int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const flo
     if (partial) hipFree(partial);
     if (r) return fail(SGV_ERR_ARG, "launch_gemm_nt rejected the arguments (%d)", r);
     if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt failed: %s", hipGetErrorString(se));
+    return SGV_OK;
+}
+
+int sgv_test_gemm_nt_lib(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
+                         int K, void* stream) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N; p.bias = bias; p.scale = scale;
+    p.addend = addend; p.ldadd = N;
+    p.M = M; p.N = N; p.K = K; p.taps = 1; p.Tlen = M; p.splitk = 1; p.vendor = 1;
+    float* vec = nullptr;
+    if (scale) {
+        HIPCHK(hipMalloc((void**)&vec, sizeof(float) * (size_t)N));
+        ew_fill_from_scalar(vec, scale, N, (hipStream_t)stream);
+        p.scale_vec = vec;
+    }
+    if (!gemm_nt_vendor_eligible(SGV_DTYPE_BF16, p)) { if (vec) hipFree(vec); return fail(SGV_ERR_ARG, "shape is not one the library path takes"); }
+    const int r = launch_gemm_nt_vendor(p, (hipStream_t)stream);
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    if (vec) hipFree(vec);
+    if (r > 0) return fail(SGV_ERR_STATE, "hipBLASLt is not available (dlopen libhipblaslt.so.1) or has no algorithm for this shape");
+    if (r < 0) return fail(SGV_ERR_HIP, "hipblasLtMatmul failed");
+    if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm failed: %s", hipGetErrorString(se));
     return SGV_OK;
 }
 

@@ -1398,6 +1398,16 @@ int ew_augment(int dtype, const void* data, void* out, long sample_elems, int ba
 __global__ void axpy_kernel(float* y, const float* x, float a, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
 }
+__global__ __launch_bounds__(256) void fill_from_scalar_kernel(float* dst, const float* src, long n) {
+    const float v = *src;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dst[i] = v;
+}
+int ew_fill_from_scalar(float* dst, const float* src_scalar, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+    hipLaunchKernelGGL(fill_from_scalar_kernel, dim3(blocks), dim3(256), 0, s, dst, src_scalar, n);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
 int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s) {
     int blocks = cdiv_i(n, 256);
     if (blocks > 2048) blocks = 2048;

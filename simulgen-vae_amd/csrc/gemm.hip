@@ -1171,6 +1171,13 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     q.a_bytes = ((long)(p.M - 1) * p.lda + p.K) * esz;
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
+    if (p.vendor && gemm_nt_vendor_eligible(dtype, p)) {
+        const int vr = launch_gemm_nt_vendor(p, s);
+        if (vr <= 0) {
+            if (main_done) hipEventRecord(main_done, s);
+            return vr;
+        }                                            // 1: library not available -> own kernel below
+    }
     const long total_steps = (long)p.taps * cdiv(p.K, dtype == 1 ? 32 : 16);
     if (p.gn_sums && (dtype != 1 || gemm_nt_is_wide(dtype, p.N, total_steps) || p.splitk != 1 || p.out_f32 || p.Tlen < 128 ||
                       p.gn_Cg < 128 || p.gn_G < 1))

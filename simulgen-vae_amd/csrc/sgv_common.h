@@ -142,7 +142,11 @@ struct GemmNT {
     // bf16 output, Tlen >= 128, gn_Cg >= 128; see gemm_nt_can_fuse_stats): gn_sums[(m / Tlen) * gn_G + n / gn_Cg][2] +=
     // (sum, sum of squares) of the stored (bf16-rounded) values, fp64 atomics into a zeroed buffer
     double* gn_sums; int gn_Cg, gn_G;
+    int vendor;                     // 1: hand eligible plain GEMMs (gemm_nt_vendor_eligible) to hipBLASLt (vendor.hip)
+    const float* scale_vec;         // >= N copies of *scale on the device (the library takes a device alpha only as a vector)
 };
+bool gemm_nt_vendor_eligible(int dtype, const GemmNT& p);
+int launch_gemm_nt_vendor(const GemmNT& p, hipStream_t s);   // 0 launched, 1 unavailable, < 0 error
 bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);
 struct GemmTN {
     const void* A; long lda;        // dY [M][lda], N1 columns used

@@ -60,6 +60,7 @@ int ew_linear_expand_bwd(int dtype, const void* dY, const float* X, const float*
 int ew_augment(int dtype, const void* data, void* out, long sample_elems, int batch, const int* idx,
                const unsigned long long* noise_seed, const float* scale, const int* mix_idx, const float* lam, hipStream_t s);
 int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s);
+int ew_fill_from_scalar(float* dst, const float* src_scalar, long n, hipStream_t s);   // dst[i] = *src_scalar
 int ew_scale(float* y, float a, long n, hipStream_t s);
 // input pipeline
 constexpr int SGV_MINMAX_ROWSPLIT = 64;
@@ -80,6 +81,8 @@ struct SNDesc {
     float* dot;        // [SGV_DOT_SLOTS] partial <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
     const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
     const void* wc;    // bf16 copy of W in the same [taps][rows][cols] order (bf16 engines), or null: W v reads it instead of W
+    float* alpha_vec;  // optional [alpha_n]: filled with 1/sigma (the library GEMM path takes its device-side scale as a vector)
+    int alpha_n;
     int taps, rows, cols;
     int active;        // participates in this forward
 };

@@ -253,3 +253,40 @@ def test_gemm_nt_wide_stress(case):
         assert rc == 0, lib.sgv_last_error()
         err = np.abs(out.cpu().numpy() - ref).max() / scale
         assert err < 2e-5, (it, err)
+
+
+@pytest.mark.parametrize("case", [(3200, 5120, 1024, True, True, False), (3200, 1280, 512, True, False, True),
+                                  (3200, 512, 2560, False, True, True), (1600, 2560, 512, False, False, False),
+                                  (3200, 128, 256, True, True, False)])
+def test_gemm_nt_library_path(case):
+    """csrc/vendor.hip (hipBLASLt for plain one-tap GEMMs): scale from a device scalar (handed over as a vector), fp32 bias
+    along N, optional bf16 residual addend, bf16 output -- against numpy and against the hand-written kernel on the same
+    operands (one fp32 result rounded to bf16 on both sides: equal up to summation order, a few one-ulp flips)."""
+    import torch
+    lib = E.load_library()
+    M, N, K, use_bias, use_scale, use_add = case
+    rng = np.random.default_rng(17)
+    A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    W = _bf16_round(rng.standard_normal((1, N, K)).astype(np.float32) * 0.05)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = _bf16_round(rng.standard_normal((M, N)).astype(np.float32))
+    dA, dW, dadd = _dev(A, 1), _dev(W, 1), _dev(add, 1)
+    dbias = torch.from_numpy(bias).cuda() if use_bias else None
+    dscale = torch.tensor([0.37], dtype=torch.float32, device="cuda") if use_scale else None
+    args = (dbias.data_ptr() if use_bias else None, dscale.data_ptr() if use_scale else None, dadd.data_ptr() if use_add else None)
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    rc = lib.sgv_test_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), *args, M, N, K, None)
+    assert rc == 0, lib.sgv_last_error()
+    ref = ref_conv_nt(A, W, bias if use_bias else None, 0.37 if use_scale else 1.0, add if use_add else None, 1, M)
+    got = out.float().cpu().numpy()
+    assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3
+    own = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    rc = lib.sgv_test_gemm_nt(1, dA.data_ptr(), dW.data_ptr(), own.data_ptr(), *args, M, N, K, 1, M, 1, 0, None)
+    assert rc == 0, lib.sgv_last_error()
+    d = np.abs(got - own.float().cpu().numpy())
+    if use_add:     # the own epilogue rounds to bf16 before adding the residual and again after; the library rounds once
+        assert d.max() / np.abs(ref).max() < 1.6e-2 and d.mean() / np.abs(ref).mean() < 3e-3
+    else:
+        assert d.max() / np.abs(ref).max() < 8e-3 and d.mean() / np.abs(ref).mean() < 1e-4
+    # shapes the engine keeps on its own kernels are refused by the hook
+    assert lib.sgv_test_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, None, 64, 64, 64, None) != 0
