@@ -318,6 +318,7 @@ def main():
                 "achieved = sum over its launches of 2*M*N*K*taps / sum of hipEvent durations of the main kernel; "
                 "traffic = (FETCH_SIZE x2 + WRITE_SIZE) per launch from the committed rocprofv3 --pmc passes") or result["roofline"]
             result["roofline_gemm_nt_128"] = roof_obj("gemm_nt", "gemm_nt_kernel (128x128 tiles: N < 256 or short K)", "same accounting")
+            result["roofline_gemm_nt_lib"] = roof_obj("gemm_nt_lib", "hipBLASLt (plain one-tap bf16 GEMMs handed to the library, csrc/vendor.hip)", "same accounting; library kernels, listed for the share of the step they take")
             result["roofline_gemm_tn"] = roof_obj("gemm_tn", "gemm_tn_w2_kernel (weight-gradient GEMM: 128x256 tiles, two blocks per CU; layers with fewer than 256 input channels on the 128x128 gemm_tn_kernel)", "same accounting; traffic sums both kernels")
     if args.layer_times and rank == 0 and world == 1:      # extra step on one rank only: never with collectives in the step
         eng.kernel_time_reset(2)
