@@ -645,6 +645,38 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p)
 }
 
 // split-K combine: out = scale * sum_z partial[z] + bias + addend
+// N % 4 == 0 (every bf16 layer): four columns per thread, 16-byte slab loads, one division per four elements
+template <typename T>
+__global__ __launch_bounds__(256) void gemm_nt_reduce4_kernel(const GemmNT p) {
+    const long total = (long)p.M * p.N, quads = total >> 2;
+    const float sc = p.scale ? *p.scale : 1.0f;
+    const int nq = p.N >> 2;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
+        const int row = (int)(q / nq), col = (int)(q - (long)row * nq) * 4;
+        float4 v = *reinterpret_cast<const float4*>(p.partial + q * 4);
+        for (int z = 1; z < p.splitk; ++z) {
+            const float4 w = *reinterpret_cast<const float4*>(p.partial + (long)z * total + q * 4);
+            v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+        }
+        float o[4] = {v.x * sc, v.y * sc, v.z * sc, v.w * sc};
+        if (p.bias) {
+            const float4 b = *reinterpret_cast<const float4*>(p.bias + col);
+            o[0] += b.x; o[1] += b.y; o[2] += b.z; o[3] += b.w;
+        }
+        if (p.addend) {
+            const T* ad = reinterpret_cast<const T*>(p.addend) + (long)row * p.ldadd + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] += to_f32(ad[e]);
+        }
+        if (p.out_f32) {
+            *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)row * p.ldc + col) = make_float4(o[0], o[1], o[2], o[3]);
+        } else {
+            T* dst = reinterpret_cast<T*>(p.C) + (long)row * p.ldc + col;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) dst[e] = from_f32<T>(o[e]);
+        }
+    }
+}
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_reduce_kernel(const GemmNT p) {
     const long total = (long)p.M * p.N;
@@ -1195,7 +1227,14 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
         long total = (long)p.M * p.N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
-        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, p);
+        const bool quad = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.addend || p.ldadd % 4 == 0) && (((uintptr_t)p.C) & 15) == 0 &&
+                          (!p.bias || (((uintptr_t)p.bias) & 15) == 0);
+        if (quad) {
+            int b4 = (int)((total / 4 + 255) / 256);
+            if (b4 > 4096) b4 = 4096;
+            if (dtype == 1) hipLaunchKernelGGL((gemm_nt_reduce4_kernel<bf16_t>), dim3(b4), dim3(256), 0, s, p);
+            else hipLaunchKernelGGL((gemm_nt_reduce4_kernel<float>), dim3(b4), dim3(256), 0, s, p);
+        } else if (dtype == 1) hipLaunchKernelGGL((gemm_nt_reduce_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, p);
         else hipLaunchKernelGGL((gemm_nt_reduce_kernel<float>), dim3(blocks), dim3(256), 0, s, p);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
