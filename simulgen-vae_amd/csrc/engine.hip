@@ -801,6 +801,18 @@ static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     return 0;
 }
 __global__ void sum_slabs_kernel(float* out, const float* partial, int splitk, long n) {
+    if ((n & 3) == 0 && ((((uintptr_t)out) | ((uintptr_t)partial)) & 15) == 0) {      // 16-byte path (every conv weight)
+        const long n4 = n >> 2;
+        for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+            float4 v = reinterpret_cast<const float4*>(partial)[i];
+            for (int z = 1; z < splitk; ++z) {
+                const float4 w = reinterpret_cast<const float4*>(partial + (long)z * n)[i];
+                v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+            }
+            reinterpret_cast<float4*>(out)[i] = v;
+        }
+        return;
+    }
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         float v = 0.f;
         for (int z = 0; z < splitk; ++z) v += partial[(long)z * n + i];
@@ -859,7 +871,7 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
         p.splitk = sk; p.out = slabs; p.out_slab_stride = nw;
         if (launch_gemm_tn(e->dt, p, st)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s", l.prefix.c_str());
         tm.end_now();
-        int blocks = (int)((nw + 255) / 256); if (blocks > 4096) blocks = 4096;
+        int blocks = (int)((nw / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;     // four elements per thread (grid-stride either way)
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, G, slabs, sk, nw);
     }
     return 0;
