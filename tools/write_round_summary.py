@@ -104,8 +104,14 @@ transposed reads) for the same bytes.
 doc += f"""
 Negative results of the round (5120^2 k5, same box, wide64p = 932-942 TFLOP/s): an NT kernel in the w2 form (K-step 32, two
 blocks per CU, 64-byte source rows) 791-820; an 8-wave NT kernel with two K-groups half a stage out of phase 878; two rows per
-round with all loads issued first in the recon-head loss/reduce pass: 459.9 -> 459.8 µs (the pass is VALU-bound, ≈54 lane-ops per
-element with exp + divide).  All removed.
+round with all loads issued first in the recon-head loss/reduce pass: 459.9 -> 459.8 µs (the pass was VALU-bound, ≈54 lane-ops per
+element; what fixed it later was the instruction count: loss kind as a template parameter and `v_rcp_f32` instead of the IEEE
+divide sequence, 467 -> 252 µs, now HBM-bound at 5 TB/s); L2 prefetch touches in the wide NT kernel for the K = 95 008 layers
+(1014 -> 1026-1210 µs: vector-memory returns are in order); one zeroing kernel per site instead of 14 memsets (no change); four
+rows per round in the bf16 `W v` pass (217 -> 243 µs); the library (hipBLASLt) on the K = 95 008 layers (1028 vs 832 µs) and on
+the conditioner's weight gradients (734 vs 1095 samples/s).  All removed.  Kept from the same series of per-kernel A/B runs
+(`tools/ab_kernel_stats.sh`): the library for plain one-tap GEMMs with K <= 8192 (+2.6 %), bf16 weight copy in the `W v` pass
+(+1.1 %), GroupNorm statistics in the 128x128 GEMM epilogue (own-kernel path), the 16-byte split-K combine passes.
 
 ## Per-layer GEMM table (bench.py --layer-times, hipEvents, one step; top 40 by time)
 
