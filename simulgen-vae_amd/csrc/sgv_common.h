@@ -144,7 +144,19 @@ struct GemmNT {
     double* gn_sums; int gn_Cg, gn_G;
     int vendor;                     // 1: hand eligible plain GEMMs (gemm_nt_vendor_eligible) to hipBLASLt (vendor.hip)
     const float* scale_vec;         // >= N copies of *scale on the device (the library takes a device alpha only as a vector)
+    // gemm256.hip (256x256 persistent kernel): deterministic GroupNorm statistics.  gn_part != null: every (work item, wave)
+    // writes 8 floats (sum / sum of squares of all, of the rows of the next sample, of the columns of the next group, of
+    // both) to gn_part[(item * 8 + wave) * 8 ..]; t256_stats_finalize then produces gn_sums in a fixed order (no atomics).
+    float* gn_part;
+    long a_rows;                    // rows of the A buffer that may be read (>= M; 0: M) -- lets a launch cover rows [0, M) of a
+                                    // longer batch whose taps reach into the rows after M (launch_gemm_nt256 main + tail split)
+    int row0;                       // first row this launch computes (128x128 / 128x256 kernels; tiles start at row0)
 };
+// gemm256.hip
+bool gemm_nt256_eligible(int dtype, const GemmNT& p);
+int gemm_nt256_pick_splitk(int M, int N, int K, int taps);
+size_t gemm_nt256_part_floats(int M, int N, int splitk);
+int launch_gemm_nt256(const GemmNT& p, hipStream_t s);
 bool gemm_nt_vendor_eligible(int dtype, const GemmNT& p);
 int launch_gemm_nt_vendor(const GemmNT& p, hipStream_t s);   // 0 launched, 1 unavailable, < 0 error
 bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);
