@@ -266,7 +266,7 @@ def main():
         value = B * world * args.steps / elapsed
         fwd, dx, dw = gemm_flops(cfg, B)
         peak = MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF
-        roof = {"kernel": "gemm_nt_wide64p_kernel + gemm_nt_kernel (conv forward + input-gradient implicit GEMMs)", "bound": "mfma",
+        roof = {"kernel": "gemm_nt_t256_kernel + gemm_nt_wide64p_kernel + gemm_nt_kernel (conv forward + input-gradient implicit GEMMs)", "bound": "mfma",
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "flop_per_step": fwd + dx}
         result = {"metric": f"simulation samples/sec/node (preset-1 {args.size}, batch 16)", "value": round(value, 3),
@@ -313,10 +313,14 @@ def main():
                     o["traffic"] = round((t["fetch_bytes"] + t["write_bytes"]) / t["launches"])
                     o["traffic_source"] = traffic.get("_source")
                 return o
+            acct = ("achieved = sum over its launches of 2*M*N*K*taps / sum of hipEvent durations of the launch's kernels (main kernel + "
+                    "its split-K combine and its 128-row tail launch for M = 3200); traffic = (FETCH_SIZE x2 + WRITE_SIZE) per "
+                    "launch from the committed rocprofv3 --pmc passes")
             result["roofline"] = roof_obj(
-                "gemm_nt_wide", "gemm_nt_wide64p_kernel (conv forward / input-gradient implicit GEMM, 128x256 tiles, LDS-DMA ring)",
-                "achieved = sum over its launches of 2*M*N*K*taps / sum of hipEvent durations of the main kernel; "
-                "traffic = (FETCH_SIZE x2 + WRITE_SIZE) per launch from the committed rocprofv3 --pmc passes") or result["roofline"]
+                "gemm_nt_t256", "gemm_nt_t256_kernel (conv forward / input-gradient implicit GEMM: 256x256 tiles, persistent, 8 waves, "
+                "quarter-refilled LDS-DMA double buffer)", acct) or result["roofline"]
+            result["roofline_gemm_nt_wide"] = roof_obj(
+                "gemm_nt_wide", "gemm_nt_wide64p_kernel (128x256 tiles, LDS-DMA ring: mid-size layers and the 128-row tails)", "same accounting")
             result["roofline_gemm_nt_128"] = roof_obj("gemm_nt", "gemm_nt_kernel (128x128 tiles: N < 256 or short K)", "same accounting")
             result["roofline_gemm_nt_lib"] = roof_obj("gemm_nt_lib", "hipBLASLt (plain one-tap bf16 GEMMs handed to the library, csrc/vendor.hip)", "same accounting; library kernels, listed for the share of the step they take")
             result["roofline_gemm_tn"] = roof_obj("gemm_tn", "gemm_tn_w2_kernel (weight-gradient GEMM: 128x256 tiles, two blocks per CU; layers with fewer than 256 input channels on the 128x128 gemm_tn_kernel)", "same accounting; traffic sums both kernels")

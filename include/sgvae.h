@@ -231,6 +231,14 @@ int sgv_test_gemm_nt_lib(const void* A, const void* W, void* C, const float* bia
  * 128x128 kernel (fewer than 64 K-steps of 32, or N < 256). */
 int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* bias, const void* addend, int M, int N, int K,
                            int taps, int Tlen, int Cg, double* sums, void* stream);
+/* Test hook for the 256x256 persistent implicit-GEMM kernel (csrc/gemm256.hip; replaces the hipBLASLt dispatch of round 1 on
+ * the reference call sites modules/decoder.py:117-121, modules/common.py:135-141, modules/encoder.py:34).  bf16 operands.
+ * mode 0: the kernel itself with the given split-K; mode 1: the engine's kernel choice (gemm_nt_plan: 256x256 kernel, or
+ * 256x256 over the first rows + the 128-row kernels over the rest, or the 128-row kernels alone); *plan_kind reports it.
+ * sums != NULL: GroupNorm (sum, sum of squares) per (sample, group of Cg channels), [ceil(M/Tlen)][N/Cg][2] fp64, produced
+ * deterministically by the epilogue + a fixed-order finalize. */
+int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
+                        int K, int taps, int Tlen, int splitk, int out_f32, int mode, int Cg, double* sums, int* plan_kind, void* stream);
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,
                      int Tlen, int splitk, int use_tr /* 2: force the 128x256 two-blocks-per-CU kernel */, void* stream);
 

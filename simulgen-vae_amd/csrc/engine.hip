@@ -160,7 +160,9 @@ struct sgv_engine {
     float *last = nullptr, *d_last = nullptr, *zlat = nullptr, *d_z = nullptr;
     int batch = 0;
     bool have_fwd = false, fwd_train = false, write_xhat = true, copies_fresh = false;
-    int vendor_gemm = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 1;   // plain one-tap GEMMs the library wins go to hipBLASLt (vendor.hip); option "vendor_gemm"
+    int vendor_gemm = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 0;   // 1: plain one-tap GEMMs go to hipBLASLt (vendor.hip) -- comparator for tests/micro only; option "vendor_gemm"
+    int deterministic = getenv("SGV_DETERMINISTIC") ? atoi(getenv("SGV_DETERMINISTIC")) : 1;   // 1: no float-atomic accumulation anywhere in the step; option "deterministic"
+    float* gn_part = nullptr; size_t gn_part_floats = 0;   // per-(tile, wave) GroupNorm partial sums of the 256x256 GEMM epilogue
     uint64_t seed = 0x5347564145ull, draw = 0;
     long step = 0;
     float scalars_host[SGV_MAX_SCALARS];
@@ -734,7 +736,9 @@ struct ScopedTimer {
         }
         r.tag = tag_id(e, name);
         hipEventRecord(r.a, e->stream);
-        if (!strncmp(cls, "gemm_nt", 7)) { gemm_nt_main_done_event(r.b); ended = true; }
+        // 128-row kernels: the launcher records the end event right after the main kernel; the 256x256 path (main kernel, its
+        // split-K combine, the 128-row tail launch) is timed as a whole
+        if (!strncmp(cls, "gemm_nt", 7) && strncmp(cls, "gemm_nt_t256", 12)) { gemm_nt_main_done_event(r.b); ended = true; }
     }
     ~ScopedTimer() { if (on) { end_now(); e->timers.push_back(r); } }
 };
@@ -749,20 +753,11 @@ static const void* wc_ptr(sgv_engine* e, const Layer& l) {
 static const void* wct_ptr(sgv_engine* e, const Layer& l) { return e->copies + l.wct * e->esz; }
 
 // Y = conv(X) * (1/sigma) + bias
-// gn_sums != null: the GEMM epilogue also accumulates the GroupNorm (sum, sum of squares) of the output per (sample,
-// group) -- callers check conv_fwd_fuses_stats first and skip ew_gn_stats
-static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& y, long M, int Cg) {
-    if (e->vendor_gemm && l.alpha != NPOS) {      // the library GEMM + a statistics pass beats the own kernel with fused statistics
-        GemmNT q; memset(&q, 0, sizeof(q));
-        q.M = (int)M; q.N = l.cout; q.K = l.cin; q.taps = l.k; q.vendor = 1; q.scale_vec = e->sn_alpha + l.alpha;
-        if (!y.f32 && gemm_nt_vendor_eligible(e->dt, q)) return false;
-    }
-    return !y.f32 && gemm_nt_can_fuse_stats(e->dt, (int)M, l.cout, l.cin, l.k, e->T, Cg);   // implies split-K 1
-}
-static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, double* gn_sums = nullptr, int gn_Cg = 0,
-                    int gn_G = 0) {
-    GemmNT p; memset(&p, 0, sizeof(p));
-    p.gn_sums = gn_sums; p.gn_Cg = gn_Cg; p.gn_G = gn_G;
+// want_stats: let the GEMM epilogue produce the GroupNorm (sum, sum of squares) of the output per (sample, group) when the
+// planned kernel can (256x256 kernel: deterministic partials + finalize; 128x128 kernel: its fp64-atomic epilogue) --
+// callers check conv_fwd_fuses_stats first and skip ew_gn_stats
+static void conv_fwd_params(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, GemmNT& p) {
+    memset(&p, 0, sizeof(p));
     p.A = x.p; p.lda = x.ld;
     p.W = wc_ptr(e, l); p.ldw = l.cin; p.w_tap_stride = (long)l.cout * l.cin;
     p.C = y.p; p.ldc = y.ld; p.out_f32 = y.f32 ? 1 : 0;
@@ -771,13 +766,42 @@ static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor
     p.M = (int)M; p.N = l.cout; p.K = l.cin; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
     p.vendor = e->vendor_gemm;
     p.scale_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr;
-    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
-    p.splitk = lib ? 1 : gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
-    if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    ScopedTimer tm(e, lib ? "gemm_nt_lib" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
-    int r = launch_gemm_nt(e->dt, p, e->stream);
-    if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d)", l.prefix.c_str(), p.M, p.N, p.K);
+}
+// 0: separate statistics pass; 1: 128x128 kernel epilogue (fp64 atomics); 2: 256x256 kernel (deterministic)
+static int conv_fwd_stats_mode(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, int Cg, int G) {
+    if (y.f32 || e->dt != SGV_DTYPE_BF16) return 0;
+    GemmNT q; conv_fwd_params(e, l, x, y, M, q);
+    q.gn_Cg = Cg; q.gn_G = G;
+    if (q.vendor && l.alpha != NPOS && gemm_nt_vendor_eligible(e->dt, q)) return 0;   // library GEMM + a statistics pass
+    const GemmPlan pl = gemm_nt_plan(e->dt, q, e->partial_floats, 1);
+    if (pl.kind == 1 && pl.fuse_stats && gemm_nt256_part_floats((int)M, l.cout, 1) <= e->gn_part_floats) return 2;
+    if (pl.kind == 0 && !e->deterministic && gemm_nt_can_fuse_stats(e->dt, (int)M, l.cout, l.cin, l.k, e->T, Cg)) return 1;
+    return 0;
+}
+static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, int Cg, int G) {
+    return conv_fwd_stats_mode(e, l, x, y, M, Cg, G) != 0;
+}
+static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, double* gn_sums = nullptr, int gn_Cg = 0,
+                    int gn_G = 0) {
+    GemmNT p; conv_fwd_params(e, l, x, y, M, p);
+    const int smode = gn_sums ? conv_fwd_stats_mode(e, l, x, y, M, gn_Cg, gn_G) : 0;
+    if (gn_sums && !smode) return fail(SGV_ERR_STATE, "conv_fwd: statistics requested from a GEMM that cannot produce them (%s)", l.prefix.c_str());
+    p.gn_Cg = gn_Cg; p.gn_G = gn_G;
+    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
+    if (lib) {
+        p.splitk = 1;
+        ScopedTimer tm(e, "gemm_nt_lib", &l, p.M, p.N, p.K, p.taps, 1);
+        if (launch_gemm_nt(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "library gemm launch failed for %s", l.prefix.c_str());
+        return 0;
+    }
+    p.vendor = 0;
+    GemmPlan pl = gemm_nt_plan(e->dt, p, e->partial_floats, smode == 2);
+    if (smode == 2) { p.gn_sums = gn_sums; p.gn_part = e->gn_part; }
+    else if (smode == 1) { p.gn_sums = gn_sums; }
+    ScopedTimer tm(e, pl.kind ? "gemm_nt_t256" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, pl.sk_main);
+    int r = launch_gemm_nt_planned(e->dt, p, pl, e->stream);
+    if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d, kind %d)", l.prefix.c_str(), p.M, p.N, p.K, pl.kind);
     return 0;
 }
 // dX = conv^T(dY) * (1/sigma) (+ addend)
@@ -791,12 +815,18 @@ static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     p.M = (int)M; p.N = l.cin; p.K = l.cout; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
     p.vendor = e->vendor_gemm;
     p.scale_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr;
-    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
-    p.splitk = lib ? 1 : gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, e->dt);
-    if ((size_t)p.splitk * p.M * p.N > e->partial_floats) p.splitk = 1;
     p.partial = e->partial;
-    ScopedTimer tm(e, lib ? "gemm_nt_lib" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, p.splitk);
-    int r = launch_gemm_nt(e->dt, p, e->stream);
+    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
+    if (lib) {
+        p.splitk = 1;
+        ScopedTimer tm(e, "gemm_nt_lib", &l, p.M, p.N, p.K, p.taps, 1);
+        if (launch_gemm_nt(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "library gemm(dX) launch failed for %s", l.prefix.c_str());
+        return 0;
+    }
+    p.vendor = 0;
+    const GemmPlan pl = gemm_nt_plan(e->dt, p, e->partial_floats, 0);
+    ScopedTimer tm(e, pl.kind ? "gemm_nt_t256" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, pl.sk_main);
+    int r = launch_gemm_nt_planned(e->dt, p, pl, e->stream);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt(dX) launch failed for %s", l.prefix.c_str());
     return 0;
 }
@@ -1046,6 +1076,9 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
     ALLOC(e->partial_tn, e->partial_tn_floats * 4);
+    e->gn_part_floats = 0;
+    for (auto& l : e->layers) if (l.used && l.op != OP_LINEAR) e->gn_part_floats = std::max(e->gn_part_floats, gemm_nt256_part_floats((int)M, l.cout, 1));
+    ALLOC(e->gn_part, e->gn_part_floats * 4);
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { e->side = nullptr; e->use_side = false; }
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
@@ -1062,7 +1095,7 @@ int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_alpha, e->sn_dot_dummy,
-                    e->scal, e->partial, e->partial_tn, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
+                    e->scal, e->partial, e->partial_tn, e->gn_part, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
                     e->items_sn_unf, e->items_adam_flat, e->items_adam_2d};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
@@ -1283,6 +1316,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     else if (!strcmp(key, "use_tr")) e->use_tr = value != 0;
     else if (!strcmp(key, "dw_side_stream")) e->use_side = value != 0 && e->side != nullptr;
     else if (!strcmp(key, "vendor_gemm")) e->vendor_gemm = value != 0;
+    else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
     else return fail(SGV_ERR_ARG, "unknown option '%s'", key);
     return SGV_OK;
 }
@@ -1340,7 +1374,7 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
     const GNLayer& g = e->gns[S.gn];
     GNParams p = gn_base(e, g, B);
     p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
-    if (conv_fwd_fuses_stats(e, L, S.y, M, p.Cg)) {        // statistics from the GEMM epilogue: one 608 MB pass less
+    if (conv_fwd_fuses_stats(e, L, e->dec_out[n_st - 1], S.y, M, p.Cg, p.G)) {        // statistics from the GEMM epilogue: one 608 MB pass less
         CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M, p.sums, p.Cg, p.G));
     } else {
         CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M));
@@ -1969,6 +2003,40 @@ int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* b
     hipError_t se = hipStreamSynchronize((hipStream_t)stream);
     if (r) return fail(SGV_ERR_ARG, "launch_gemm_nt rejected the arguments (%d)", r);
     if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt failed: %s", hipGetErrorString(se));
+    return SGV_OK;
+}
+
+// 256x256 persistent kernel (gemm256.hip), bf16.  mode 0: forced (launch_gemm_nt256, split-K as given), 1: the engine's plan
+// (gemm_nt_plan: kernel choice, split-K, main + tail rows).  sums != null: fused GroupNorm statistics (mode 0, split-K 1).
+int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
+                        int K, int taps, int Tlen, int splitk, int out_f32, int mode, int Cg, double* sums, int* plan_kind, void* stream) {
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N;
+    p.addend = addend; p.ldadd = N; p.bias = bias; p.scale = scale;
+    p.M = M; p.N = N; p.K = K; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.out_f32 = out_f32;
+    const size_t cap = (size_t)32 << 20;
+    float* partial = nullptr; float* part = nullptr;
+    HIPCHK(hipMalloc((void**)&partial, sizeof(float) * std::max(cap, (size_t)p.splitk * M * N)));
+    p.partial = partial;
+    if (sums) {
+        if (Cg < 1 || N % Cg) { hipFree(partial); return fail(SGV_ERR_ARG, "N must be a multiple of Cg"); }
+        HIPCHK(hipMalloc((void**)&part, sizeof(float) * gemm_nt256_part_floats(M, N, 1)));
+        p.gn_part = part; p.gn_sums = sums; p.gn_Cg = Cg; p.gn_G = N / Cg;
+    }
+    int r;
+    if (mode == 0) {
+        if (plan_kind) *plan_kind = 1;
+        r = launch_gemm_nt256(p, (hipStream_t)stream);
+    } else {
+        const GemmPlan pl = gemm_nt_plan(SGV_DTYPE_BF16, p, cap, sums != nullptr);
+        if (plan_kind) *plan_kind = pl.kind;
+        if (sums && !pl.fuse_stats) r = -3;
+        else r = launch_gemm_nt_planned(SGV_DTYPE_BF16, p, pl, (hipStream_t)stream);
+    }
+    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    hipFree(partial); if (part) hipFree(part);
+    if (r) return fail(SGV_ERR_ARG, "the 256x256 GEMM path rejected the arguments (%d)", r);
+    if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt256 failed: %s", hipGetErrorString(se));
     return SGV_OK;
 }
 

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M + 127) >> 7;
+    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M - p.row0 + 127) >> 7;
     const int ntiles = tiles_n * tiles_m;
     // 1-D grid of ntiles*splitk blocks: XCD-chunked, split-K slice slowest, grouped tile raster within.
     const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
@@ -79,7 +79,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     const int tile = logical - z * ntiles;
     int tm, tn;
     grouped_raster(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm << 7, n0 = tn << 7;
+    const int m0 = p.row0 + (tm << 7), n0 = tn << 7;
     const int kchunks = (p.K + BK - 1) / BK;
     const int total = p.taps * kchunks;
     const int s_begin = (int)((long)total * z / p.splitk);
@@ -336,7 +336,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
             const int colc = cok ? col : 0;
             const int rbase = m0 + wm * 64 + a * 32 + 4 * lh;
             if (p.splitk > 1) {
-                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
+                float* dst = p.partial + ((long)z * (p.M - p.row0) - p.row0) * p.N + colc;      // slab rows are relative to row0
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -393,14 +393,14 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p)
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M + 127) >> 7;
+    const int tiles_n = (p.N + 255) >> 8, tiles_m = (p.M - p.row0 + 127) >> 7;
     const int ntiles = tiles_n * tiles_m;
     const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
     const int z = logical / ntiles;
     const int tile = logical - z * ntiles;
     int tm, tn;
     grouped_raster(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = tm << 7, n0 = tn << 8;
+    const int m0 = p.row0 + (tm << 7), n0 = tn << 8;
     const int kchunks = (p.K + BK - 1) / BK;
     const int total = p.taps * kchunks;
     const int s_begin = (int)((long)total * z / p.splitk);
@@ -622,7 +622,7 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p)
             const int colc = cok ? col : 0;
             const int rbase = m0 + a * 32 + 4 * lh;
             if (p.splitk > 1) {
-                float* dst = p.partial + ((long)z * p.M) * p.N + colc;
+                float* dst = p.partial + ((long)z * (p.M - p.row0) - p.row0) * p.N + colc;      // slab rows are relative to row0
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int row = rbase + (r & 3) + 8 * (r >> 2);
@@ -648,11 +648,12 @@ __global__ __launch_bounds__(256, 1) void gemm_nt_wide64p_kernel(const GemmNT p)
 // N % 4 == 0 (every bf16 layer): four columns per thread, 16-byte slab loads, one division per four elements
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_reduce4_kernel(const GemmNT p) {
-    const long total = (long)p.M * p.N, quads = total >> 2;
+    const long total = (long)(p.M - p.row0) * p.N, quads = total >> 2;
     const float sc = p.scale ? *p.scale : 1.0f;
     const int nq = p.N >> 2;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < quads; q += (long)gridDim.x * 256) {
-        const int row = (int)(q / nq), col = (int)(q - (long)row * nq) * 4;
+        const int rrow = (int)(q / nq), col = (int)(q - (long)rrow * nq) * 4;
+        const int row = rrow + p.row0;
         float4 v = *reinterpret_cast<const float4*>(p.partial + q * 4);
         for (int z = 1; z < p.splitk; ++z) {
             const float4 w = *reinterpret_cast<const float4*>(p.partial + (long)z * total + q * 4);
@@ -679,10 +680,11 @@ __global__ __launch_bounds__(256) void gemm_nt_reduce4_kernel(const GemmNT p) {
 }
 template <typename T>
 __global__ __launch_bounds__(256) void gemm_nt_reduce_kernel(const GemmNT p) {
-    const long total = (long)p.M * p.N;
+    const long total = (long)(p.M - p.row0) * p.N;
     const float sc = p.scale ? *p.scale : 1.0f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
-        const int row = (int)(i / p.N), col = (int)(i - (long)row * p.N);
+        const int rrow = (int)(i / p.N), col = (int)(i - (long)rrow * p.N);
+        const int row = rrow + p.row0;
         float v = 0.f;
         for (int z = 0; z < p.splitk; ++z) v += p.partial[(long)z * total + i];
         v = v * sc + (p.bias ? p.bias[col] : 0.f);
@@ -1200,10 +1202,13 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (p.splitk > 1 && !p.partial) return -1;
     const int esz = dtype == 1 ? 2 : 4;
     GemmNT q = p;
-    q.a_bytes = ((long)(p.M - 1) * p.lda + p.K) * esz;
+    const long arows = p.a_rows > p.M ? p.a_rows : p.M;
+    q.a_bytes = ((arows - 1) * p.lda + p.K) * esz;
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * esz;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
-    if (p.vendor && gemm_nt_vendor_eligible(dtype, p)) {
+    if (p.row0 < 0 || p.row0 >= p.M || (p.row0 && p.gn_sums)) return -1;
+    const int Mr = p.M - p.row0;                                           // rows this launch computes
+    if (p.vendor && !p.row0 && gemm_nt_vendor_eligible(dtype, p)) {
         const int vr = launch_gemm_nt_vendor(p, s);
         if (vr <= 0) {
             if (main_done) hipEventRecord(main_done, s);
@@ -1215,16 +1220,16 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
                       p.gn_Cg < 128 || p.gn_G < 1))
         return -1;                                   // only the bf16 128x128 epilogue accumulates statistics
     if (gemm_nt_is_wide(dtype, p.N, total_steps)) {
-        dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 256) * p.splitk);
+        dim3 grid(cdiv(Mr, 128) * cdiv(p.N, 256) * p.splitk);
         hipLaunchKernelGGL(gemm_nt_wide64p_kernel, grid, dim3(256), 0, s, q);
     } else {
-        dim3 grid(cdiv(p.M, 128) * cdiv(p.N, 128) * p.splitk);
+        dim3 grid(cdiv(Mr, 128) * cdiv(p.N, 128) * p.splitk);
         if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4>), grid, dim3(256), 0, s, q);
         else hipLaunchKernelGGL((gemm_nt_kernel<float, 4>), grid, dim3(256), 0, s, q);
     }
     if (main_done) hipEventRecord(main_done, s);
     if (p.splitk > 1) {
-        long total = (long)p.M * p.N;
+        long total = (long)Mr * p.N;
         int blocks = (int)((total + 255) / 256);
         if (blocks > 4096) blocks = 4096;
         const bool quad = p.N % 4 == 0 && p.ldc % 4 == 0 && (!p.addend || p.ldadd % 4 == 0) && (((uintptr_t)p.C) & 15) == 0 &&

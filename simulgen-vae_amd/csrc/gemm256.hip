@@ -39,6 +39,22 @@ constexpr uint32_t T256_OOB = 0x7FFFFFF0u;
 #ifndef T256_STAGGER
 #define T256_STAGGER 1       // 1: the two row halves of a workgroup run half a section out of phase (see T256_KTILE)
 #endif
+#ifdef T256_ABL_NOBAR
+#define T256_ABL_NOBAR_ 1
+#else
+#define T256_ABL_NOBAR_ 0
+#endif
+#ifndef T256_FINEWAIT
+#define T256_FINEWAIT 1
+#endif
+#ifndef T256_DELAY
+#define T256_DELAY 0         // start skew: workgroup slot j of an XCD sleeps j * T256_DELAY * 64 cycles (de-phases the epilogue write bursts)
+#endif
+#ifdef T256_ABL_NOSTORE
+#define T256_ABL_NOSTORE_ 1
+#else
+#define T256_ABL_NOSTORE_ 0
+#endif
 #ifndef T256_SETPRIO
 #define T256_SETPRIO 1
 #endif
@@ -76,6 +92,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     const int it_hi = it_lo + (xcd < r8 ? q8 + 1 : q8);
     const int nbx = ((int)gridDim.x - xcd + 7) >> 3;          // workgroups carrying this XCD label
     if (it_lo + jb >= it_hi) return;                          // workgroup-uniform
+    if (T256_DELAY > 0 && q8 >= nbx) for (int d_ = 0; d_ < jb; ++d_) __builtin_amdgcn_s_sleep(T256_DELAY);
 
     const int lda_b = (int)(p.lda * ESZ), ldw_b = (int)(p.ldw * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
     const int kK_b = p.K * ESZ;
@@ -149,7 +166,11 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
 #define T256_VA(V, IM) (MT ? ((V) | ((uint32_t)__builtin_amdgcn_sbfe((int)(IM), (unsigned)ld_j, 1u) & 0x80000000u)) : (V))
     // K tail (last channel chunk of a K that is not a multiple of 64): chunks past K are zero-filled (general path only)
 #define T256_KT(V, DC) ((ld_kcb + (DC) * 16 < kK_b) ? (V) : 0x80000000u)
+#ifdef T256_ABL_NODMA
+#define T256_DMA(RS, VOFF, SOFF, DST) asm volatile("; no dma %0 %1" :: "v"(VOFF), "s"(SOFF));
+#else
 #define T256_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (t256_lds_t*)(DST), 16, (VOFF), (SOFF), 0, 0);
+#endif
     // quarter issues: F = 1 fast path (cursor active, no K tail), F = 0 general; PB = byte offset of the parity buffer filled
 #define T256_ISSUE_A0(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
@@ -204,7 +225,11 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     bf16x8 fb00, fb01, fb10, fb11;                             // weight fragments, columns 0-31: [col tile][k sub-step]
     bf16x8 fc00, fc01, fc10, fc11;                             // weight fragments, columns 32-63
 
+#ifdef T256_ABL_NOREAD      // timing-only ablation builds (tests/micro): results are wrong by construction
+#define T256_DSR(DST, ADDR, IMM) asm volatile("; no read %0 %1" : "=v"(DST) : "v"(ADDR));
+#else
 #define T256_DSR(DST, ADDR, IMM) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(DST) : "v"(ADDR), "n"(IMM));
+#endif
 #define T256_READ_A(A0_, A1_, BASE)                                                                           \
     {                                                                                                         \
         T256_DSR(fa00, A0_, (BASE) + 0) T256_DSR(fa01, A1_, (BASE) + 0)                                       \
@@ -219,7 +244,11 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     }
 #define T256_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa00), "+v"(fa01), "+v"(fa10), "+v"(fa11), "+v"(fa20), "+v"(fa21), "+v"(fa30), "+v"(fa31));
 #define T256_WAIT_B(X) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X##00), "+v"(X##01), "+v"(X##10), "+v"(X##11));
+#ifdef T256_ABL_NOMFMA
+#define T256_MMA(I, N, X, NI, FA, S) asm volatile("; no mfma" : "+v"(acc[I][N]) : "v"(X##NI##S), "v"(FA##S));
+#else
 #define T256_MMA(I, N, X, NI, FA, S) acc[I][N] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(X##NI##S, FA##S, acc[I][N], 0, 0, 0);
+#endif
     // 16 MFMAs: row tiles R0..R0+3 x column tiles C0, C0+1 (weights X) x 2 k sub-steps
 #define T256_MMA16(R0, C0, X)                                                                                 \
     {                                                                                                         \
@@ -240,7 +269,8 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // 2: the DMA stream has ended (sections may have issued nothing: drain)
 #define T256_LEND(F)                                                                                          \
     {                                                                                                         \
-        if ((F) || wmode == 0) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");                  \
+        if (T256_ABL_NOBAR_ && (F)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
+        else if ((F) || wmode == 0) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");                  \
         else if (wmode == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(8 + NST) : "memory");     \
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -248,27 +278,80 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // one K-tile: parity buffer PB is consumed; quarters of the stream's next K-tiles are issued into PN (B1, A1: the K-tile
     // the cursor points at) and, after the cursor has moved, into PB (A0, B0).  A quarter is refilled two sections after the
     // section that read it, so the barrier of the section in between orders the reads before the DMA for every wave.
+#if T256_FINEWAIT
+    // reads ordered by first use; every MFMA pair waits only for the fragments it consumes (LDS returns in order)
+#define T256_W3(N, X, Y, Z) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X), "+v"(Y), "+v"(Z));
+#define T256_W1(N, X) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X));
+#define T256_W2(N, X, Y) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X), "+v"(Y));
+#define T256_MM2(R, C0, X, FA, S) T256_MMA(R, C0 + 0, X, 0, FA, S) T256_MMA(R, C0 + 1, X, 1, FA, S)
+#define T256_SEC1_READ(A0P, A1P, B0P, B1P)                                                                    \
+        T256_DSR(fb00, B0P, 0) T256_DSR(fb10, B0P, 2048) T256_DSR(fa00, A0P, 0)                               \
+        T256_DSR(fa10, A0P, 2048) T256_DSR(fa20, A0P, 4096) T256_DSR(fa30, A0P, 6144)                         \
+        T256_DSR(fb01, B1P, 0) T256_DSR(fb11, B1P, 2048) T256_DSR(fa01, A1P, 0)                               \
+        T256_DSR(fa11, A1P, 2048) T256_DSR(fa21, A1P, 4096) T256_DSR(fa31, A1P, 6144)
+#define T256_SEC1_MMA()                                                                                       \
+        if (T256_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                      \
+        T256_W3(9, fb00, fb10, fa00) __builtin_amdgcn_sched_barrier(0); T256_MM2(0, 0, fb, fa0, 0)            \
+        T256_W1(8, fa10) __builtin_amdgcn_sched_barrier(0); T256_MM2(1, 0, fb, fa1, 0)                        \
+        T256_W1(7, fa20) __builtin_amdgcn_sched_barrier(0); T256_MM2(2, 0, fb, fa2, 0)                        \
+        T256_W1(6, fa30) __builtin_amdgcn_sched_barrier(0); T256_MM2(3, 0, fb, fa3, 0)                        \
+        T256_W3(3, fb01, fb11, fa01) __builtin_amdgcn_sched_barrier(0); T256_MM2(0, 0, fb, fa0, 1)            \
+        T256_W1(2, fa11) __builtin_amdgcn_sched_barrier(0); T256_MM2(1, 0, fb, fa1, 1)                        \
+        T256_W1(1, fa21) __builtin_amdgcn_sched_barrier(0); T256_MM2(2, 0, fb, fa2, 1)                        \
+        T256_W1(0, fa31) __builtin_amdgcn_sched_barrier(0); T256_MM2(3, 0, fb, fa3, 1)                        \
+        if (T256_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0);
+#define T256_SEC2_READ(B0P, B1P)                                                                              \
+        T256_DSR(fc00, B0P, 4096) T256_DSR(fc10, B0P, 4096 + 2048) T256_DSR(fc01, B1P, 4096) T256_DSR(fc11, B1P, 4096 + 2048)
+#define T256_SEC2_MMA()                                                                                       \
+        if (T256_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                      \
+        T256_W2(2, fc00, fc10) __builtin_amdgcn_sched_barrier(0);                                             \
+        T256_MM2(0, 2, fc, fa0, 0) T256_MM2(1, 2, fc, fa1, 0) T256_MM2(2, 2, fc, fa2, 0) T256_MM2(3, 2, fc, fa3, 0) \
+        T256_W2(0, fc01, fc11) __builtin_amdgcn_sched_barrier(0);                                             \
+        T256_MM2(0, 2, fc, fa0, 1) T256_MM2(1, 2, fc, fa1, 1) T256_MM2(2, 2, fc, fa2, 1) T256_MM2(3, 2, fc, fa3, 1) \
+        if (T256_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0);
+#define T256_SEC3_READ(A0P, A1P)                                                                              \
+        T256_DSR(fa00, A0P, 8192) T256_DSR(fa10, A0P, 8192 + 2048) T256_DSR(fa20, A0P, 8192 + 4096) T256_DSR(fa30, A0P, 8192 + 6144) \
+        T256_DSR(fa01, A1P, 8192) T256_DSR(fa11, A1P, 8192 + 2048) T256_DSR(fa21, A1P, 8192 + 4096) T256_DSR(fa31, A1P, 8192 + 6144)
+#define T256_SEC3_MMA()                                                                                       \
+        if (T256_SETPRIO) __builtin_amdgcn_s_setprio(1);                                                      \
+        T256_W1(7, fa00) __builtin_amdgcn_sched_barrier(0); T256_MM2(4, 2, fc, fa0, 0)                        \
+        T256_W1(6, fa10) __builtin_amdgcn_sched_barrier(0); T256_MM2(5, 2, fc, fa1, 0)                        \
+        T256_W1(5, fa20) __builtin_amdgcn_sched_barrier(0); T256_MM2(6, 2, fc, fa2, 0)                        \
+        T256_W1(4, fa30) __builtin_amdgcn_sched_barrier(0); T256_MM2(7, 2, fc, fa3, 0)                        \
+        T256_W1(3, fa01) __builtin_amdgcn_sched_barrier(0); T256_MM2(4, 2, fc, fa0, 1)                        \
+        T256_W1(2, fa11) __builtin_amdgcn_sched_barrier(0); T256_MM2(5, 2, fc, fa1, 1)                        \
+        T256_W1(1, fa21) __builtin_amdgcn_sched_barrier(0); T256_MM2(6, 2, fc, fa2, 1)                        \
+        T256_W1(0, fa31) __builtin_amdgcn_sched_barrier(0); T256_MM2(7, 2, fc, fa3, 1)                        \
+        if (T256_SETPRIO) __builtin_amdgcn_s_setprio(0);                                                      \
+        __builtin_amdgcn_sched_barrier(0);
+#else
+#define T256_SEC1_READ(A0P, A1P, B0P, B1P) T256_READ_A(A0P, A1P, 0) T256_READ_B(fb, B0P, B1P, 0)
+#define T256_SEC1_MMA() T256_WAIT_A() T256_WAIT_B(fb) __builtin_amdgcn_sched_barrier(0); T256_MMA16(0, 0, fb)
+#define T256_SEC2_READ(B0P, B1P) T256_READ_B(fc, B0P, B1P, 4096)
+#define T256_SEC2_MMA() T256_WAIT_B(fc) __builtin_amdgcn_sched_barrier(0); T256_MMA16(0, 2, fc)
+#define T256_SEC3_READ(A0P, A1P) T256_READ_A(A0P, A1P, 8192)
+#define T256_SEC3_MMA() T256_WAIT_A() __builtin_amdgcn_sched_barrier(0); T256_MMA16(4, 2, fc)
+#endif
 #define T256_KTILE(A0P, A1P, B0P, B1P, PB, PN, F)                                                             \
     {                                                                                                         \
-        T256_READ_A(A0P, A1P, 0) T256_READ_B(fb, B0P, B1P, 0)                                                 \
+        T256_SEC1_READ(A0P, A1P, B0P, B1P)                                                                    \
         T256_ISSUE_B1(PN, F)                                                                                  \
         if (early) T256_LEND(F)                                                                               \
-        T256_WAIT_A() T256_WAIT_B(fb) __builtin_amdgcn_sched_barrier(0);                                      \
-        T256_MMA16(0, 0, fb)                                                                                  \
+        T256_SEC1_MMA()                                                                                       \
         if (!early) T256_LEND(F)                                                                              \
-        T256_READ_B(fc, B0P, B1P, 4096)                                                                       \
+        T256_SEC2_READ(B0P, B1P)                                                                              \
         T256_ISSUE_A1(PN, F)                                                                                  \
         if (early) T256_LEND(F)                                                                               \
-        T256_WAIT_B(fc) __builtin_amdgcn_sched_barrier(0);                                                    \
-        T256_MMA16(0, 2, fc)                                                                                  \
+        T256_SEC2_MMA()                                                                                       \
         if (!early) T256_LEND(F)                                                                              \
-        T256_READ_A(A0P, A1P, 8192)                                                                           \
+        T256_SEC3_READ(A0P, A1P)                                                                              \
         T256_ADVANCE(F)                                                                                       \
         if (!(F) && !l_active) wmode = 2;                                                                     \
         T256_ISSUE_A0(PB, F)                                                                                  \
         if (early) T256_LEND(F)                                                                               \
-        T256_WAIT_A() __builtin_amdgcn_sched_barrier(0);                                                      \
-        T256_MMA16(4, 2, fc)                                                                                  \
+        T256_SEC3_MMA()                                                                                       \
         if (!early) T256_LEND(F)                                                                              \
         T256_ISSUE_B0(PB, F)                                                                                  \
         if (early) T256_LEND(F)                                                                               \
@@ -410,7 +493,11 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
                                     ch[e] = t256_pack2(t256_lo(ch[e]) + t256_lo(ad[e]), t256_hi(ch[e]) + t256_hi(ad[e]));
                             }
                         }
-                        __builtin_amdgcn_raw_buffer_store_b128(ch, rsC, ok ? (uint32_t)(((long)row * p.ldc + col) * 2) : T256_OOB, 0, 0);
+#ifdef T256_ABL_CONTIG      // timing only: every store instruction writes 1 KiB of consecutive bytes
+                        __builtin_amdgcn_raw_buffer_store_b128(ch, rsC, (uint32_t)((((long)mw * p.ldc + nw) * 2 & ~1023L) + ((i * 2 + pr) * 8 + wave) * 1024 + lane * 16), 0, 0);
+#else
+                        if (!T256_ABL_NOSTORE_) __builtin_amdgcn_raw_buffer_store_b128(ch, rsC, ok ? (uint32_t)(((long)row * p.ldc + col) * 2) : T256_OOB, 0, 0);
+#endif
                         if (st) {
                             // the chunk's two 4-column halves may lie in different groups (Cg % 4 == 0)
                             const float l0 = t256_lo(ch[0]), h0 = t256_hi(ch[0]), l1 = t256_lo(ch[1]), h1 = t256_hi(ch[1]);
@@ -612,4 +699,72 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
         hipLaunchKernelGGL(t256_stats_finalize_kernel, dim3(B * p.gn_G), dim3(64), 0, s, p.gn_part, p.gn_sums, p.M, p.N, p.Tlen, p.gn_Cg, p.gn_G);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// ---- kernel choice -------------------------------------------------------------------------------------------------
+// costs in units of one K-tile of the 256 kernel (~1.7 us): measured on MI355X with tests/micro/g256_harness.hip
+static double t256_cost(int M, int N, long total_kt, int sk) {
+    const double items = (double)t256_cdiv(M, 256) * t256_cdiv(N, 256) * sk;
+    const double rounds = ceil(items / 256.0);
+    double c = rounds * (ceil((double)total_kt / sk) + 2.5) + 3.0;
+    if (sk > 1) c += (2.0 * sk * (double)M * N * 4.0 / 3.5e12) / 1.7e-6 + 4.0;
+    return c;
+}
+static int t256_best_sk(int M, int N, long total_kt, size_t partial_floats, double* cost) {
+    int best = 1; double bc = 1e30;
+    for (int sk = 1; sk <= 32; ++sk) {
+        if (sk > 1 && (total_kt / sk < 24 || (size_t)sk * M * N > partial_floats)) break;
+        const double c = t256_cost(M, N, total_kt, sk);
+        if (c < bc * 0.97) { bc = c; best = sk; }
+    }
+    if (cost) *cost = bc;
+    return best;
+}
+GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int want_stats) {
+    static const double min_gf = getenv("SGV_T256_MIN_GF") ? atof(getenv("SGV_T256_MIN_GF")) : 30.0;
+    GemmPlan pl = {0, 1, 1, p.M, 0};
+    const long total_kt = (long)p.taps * t256_cdiv(p.K, 64);
+    const double gf = 2.0e-9 * p.M * p.N * p.K * p.taps;
+    const bool big = gemm_nt256_eligible(dtype, p) && p.N >= 1024 && gf >= min_gf && !p.out_f32 && total_kt >= 8;
+    if (!big) {
+        pl.sk_main = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, dtype);
+        if ((size_t)pl.sk_main * p.M * p.N > partial_floats) pl.sk_main = 1;
+        pl.fuse_stats = 0;
+        return pl;
+    }
+    const bool stats_ok = want_stats && p.Tlen >= 128 && p.gn_Cg >= 64 && p.gn_Cg % 4 == 0;
+    double c_all, c_main = 1e30;
+    const int sk_all = stats_ok ? 1 : t256_best_sk(p.M, p.N, total_kt, partial_floats, &c_all);
+    if (stats_ok) { pl.kind = 1; pl.sk_main = 1; pl.fuse_stats = 1; return pl; }
+    const int rem = p.M & 255;
+    int sk_main = 1, sk_tail = 1;
+    if (rem > 0 && rem <= 128 && p.M - rem >= 256) {
+        sk_main = t256_best_sk(p.M - rem, p.N, total_kt, partial_floats, &c_main);
+        sk_tail = gemm_nt_pick_splitk(rem, p.N, p.K, p.taps, dtype);
+        if ((size_t)sk_tail * rem * p.N > partial_floats) sk_tail = 1;
+        // the tail: 128x256 tiles of the gemm.hip kernel at ~60 % of the 256 kernel's rate per CU, + its combine pass and launch
+        const double tail_tiles = (double)t256_cdiv(p.N, 256) * sk_tail;
+        c_main += ceil(tail_tiles / 256.0) * ((double)total_kt / sk_tail * 0.85 + 4.0) + 6.0;
+    }
+    if (c_main < c_all) { pl.kind = 2; pl.sk_main = sk_main; pl.sk_tail = sk_tail; pl.m_main = p.M - rem; }
+    else { pl.kind = 1; pl.sk_main = sk_all; }
+    return pl;
+}
+int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s) {
+    if (pl.kind == 0) {
+        GemmNT q = p; q.splitk = pl.sk_main; q.gn_part = nullptr;
+        return launch_gemm_nt(dtype, q, s);
+    }
+    GemmNT q = p;
+    q.vendor = 0;
+    q.splitk = pl.sk_main;
+    if (!pl.fuse_stats) { q.gn_part = nullptr; q.gn_sums = nullptr; }
+    if (pl.kind == 1) return launch_gemm_nt256(q, s);
+    q.M = pl.m_main; q.a_rows = p.M;
+    int r = launch_gemm_nt256(q, s);
+    if (r) return r;
+    GemmNT t = p;
+    t.vendor = 0; t.gn_part = nullptr; t.gn_sums = nullptr;
+    t.row0 = pl.m_main; t.splitk = pl.sk_tail;
+    return launch_gemm_nt(dtype, t, s);
 }

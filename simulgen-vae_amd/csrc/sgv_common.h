@@ -157,6 +157,14 @@ bool gemm_nt256_eligible(int dtype, const GemmNT& p);
 int gemm_nt256_pick_splitk(int M, int N, int K, int taps);
 size_t gemm_nt256_part_floats(int M, int N, int splitk);
 int launch_gemm_nt256(const GemmNT& p, hipStream_t s);
+// Kernel choice for one NT GEMM / implicit-GEMM convolution (gemm256.hip): kind 0 = 128x128 / 128x256 kernels of gemm.hip,
+// 1 = 256x256 persistent kernel over all rows, 2 = 256x256 kernel over the first m_main rows (a multiple of 256) + the
+// gemm.hip kernels over the remaining <= 128 rows (M = 3200 is 12.5 row tiles: thirteen 256-row tiles would need two rounds
+// of the 256 workgroups where 12 x N/256 fit one).  fuse_stats: the GroupNorm statistics can come from the GEMM epilogue
+// deterministically (kind 1, split-K 1).
+struct GemmPlan { int kind, sk_main, sk_tail, m_main, fuse_stats; };
+GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int want_stats);
+int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s);
 bool gemm_nt_vendor_eligible(int dtype, const GemmNT& p);
 int launch_gemm_nt_vendor(const GemmNT& p, hipStream_t s);   // 0 launched, 1 unavailable, < 0 error
 bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);

@@ -78,7 +78,7 @@ static float time_it(int reps, hipStream_t s, const std::function<int()>& f) {
 }
 
 int main(int argc, char** argv) {
-    int check = 1, reps = 5, stats = 0, addend_on = 0, old_on = 1, Tlen = 200;
+    int check = 1, reps = 5, stats = 0, addend_on = 0, old_on = 1, Tlen = 200, autop = 0;
     std::vector<int> nums;
     for (int i = 1; i < argc; ++i) {
         if (!strncmp(argv[i], "check=", 6)) check = atoi(argv[i] + 6);
@@ -87,6 +87,7 @@ int main(int argc, char** argv) {
         else if (!strncmp(argv[i], "addend=", 7)) addend_on = atoi(argv[i] + 7);
         else if (!strncmp(argv[i], "old=", 4)) old_on = atoi(argv[i] + 4);
         else if (!strncmp(argv[i], "T=", 2)) Tlen = atoi(argv[i] + 2);
+        else if (!strncmp(argv[i], "auto=", 5)) autop = atoi(argv[i] + 5);
         else nums.push_back(atoi(argv[i]));
     }
     if (nums.size() % 5) { printf("usage: g256 [check=1] [reps=5] [stats=0] [addend=0] [old=1] [T=200] M N K taps splitk ...\n"); return 1; }
@@ -113,9 +114,17 @@ int main(int argc, char** argv) {
         p.addend = AD; p.ldadd = N;
         p.M = M; p.N = N; p.K = K; p.taps = taps; p.pad = pad; p.Tlen = Tlen;
         const int G = 8;
-        if (sk <= 0) sk = gemm_nt256_pick_splitk(M, N, K, taps);
+        GemmPlan pl = {1, 1, 1, M, 0};
+        const size_t cap = (size_t)80 << 20;       // floats of split-K workspace, as the engine has
+        if (autop) {
+            CK(hipMalloc(&partial, cap * 4)); p.partial = partial;
+            pl = gemm_nt_plan(1, p, cap, 0);
+            sk = pl.sk_main;
+        } else {
+            if (sk <= 0) sk = gemm_nt256_pick_splitk(M, N, K, taps);
+            if (sk > 1) { CK(hipMalloc(&partial, (size_t)sk * M * N * 4)); p.partial = partial; }
+        }
         p.splitk = sk;
-        if (sk > 1) { CK(hipMalloc(&partial, (size_t)sk * M * N * 4)); p.partial = partial; }
         const bool do_stats = stats && sk == 1 && N % G == 0 && (N / G) % 4 == 0 && N / G >= 64 && Tlen >= 128;
         if (do_stats) {
             CK(hipMalloc(&gpart, gemm_nt256_part_floats(M, N, 1) * 4));
@@ -125,7 +134,7 @@ int main(int argc, char** argv) {
         }
         const double flop = 2.0 * M * N * K * taps;
         fprintf(stderr, "[%d %d %d %d] t256...\n", M, N, K, taps);
-        const float t_new = time_it(reps, s, [&]() { return launch_gemm_nt256(p, s); });
+        const float t_new = time_it(reps, s, [&]() { return autop ? launch_gemm_nt_planned(1, p, pl, s) : launch_gemm_nt256(p, s); });
         // round-1 kernels
         GemmNT po = p; po.C = C2; po.gn_part = nullptr; po.gn_sums = nullptr;
         po.splitk = gemm_nt_pick_splitk(M, N, K, taps, 1);
@@ -179,6 +188,7 @@ int main(int argc, char** argv) {
         const bool ok_old = !check || !old_on || (err_old <= 0.012f * mref + 1e-3f);
         const bool ok_st = serr < 0.f || serr < 2e-5f;
         if (!ok_new || !ok_st) bad = 1;
+        if (autop) printf("[plan kind=%d sk=%d/%d m_main=%d] ", pl.kind, pl.sk_main, pl.sk_tail, pl.m_main);
         printf("M=%d N=%d K=%d taps=%d | t256 sk=%d %8.1f us %7.1f TF/s err %.3g/%.3g %s%s", M, N, K, taps, sk, t_new * 1e3, flop / t_new / 1e9,
                err_new, mref, ok_new ? "OK" : "FAIL", serr >= 0.f ? (ok_st ? " stats OK" : " stats FAIL") : "");
         if (serr >= 0.f) printf("(%.2g)", serr);

@@ -160,6 +160,108 @@ def test_gemm_nt_stats_epilogue(case):
                                       dummy.data_ptr(), None) != 0          # Cg < 128
 
 
+NT256_CASES = [
+    # M, N, K, taps, Tlen, splitk, mode (0: the 256x256 kernel forced, 1: the engine's plan)
+    (256, 256, 512, 1, 128, 1, 0),        # one tile, 8 K-tiles
+    (600, 520, 200, 3, 200, 1, 0),        # ragged M / N, K tail (200 = 3*64 + 8), sample boundaries inside tiles
+    (1000, 768, 1032, 5, 200, 1, 0),      # five taps, K tail of 8
+    (1000, 768, 1024, 1, 200, 2, 0),      # split-K slabs + fixed-order combine
+    (800, 1024, 4104, 1, 200, 3, 0),      # split-K with a K tail in the last slice
+    (3200, 1280, 256, 5, 200, 1, 0),      # more work items than workgroups on an XCD label: item transitions inside a workgroup
+    (256, 256, 95008, 1, 128, 4, 0),      # the first encoder layer's K (95008 = 1484*64 + 32), four slices
+    (3200, 1024, 1280, 5, 200, 0, 1),     # planned: 256 kernel (all rows, or 12 row tiles + 128 tail rows on the 128-row kernel)
+    (3200, 2560, 1280, 5, 200, 0, 1),     # planned: 12 x 10 tiles x 2 slices on the 256 kernel + the 128-row tail
+    (3200, 1024, 512, 1, 200, 0, 1),      # planned: below the size threshold -> 128-row kernels only
+]
+
+
+@pytest.mark.parametrize("case", NT256_CASES)
+def test_gemm_nt256(case):
+    """256x256 persistent LDS-DMA kernel (csrc/gemm256.hip) against numpy on bf16-exact inputs: fp32 output (2e-5, fp32
+    accumulation order only) and bf16 output with scale, bias and addend; forced and through the engine's kernel plan."""
+    import torch
+    lib = E.load_library()
+    M, N, K, taps, Tlen, splitk, mode = case
+    rng = np.random.default_rng(hash(case) % (2 ** 31))
+    A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32)
+    add = _bf16_round(rng.standard_normal((M, N)).astype(np.float32))
+    dA, dW, dadd = _dev(A, 1), _dev(W, 1), _dev(add, 1)
+    dbias, dscale = torch.from_numpy(bias).cuda(), torch.tensor([0.37], device="cuda")
+    kind = C.c_int(-1)
+    ref = ref_conv_nt(A, W, bias, 0.37, None, taps, Tlen)
+    if mode == 0:       # fp32 output: final (split-K 1) or slabs + combine
+        out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
+        rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), dbias.data_ptr(), dscale.data_ptr(), None, M, N, K,
+                                     taps, Tlen, splitk, 1, 0, 0, None, C.byref(kind), None)
+        assert rc == 0, lib.sgv_last_error()
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all()
+        assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-5
+    out2 = torch.full((M, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+    rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out2.data_ptr(), dbias.data_ptr(), dscale.data_ptr(), dadd.data_ptr(), M, N, K,
+                                 taps, Tlen, splitk, 0, mode, 0, None, C.byref(kind), None)
+    assert rc == 0, lib.sgv_last_error()
+    if mode == 1:
+        assert (kind.value in (1, 2)) if N * K * taps >= 1024 * 1280 * 5 else kind.value == 0, kind.value
+    want = _bf16_round(ref.astype(np.float32)).astype(np.float64) + add        # the kernels round before adding the addend
+    got2 = out2.float().cpu().numpy()
+    assert np.isfinite(got2).all()
+    assert np.abs(got2 - want).max() / np.abs(want).max() < 8e-3
+
+
+NT256_STATS_CASES = [
+    # M, N, K, taps, Tlen, Cg
+    (600, 1024, 512, 1, 200, 256),       # sample boundaries inside the waves' 128-row halves; group boundaries on wave edges
+    (600, 1056, 512, 3, 200, 132),       # 132 = 4 * 33: group boundaries inside 64-column blocks and inside 8-column chunks
+    (520, 1360, 520, 1, 130, 68),        # ragged M / N, Cg just above the 64-column limit, K tail
+    (3200, 2048, 512, 1, 200, 256),      # several items per workgroup
+]
+
+
+@pytest.mark.parametrize("case", NT256_STATS_CASES)
+def test_gemm_nt256_stats_epilogue(case):
+    """GroupNorm statistics from the 256x256 kernel's epilogue (per-(item, wave) partial sums + fixed-order finalize, no atomics)
+    == per-(sample, group) sum / sum of squares of the bf16 output the kernel stored (fp64), and bitwise equal between runs."""
+    import torch
+    lib = E.load_library()
+    M, N, K, taps, Tlen, Cg = case
+    rng = np.random.default_rng(37)
+    A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
+    W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.1)
+    bias = rng.standard_normal(N).astype(np.float32)
+    dA, dW, dbias = _dev(A, 1), _dev(W, 1), torch.from_numpy(bias).cuda()
+    B, G = -(-M // Tlen), N // Cg
+    ref = ref_conv_nt(A, W, bias, 1.0, None, taps, Tlen)
+    first = None
+    for rep in range(2):
+        out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+        sums = torch.full((B, G, 2), float("nan"), dtype=torch.float64, device="cuda")      # the finalize overwrites: no zero-fill needed
+        rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), dbias.data_ptr(), None, None, M, N, K, taps, Tlen, 1, 0,
+                                     0, Cg, sums.data_ptr(), None, None)
+        assert rc == 0, lib.sgv_last_error()
+        y = out.float().cpu().numpy().astype(np.float64)
+        assert np.abs(y - ref).max() / np.abs(ref).max() < 8e-3
+        want = np.zeros((B, G, 2))
+        for b in range(B):
+            blk = y[b * Tlen:(b + 1) * Tlen]
+            for g in range(G):
+                want[b, g, 0] = blk[:, g * Cg:(g + 1) * Cg].sum()
+                want[b, g, 1] = (blk[:, g * Cg:(g + 1) * Cg] ** 2).sum()
+        got = sums.cpu().numpy()
+        assert np.abs(got[..., 1] - want[..., 1]).max() <= 2e-6 * want[..., 1].max(), (case, rep)
+        assert np.abs(got[..., 0] - want[..., 0]).max() <= 2e-6 * want[..., 1].max(), (case, rep)
+        if first is None:
+            first = got.copy()
+        else:
+            assert np.array_equal(first, got)          # deterministic: bitwise equal between launches
+    dummy = torch.zeros(64, dtype=torch.float64, device="cuda")
+    out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    assert lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, None, M, N, K, taps, 100, 1, 0, 0, Cg,
+                                   dummy.data_ptr(), None, None) != 0          # Tlen < 128
+
+
 TN_CASES = [
     # M, N1, N2, taps, Tlen, splitk
     (128, 128, 128, 1, 16, 1),
