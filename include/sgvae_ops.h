@@ -34,9 +34,10 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
 
 /* nn.GroupNorm + optional ReLU (model_cnn.py:94,98,104,187-188; act: 0 none, 3 relu) on [B][P][C], C % 8 == 0,
  * G <= 32.  sums: B*G*2 doubles written by the forward and read by the backward; sums2: same size scratch;
- * part: sgv_op_gn_workspace_floats() floats scratch; dgamma/dbeta are ACCUMULATED into (+=). */
+ * part: sgv_op_gn_workspace_floats() floats scratch (forward and backward: per-block partial sums, combined in a fixed order --
+ * no atomics, results are bitwise reproducible); dgamma/dbeta are ACCUMULATED into (+=). */
 int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
-                  double* sums, void* stream);
+                  double* sums, float* part, void* stream);
 size_t sgv_op_gn_workspace_floats(int B, int P, int C);
 int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
                   const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream);

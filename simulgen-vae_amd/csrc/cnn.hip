@@ -827,15 +827,15 @@ int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* 
     return OPLAUNCH_OK();
 }
 
-// GroupNorm (+ activation: 0 none, 3 relu) on [B][P][C]; sums: B*G*2 doubles (zeroed here); out may carry res + rscale*f
+// GroupNorm (+ activation: 0 none, 3 relu) on [B][P][C]; sums: B*G*2 doubles (written); part: sgv_op_gn_workspace_floats floats of
+// scratch (per-block partial sums, combined in a fixed order: no atomics)
 int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
-                  double* sums, void* stream) {
-    OPCHK(y && out && gamma && beta && sums, "sgv_op_gn_fwd: null argument");
+                  double* sums, float* part, void* stream) {
+    OPCHK(y && out && gamma && beta && sums && part, "sgv_op_gn_fwd: null argument");
     OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_fwd: C %% 8 == 0, 1 <= G <= %d, C %% G == 0 required", SGV_GN_MAX_GROUPS);
-    if (hipMemsetAsync(sums, 0, sizeof(double) * 2 * B * G, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
-    p.out = out; p.ldout = C;
-    ew_gn_fwd(dtype, act, p, ST(stream));
+    p.out = out; p.ldout = C; p.part = part;
+    if (ew_gn_fwd(dtype, act, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_fwd: launch failed");
     return OPLAUNCH_OK();
 }
 size_t sgv_op_gn_workspace_floats(int B, int P, int C) { return ew_gn_part_floats(B, P, C); }
@@ -845,11 +845,10 @@ int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy,
                   const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream) {
     OPCHK(y && dout && dy && gamma && beta && sums && sums2 && part && dgamma && dbeta, "sgv_op_gn_bwd: null argument");
     OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_bwd: bad channel / group counts");
-    if (hipMemsetAsync(sums2, 0, sizeof(double) * 2 * B * G, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
     p.sums2 = sums2; p.dout = dout; p.lddout = C; p.rscale = 1.f; p.dgamma = dgamma; p.dbeta = dbeta; p.part = part;
-    p.out = dy; p.ldout = C;
-    ew_gn_bwd(dtype, act, p, ST(stream));
+    p.out = dy; p.ldout = C; p.accum_affine = 1;
+    if (ew_gn_bwd(dtype, act, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_bwd: launch failed");
     return OPLAUNCH_OK();
 }
 

@@ -70,6 +70,7 @@ struct Layer {
     size_t alpha = NPOS;                            // [max(cin, cout)] copies of 1/sigma for the library GEMM path (one-tap bf16 layers)
     int sn = -1;
     int splitk_tn = 1;
+    size_t dot_part = NPOS;                         // per-block <G,W_eff> partials of the layer's dY kernel (e->red arena)
     long nw() const { return (long)cout * cin * k; }
 };
 struct GNLayer {
@@ -77,6 +78,7 @@ struct GNLayer {
     int C = 0, G = 1;
     bool used = true, has_grad = true;
     size_t gamma = NPOS, beta = NPOS, ggamma = NPOS, gbeta = NPOS;
+    size_t ptot = NPOS;                             // [B][3][C] per-sample column totals of the backward pass (e->red arena)
 };
 struct Stage {
     int layer = -1, gn = -1, act = 0;
@@ -119,7 +121,12 @@ struct sgv_engine {
     double* stats = nullptr; size_t n_stats = 0, n_stats_fwd = 0;  // [fwd sums | bwd sums2]
     float* sn_tmp = nullptr; size_t n_sn_tmp = 0;   // [tmp_t of fused layers][tmp_t of the others][tmp_s of all]
     size_t n_sn_tmp_fused = 0, sn_tmp_s_off = 0;
-    bool wtu_fresh = false;                          // tmp_t of the fused layers holds W^T u for the current weights
+    bool wtu_fresh = false;                          // tpart of the fused layers holds the W^T u partials for the current weights
+    std::vector<size_t> sn_tpart_off, sn_spart_off;  // per layer: offsets of the power-iteration partials inside sn_tmp
+    WorkItem* items_ts = nullptr; WorkItem* items_ss = nullptr; int n_items_ts = 0, n_items_ss = 0;
+    float* lin_dot_part = nullptr;                   // per-work-item <G,W>/sigma partials of the Linear layers
+    std::vector<FinDot> fin_lin_dots;
+    double* gnorm_part = nullptr; int n_gnorm_part = 0;   // per-work-item sums of squared gradients of the AdamW passes
     float* sn_sigma = nullptr;
     float* sn_alpha = nullptr; size_t n_sn_alpha = 0;   // per-layer vectors of 1/sigma (Layer::alpha)
     float* sn_dot_dummy = nullptr;
@@ -163,6 +170,11 @@ struct sgv_engine {
     int vendor_gemm = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 0;   // 1: plain one-tap GEMMs go to hipBLASLt (vendor.hip) -- comparator for tests/micro only; option "vendor_gemm"
     int deterministic = getenv("SGV_DETERMINISTIC") ? atoi(getenv("SGV_DETERMINISTIC")) : 1;   // 1: no float-atomic accumulation anywhere in the step; option "deterministic"
     float* gn_part = nullptr; size_t gn_part_floats = 0;   // per-(tile, wave) GroupNorm partial sums of the 256x256 GEMM epilogue
+    // deterministic reductions: block partials that nobody needs before the optimizer (GroupNorm affine / bias gradients,
+    // <G,W_eff>) stay in this arena until the bucket they belong to is released, then two table-driven passes sum them
+    float* red = nullptr; size_t red_floats = 0;
+    std::vector<FinDot> fin_dots; std::vector<FinAffine> fin_affine;
+    int dot_counts[512];
     uint64_t seed = 0x5347564145ull, draw = 0;
     long step = 0;
     float scalars_host[SGV_MAX_SCALARS];
@@ -597,6 +609,13 @@ static int build_tables(sgv_engine* e) {
     for (auto& l : e->layers) if (!layer_fused_adam(l)) nt += align_up((size_t)l.cin * l.k, 4);
     e->sn_tmp_s_off = nt;
     for (auto& l : e->layers) nt += align_up((size_t)l.cout, 4);
+    e->sn_tpart_off.clear(); e->sn_spart_off.clear();
+    for (auto& l : e->layers) {
+        e->sn_tpart_off.push_back(nt);
+        nt += align_up((size_t)((l.cout + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM) * l.k * l.cin, 4);
+        e->sn_spart_off.push_back(nt);
+        nt += align_up((size_t)l.k * ((l.cin + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM) * l.cout, 4);
+    }
     e->n_sn_tmp = nt;
     return 0;
 }
@@ -605,7 +624,8 @@ static int upload_tables(sgv_engine* e) {
     const int L = (int)e->layers.size();
     e->sn_host.resize(L);
     size_t to_f = 0, to_u = e->n_sn_tmp_fused, to_s = e->sn_tmp_s_off;
-    std::vector<WorkItem> i_sn, i_sn_unf, i_dot, i_adam, i_adam_flat, i_adam_2d, i_copy, i_wct;
+    std::vector<WorkItem> i_sn, i_sn_unf, i_dot, i_adam, i_adam_flat, i_adam_2d, i_copy, i_wct, i_ts, i_ss;
+    e->fin_lin_dots.clear();
     const int nbk = (int)e->buckets.size();
     std::vector<std::vector<WorkItem>> flat_b(nbk), tile_b(nbk);
     auto bucket_of = [&](size_t goff) {
@@ -619,6 +639,7 @@ static int upload_tables(sgv_engine* e) {
         size_t& to_t = layer_fused_adam(l) ? to_f : to_u;
         d.tmp_t = e->sn_tmp + to_t; to_t += align_up((size_t)l.cin * l.k, 4);
         d.tmp_s = e->sn_tmp + to_s; to_s += align_up((size_t)l.cout, 4);
+        d.tpart = e->sn_tmp + e->sn_tpart_off[i]; d.spart = e->sn_tmp + e->sn_spart_off[i];
         d.sigma = e->sn_sigma + 2 * i;
         d.dot = l.has_grad ? e->grads + l.gdot : e->sn_dot_dummy;
         d.G = l.has_grad ? e->grads + l.gw : nullptr;
@@ -629,9 +650,12 @@ static int upload_tables(sgv_engine* e) {
         if (l.used) {
             const int rb = (l.cout + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (l.cin + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
             for (int c = 0; c < l.k * rb * cb; ++c) { i_sn.push_back({i, c}); if (!layer_fused_adam(l)) i_sn_unf.push_back({i, c}); }
+            for (int c = 0; c < (l.k * l.cin + 1023) / 1024; ++c) i_ts.push_back({i, c});
+            for (int c = 0; c < (l.cout + 1023) / 1024; ++c) i_ss.push_back({i, c});
         }
         if (l.has_grad && l.op == OP_LINEAR) {   // conv layers get <G,W_eff> from their dY kernels (ew.hip)
             const long nch = (l.nw() + OPT_CHUNK - 1) / OPT_CHUNK;
+            e->fin_lin_dots.push_back({(const float*)(uintptr_t)i_dot.size(), e->grads + l.gdot, (int)nch, 0});   // src = index for now, rebased below
             for (long c = 0; c < nch; ++c) i_dot.push_back({i, (int)c});
         }
     }
@@ -702,6 +726,14 @@ static int upload_tables(sgv_engine* e) {
     if (up(i_sn_unf.data(), sizeof(WorkItem) * i_sn_unf.size(), (void**)&e->items_sn_unf)) return fail(SGV_ERR_HIP, "table upload failed");
     if (up(i_adam_flat.data(), sizeof(WorkItem) * i_adam_flat.size(), (void**)&e->items_adam_flat)) return fail(SGV_ERR_HIP, "table upload failed");
     if (up(i_adam_2d.data(), sizeof(WorkItem) * i_adam_2d.size(), (void**)&e->items_adam_2d)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_ts.data(), sizeof(WorkItem) * i_ts.size(), (void**)&e->items_ts)) return fail(SGV_ERR_HIP, "table upload failed");
+    if (up(i_ss.data(), sizeof(WorkItem) * i_ss.size(), (void**)&e->items_ss)) return fail(SGV_ERR_HIP, "table upload failed");
+    e->n_items_ts = (int)i_ts.size(); e->n_items_ss = (int)i_ss.size();
+    if (hipMalloc((void**)&e->lin_dot_part, sizeof(float) * std::max<size_t>(i_dot.size(), 1)) != hipSuccess) return fail(SGV_ERR_HIP, "hipMalloc failed");
+    for (auto& f : e->fin_lin_dots) f.src = e->lin_dot_part + (size_t)(uintptr_t)f.src;
+    e->n_gnorm_part = (int)std::max(i_adam_flat.size() + i_adam_2d.size(), i_adam.size());
+    if (hipMalloc((void**)&e->gnorm_part, sizeof(double) * std::max(e->n_gnorm_part, 1)) != hipSuccess) return fail(SGV_ERR_HIP, "hipMalloc failed");
+    if (hipMemset(e->gnorm_part, 0, sizeof(double) * std::max(e->n_gnorm_part, 1)) != hipSuccess) return fail(SGV_ERR_HIP, "memset failed");
     e->n_items_sn_unf = (int)i_sn_unf.size(); e->n_items_adam_flat = (int)i_adam_flat.size(); e->n_items_adam_2d = (int)i_adam_2d.size();
     e->n_items_sn = (int)i_sn.size(); e->n_items_dot = (int)i_dot.size();
     e->n_items_adam = (int)i_adam.size(); e->n_items_copy = (int)i_copy.size(); e->n_items_wct = (int)i_wct.size();
@@ -930,7 +962,7 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
         if (S.gn >= 0) {
             const GNLayer& g = e->gns[S.gn];
             GNParams p = gn_base(e, g, B);
-            p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
+            p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.part = e->colpart;
             p.out = S.a.p; p.ldout = S.a.ld;
             if (b.residual && s + 1 == b.st.size()) { p.res = in.p; p.ldres = in.ld; p.rscale = 0.1f; }
             ew_gn_fwd(e->dt, S.act, p, e->stream);
@@ -957,28 +989,38 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
         const Tensor x_raw = (s == 0) ? in : b.st[s - 1].a;
         const Tensor x_conv = S.pre_gelu ? S.pre : x_raw;
         Tensor dY;
+        // <G,W_eff> and the GroupNorm affine / bias gradients leave these kernels as block / per-sample partials in e->red; the
+        // fixed-order sums run once per bucket (flush_fin in backward_impl)
+        int* cnt = &e->dot_counts[e->fin_dots.size() % 512];
         if (S.gn >= 0) {
             const GNLayer& g = e->gns[S.gn];
             GNParams p = gn_base(e, g, B);
             p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
             p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
-            p.dgamma = e->grads + g.ggamma; p.dbeta = e->grads + g.gbeta;
-            p.dbias = e->grads + L.gb; p.part = e->colpart;
+            p.part = e->colpart;
+            p.ptot = e->red + g.ptot;
             p.out = S.dy.p; p.ldout = S.dy.ld;
             p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;   // <G,W_eff> = sum dY*(y - bias)
-            ew_gn_bwd(e->dt, 1, p, e->stream);           // sums2, dgamma, dbeta, dbias, dY (GELU)
+            p.cdot_part = e->red + L.dot_part; p.cdot_blocks = cnt;
+            if (ew_gn_bwd(e->dt, 1, p, e->stream)) return fail(SGV_ERR_STATE, "GroupNorm backward launch failed (%s)", L.prefix.c_str());           // sums2, dY (GELU), partials
+            e->fin_dots.push_back({p.cdot_part, p.cdot, *cnt, 0});
+            e->fin_affine.push_back({p.ptot, e->grads + g.gbeta, e->grads + g.ggamma, e->grads + L.gb, g.C, B, 0, 0});
             dY = S.dy;
         } else if (S.act) {
             GNParams p; p.y = S.y.p; p.ldy = S.y.ld; p.dout = dA.p; p.lddout = dA.ld; p.rscale = sc;
             p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
             p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;
+            p.cdot_part = e->red + L.dot_part; p.cdot_blocks = cnt;
             ew_act(e->dt, 1, p, e->stream);
+            e->fin_dots.push_back({p.cdot_part, p.cdot, *cnt, 0});
             dY = S.dy;
         } else {
             GNParams p; p.y = dA.p; p.ldy = dA.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
             if (!S.y.f32) return fail(SGV_ERR_STATE, "conv without norm/activation must have an fp32 output (%s)", L.prefix.c_str());
             p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b; p.yf32 = (const float*)S.y.p; p.ldyf = S.y.ld;
+            p.cdot_part = e->red + L.dot_part; p.cdot_blocks = cnt;
             ew_act(e->dt, 2, p, e->stream);
+            e->fin_dots.push_back({p.cdot_part, p.cdot, *cnt, 0});
             dY = dA;
         }
         sc = 1.0f;
@@ -1079,6 +1121,13 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     e->gn_part_floats = 0;
     for (auto& l : e->layers) if (l.used && l.op != OP_LINEAR) e->gn_part_floats = std::max(e->gn_part_floats, gemm_nt256_part_floats((int)M, l.cout, 1));
     ALLOC(e->gn_part, e->gn_part_floats * 4);
+    {
+        size_t nr = 0;
+        for (auto& g : e->gns) { g.ptot = nr; nr += align_up((size_t)e->maxB * 3 * g.C, 4); }
+        for (auto& l : e->layers) if (l.op != OP_LINEAR) { l.dot_part = nr; nr += align_up((size_t)ew_gn_max_blocks(e->maxB, e->T, l.cout), 4); }
+        e->red_floats = nr;
+    }
+    ALLOC(e->red, e->red_floats * 4);
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { e->side = nullptr; e->use_side = false; }
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
@@ -1095,8 +1144,8 @@ int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_alpha, e->sn_dot_dummy,
-                    e->scal, e->partial, e->partial_tn, e->gn_part, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
-                    e->items_sn_unf, e->items_adam_flat, e->items_adam_2d};
+                    e->scal, e->partial, e->partial_tn, e->gn_part, e->red, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
+                    e->items_sn_unf, e->items_adam_flat, e->items_adam_2d, e->items_ts, e->items_ss, e->lin_dot_part, e->gnorm_part};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
@@ -1182,11 +1231,10 @@ static int run_sn(sgv_engine* e, int train) {
     // tmp_t of the fused layers may already hold W^T u from the last AdamW pass (still valid: neither W nor u
     // changed since); eval forwards never read or clobber it
     const bool reuse = train && e->wtu_fresh;
-    const size_t z0 = !train ? e->sn_tmp_s_off : (reuse ? e->n_sn_tmp_fused : 0);
-    HIPCHK(hipMemsetAsync(e->sn_tmp + z0, 0, (e->n_sn_tmp - z0) * 4, e->stream));
     const WorkItem* it1 = reuse ? e->items_sn_unf : e->items_sn;
     const int n1 = reuse ? e->n_items_sn_unf : e->n_items_sn;
-    if (opt_sn_power_iteration(e->sn_dev, it1, n1, e->items_sn, e->n_items_sn, (int)e->layers.size(), train, e->stream))
+    if (opt_sn_power_iteration(e->sn_dev, it1, n1, e->items_sn, e->n_items_sn, e->items_ts, e->n_items_ts, e->items_ss, e->n_items_ss,
+                               (int)e->layers.size(), train, e->stream))
         return fail(SGV_ERR_HIP, "spectral-norm launch failed");
     if (train) e->wtu_fresh = false;     // u moved
     return 0;
@@ -1330,11 +1378,11 @@ static int encoder_fwd(sgv_engine* e, int B) {
         x = e->enc_h[i];
         if (i < n - 1) {
             const Layer& l = e->layers[e->xs_lin[i]];
-            ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xs_raw[i], B, l.cin, l.cout, e->stream);
+            ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xs_raw[i], B, l.cin, l.cout, e->colpart, e->stream);
         }
     }
     const Layer& l = e->layers[e->last_lin];
-    ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->last, B, l.cin, l.cout, e->stream);
+    ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->last, B, l.cin, l.cout, e->colpart, e->stream);
     return 0;
 }
 
@@ -1366,14 +1414,14 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
         CHK(block_fwd(e, e->decQ1[i], e->cat[i], B));
         CHK(block_fwd(e, e->decQ2[i], e->decQ1[i].st.back().a, B));
         ew_stage_fwd(e->dt, (const float*)e->decP2[i].st[0].y.p, (const float*)e->decQ2[i].st[0].y.p, e->eps[i + 1], e->dec_out[i].p, e->dec_out[i].ld,
-                     e->zs[i + 1].p, e->zs[i + 1].ld, e->zmap[i], (int)M, C, mode_fix ? 1e-10f : 1.0f, e->scal + 3 + i, 1.0f / B, e->stream);
+                     e->zs[i + 1].p, e->zs[i + 1].ld, e->zmap[i], (int)M, C, mode_fix ? 1e-10f : 1.0f, e->scal + 3 + i, 1.0f / B, (double*)e->colpart, e->stream);
     }
     // recon head: conv -> GroupNorm stats -> tanh + loss (+ backward reductions in training)
     Stage& S = e->recon.st[0];
     const Layer& L = e->layers[S.layer];
     const GNLayer& g = e->gns[S.gn];
     GNParams p = gn_base(e, g, B);
-    p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums;
+    p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.part = e->colpart;
     if (conv_fwd_fuses_stats(e, L, e->dec_out[n_st - 1], S.y, M, p.Cg, p.G)) {        // statistics from the GEMM epilogue: one 608 MB pass less
         CHK(conv_fwd(e, L, e->dec_out[n_st - 1], S.y, M, p.sums, p.Cg, p.G));
     } else {
@@ -1387,7 +1435,7 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
         HIPCHK(hipMemsetAsync(e->recon_unit, 0, 3L * e->N * 4, e->stream));
         p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
         HIPCHK(hipMemsetAsync(p.sums2, 0, sizeof(double) * 2 * B * g.G, e->stream));   // the reduce pass accumulates into it
-        p.dbias = e->recon_unit + 2L * e->N; p.part = e->colpart; p.gscale = 1.0f;
+        p.dbias = e->recon_unit + 2L * e->N; p.gscale = 1.0f;
     }
     ew_recon_loss(e->dt, train, p, e->stream);
     return 0;
@@ -1668,7 +1716,14 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             e->side_dirty = true;
         }
     };
-    auto fire = [&]() { fire_at(bucket); ++bucket; };
+    // fixed-order sums of the partials collected so far: the <G,W_eff> scalars of the layers whose dY kernels have been enqueued
+    // (every fire point: the bucket's AdamW / all-reduce reads them), the GroupNorm affine and bias gradients (small bucket)
+    auto flush_fin = [&](bool affine) {
+        if (!e->fin_dots.empty()) { ew_fin_dots(e->fin_dots.data(), (int)e->fin_dots.size(), e->stream); e->fin_dots.clear(); }
+        if (affine && !e->fin_affine.empty()) { ew_fin_affine(e->fin_affine.data(), (int)e->fin_affine.size(), e->stream); e->fin_affine.clear(); }
+    };
+    e->fin_dots.clear(); e->fin_affine.clear();
+    auto fire = [&]() { flush_fin(false); fire_at(bucket); ++bucket; };
     const int small_bucket = (int)e->buckets.size() - 1;
     // zero the small-gradient zone (biases / GroupNorm affine use atomics) and the backward group sums
     HIPCHK(hipMemsetAsync(e->grads + e->n_grads_w, 0, (e->n_grads - e->n_grads_w) * 4, e->stream));
@@ -1689,7 +1744,9 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         p.dout = e->x_in.p; p.lddout = e->x_in.ld; p.loss_type = e->cfg.loss_type; p.gscale = gs;
         p.out = e->dy_recon.p; p.ldout = e->dy_recon.ld;
         p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;
+        p.cdot_part = e->red + L.dot_part; p.cdot_blocks = &e->dot_counts[0];
         ew_recon_bwd_apply(e->dt, p, e->stream);
+        e->fin_dots.push_back({p.cdot_part, p.cdot, e->dot_counts[0], 0});
         ew_axpy(e->grads + g.ggamma, e->recon_unit, gs, e->N, e->stream);
         ew_axpy(e->grads + g.gbeta, e->recon_unit + e->N, gs, e->N, e->stream);
         ew_axpy(e->grads + L.gb, e->recon_unit + 2L * e->N, gs, e->N, e->stream);
@@ -1746,11 +1803,12 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         if (i == 0) {
             fire();   // everything but the first block's weight gradients is now enqueued
             // <G,W_eff> of the (small) Linear layers from their weights; conv layers accumulated theirs in the dY kernels
-            if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
+            if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->lin_dot_part, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
+            e->fin_dots.insert(e->fin_dots.end(), e->fin_lin_dots.begin(), e->fin_lin_dots.end());
             // the small zone (biases, GroupNorm affine, <G,W_eff> scalars) is complete once the first conv's dY exists:
             // release it BEFORE the first-layer weight-gradient GEMM so that its all-reduce (and, with it, the AdamW
             // of every other layer) does not queue behind the 390 MB first-layer bucket
-            const std::function<void()> early = [&]() { fire_at(small_bucket); };
+            const std::function<void()> early = [&]() { flush_fin(true); fire_at(small_bucket); };
             CHK(block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early));
         } else {
             CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], &e->d_h[i - 1], B));
@@ -1766,6 +1824,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             CHK(adamw_range(e, fuse_lr, 0, nbk, 2, e->stream));           // every flat item
             e->side_dirty = true;                                          // AdamW launches may still run on the side stream
             CHK(join_side(e));
+            ew_rowsum_d(e->gnorm_part, e->n_items_adam_flat + e->n_items_adam_2d, 1, e->scal + 15, 1.0, e->stream);
             e->copies_fresh = true;
             e->wtu_fresh = true;
         } else {
@@ -1786,8 +1845,8 @@ int sgv_backward_step(sgv_engine* e, float alpha, float beta, float lr) {
 
 int sgv_grad_norm(sgv_engine* e, double* out) {
     if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
-    HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
-    if (opt_grad_norm(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, e->scal + 15, e->stream)) return fail(SGV_ERR_HIP, "grad-norm launch failed");
+    if (opt_grad_norm(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, e->gnorm_part, e->stream)) return fail(SGV_ERR_HIP, "grad-norm launch failed");
+    ew_rowsum_d(e->gnorm_part, e->n_items_adam, 1, e->scal + 15, 1.0, e->stream);
     double h = 0.0;
     HIPCHK(hipMemcpyAsync(&h, e->scal + 15, 8, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1798,8 +1857,6 @@ int sgv_grad_norm(sgv_engine* e, double* out) {
 // which: 1 = conv-weight tiles, 2 = flat items (biases, GroupNorm affine, Linear heads), 3 = both
 static int adamw_begin(sgv_engine* e) {
     e->step += 1;
-    HIPCHK(hipMemsetAsync(e->scal + 15, 0, 8, e->stream));
-    if (e->n_sn_tmp_fused) HIPCHK(hipMemsetAsync(e->sn_tmp, 0, e->n_sn_tmp_fused * 4, e->stream));
     e->copies_fresh = false;
     e->wtu_fresh = false;
     return 0;
@@ -1819,9 +1876,9 @@ static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, in
     // biases, GroupNorm affine and the Linear heads: flat pass.  Conv weights: tiled pass that also writes both
     // compute copies and W_new^T u for the next forward's power iteration.
     const int f0 = e->flat_off[bucket_lo], f1 = e->flat_off[bucket_hi], t0 = e->tile_off[bucket_lo], t1 = e->tile_off[bucket_hi];
-    if ((which & 2) && opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, st))
+    if ((which & 2) && opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->gnorm_part + f0, e->dt, st))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    if ((which & 1) && opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->scal + 15, e->dt, st))
+    if ((which & 1) && opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->gnorm_part + e->n_items_adam_flat + t0, e->dt, st))
         return fail(SGV_ERR_HIP, "adamw launch failed");
     return 0;
 }
@@ -1835,6 +1892,7 @@ int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, 
     if (last) {
         e->copies_fresh = true;
         e->wtu_fresh = true;
+        ew_rowsum_d(e->gnorm_part, e->n_items_adam_flat + e->n_items_adam_2d, 1, e->scal + 15, 1.0, e->stream);   // gradient norm^2, fixed order
     }
     return SGV_OK;
 }

@@ -7,6 +7,7 @@
 // modules/decoder.py:133,143), layout conversion and augmentation (modules/augmentation.py:86-124).
 // All arithmetic in fp32 (group sums in fp64); every thread owns 8 consecutive channels (16/32-byte
 // vector accesses) and walks rows, so per-channel constants stay in registers.
+#include <algorithm>
 #include "sgv_ew.h"
 
 static inline int cdiv_i(long a, long b) { return (int)((a + b - 1) / b); }
@@ -87,22 +88,44 @@ __device__ __forceinline__ void gn_consts(const GNParams& p, const GNCtx& c, flo
     }
 }
 
-// Block-level reduction: column sums over the block's rows (optionally accumulated to per-channel
-// outputs) and weighted group sums accumulated into global fp64 (2 values per (b, group)).
-__device__ __forceinline__ void gn_block_reduce(const GNParams& p, const GNCtx& c, float colA[8], float colB[8],
-                                                const float w[8], float* chanA, float* chanB, double* gsums) {
+// sum of one float per thread over the block in a fixed order (shuffle tree per wave, then the waves in index order);
+// the result is returned to every thread.  All blockDim.x (<= 1024, multiple of 64) threads must call.
+__device__ __forceinline__ float block_sum_fixed(float v, float* smw) {
+    const float w = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) smw[threadIdx.x >> 6] = w;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += smw[i];
+    return t;
+}
+// sum of one double per thread over the block, result broadcast to every thread (all 256 threads call)
+__device__ __forceinline__ double block_sum_f64(double v, double* sm4) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sm4[0] + sm4[1] + sm4[2] + sm4[3];
+}
+
+// linear index of this block in its grid
+__device__ __forceinline__ int block_linear() { return ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x; }
+
+// Block-level reduction for the statistics pass: column sums over the block's rows, then per-group sums of this block's
+// columns, written (not accumulated) to gpart[block_linear()][G][2]; ew_gn_stats sums the blocks of a sample in a fixed order.
+__device__ __forceinline__ void gn_block_group_partials(const GNParams& p, const GNCtx& c, float colA[8], float colB[8], float* gpart) {
     __shared__ float smA[2048];
     __shared__ float smB[2048];
-    __shared__ float smG[2 * SGV_GN_MAX_GROUPS];
-    const int tid = threadIdx.x;
-    if (tid < 2 * SGV_GN_MAX_GROUPS) smG[tid] = 0.f;
+    __shared__ float smw[4];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
         smA[(c.ty * p.CV + c.tx) * 8 + e] = colA[e];
         smB[(c.ty * p.CV + c.tx) * 8 + e] = colB[e];
     }
     __syncthreads();
-    if (c.ty == 0 && c.col_ok) {
+    const bool owner = c.ty == 0 && c.col_ok;
+    if (owner) {
         for (int r = 1; r < c.RL; ++r) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
@@ -110,34 +133,23 @@ __device__ __forceinline__ void gn_block_reduce(const GNParams& p, const GNCtx& 
                 colB[e] += smB[(r * p.CV + c.tx) * 8 + e];
             }
         }
-        if (chanA) {
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                atomicAdd(chanA + c.c0 + e, colA[e]);
-                atomicAdd(chanB + c.c0 + e, colB[e]);
-            }
-        }
-        int gprev = c.c0 / p.Cg;
-        float ga = 0.f, gb = 0.f;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int g = (c.c0 + e) / p.Cg;
-            if (g != gprev) {
-                atomicAdd(&smG[gprev * 2], ga);
-                atomicAdd(&smG[gprev * 2 + 1], gb);
-                ga = 0.f; gb = 0.f; gprev = g;
-            }
-            ga += w[e] * colA[e];
-            gb += w[e] * colB[e];
-        }
-        atomicAdd(&smG[gprev * 2], ga);
-        atomicAdd(&smG[gprev * 2 + 1], gb);
     }
-    __syncthreads();
-    if (tid < p.G * 2) {
-        // only groups that intersect this block's columns carry non-zero sums
-        const float v = smG[tid];
-        if (v != 0.f) atomicAdd(&gsums[(long)c.b * p.G * 2 + tid], (double)v);
+    float* dst = gpart + (long)block_linear() * p.G * 2;
+    const int g_lo = min((int)(blockIdx.x * p.CV * 8) / p.Cg, p.G - 1);
+    const int g_hi = min((int)(min((long)(blockIdx.x + 1) * p.CV * 8, (long)p.C) - 1) / p.Cg, p.G - 1);
+    for (int g = 0; g < p.G; ++g) {
+        float ga = 0.f, gb = 0.f;
+        if (g >= g_lo && g <= g_hi) {            // block-uniform
+            float a = 0.f, b2 = 0.f;
+            if (owner) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (min((c.c0 + e) / p.Cg, p.G - 1) == g) { a += colA[e]; b2 += colB[e]; }
+            }
+            ga = block_sum_fixed(a, smw);
+            gb = block_sum_fixed(b2, smw);
+        }
+        if (threadIdx.x == 0) { dst[g * 2] = ga; dst[g * 2 + 1] = gb; }
     }
 }
 
@@ -167,23 +179,19 @@ __device__ __forceinline__ void gn_block_colsums(const GNParams& p, const GNCtx&
     }
 }
 
-// block sum of one float per thread -> atomicAdd into one of the SGV_DOT_SLOTS slots at dst (all 256 threads must call)
-__device__ __forceinline__ void block_atomic_add(float v, float* dst) {
-    __shared__ float smr[4];
-    const float w = wave_sum(v);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) smr[threadIdx.x >> 6] = w;
-    __syncthreads();
-    if (threadIdx.x == 0)
-        atomicAdd(dst + ((blockIdx.x + blockIdx.y * gridDim.x + blockIdx.z * 7) & (SGV_DOT_SLOTS - 1)), smr[0] + smr[1] + smr[2] + smr[3]);
+// block sum of one float per thread -> dst[block_linear()] (all threads must call); the partials are summed later in a fixed order
+__device__ __forceinline__ void block_store_partial(float v, float* dst) {
+    __shared__ float smr[16];
+    const float t = block_sum_fixed(v, smr);
+    if (threadIdx.x == 0) dst[block_linear()] = t;
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
     const GNCtx c = gn_ctx(p);
-    float a[8], s[8], w[8];
+    float a[8], s[8];
 #pragma unroll
-    for (int e = 0; e < 8; ++e) { a[e] = 0.f; s[e] = 0.f; w[e] = 1.f; }
+    for (int e = 0; e < 8; ++e) { a[e] = 0.f; s[e] = 0.f; }
     if (c.col_ok) {
         const T* y = reinterpret_cast<const T*>(p.y);
         // two rows per round, both loads issued before the first use (streaming pass: latency, not VALU, limits it)
@@ -203,7 +211,7 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GNParams p) {
             }
         }
     }
-    gn_block_reduce(p, c, a, s, w, nullptr, nullptr, p.sums);
+    gn_block_group_partials(p, c, a, s, p.part);
 }
 
 __device__ __forceinline__ float act_apply(int act, float z) {
@@ -317,74 +325,58 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
         }
     }
     if constexpr (FROM_LOSS) {
-        __shared__ float sml[8];
-        const float a = wave_sum(lsel), b2 = wave_sum(lsq);
-        const int wv = threadIdx.x >> 6;
-        if ((threadIdx.x & 63) == 0) { sml[wv * 2] = a; sml[wv * 2 + 1] = b2; }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            atomicAdd(&p.loss_sums[0], (double)(sml[0] + sml[2] + sml[4] + sml[6]));
-            atomicAdd(&p.loss_sums[1], (double)(sml[1] + sml[3] + sml[5] + sml[7]));
-        }
+        // per-block loss partials (selected loss, squared error) -> lpart[block][2]; ew_recon_loss sums them in a fixed order
+        __shared__ float sml[4];
+        const float a = block_sum_fixed(lsel, sml);
+        const float b2 = block_sum_fixed(lsq, sml);
+        if (threadIdx.x == 0) { p.lpart[(long)block_linear() * 2] = a; p.lpart[(long)block_linear() * 2 + 1] = b2; }
     }
-    if constexpr (TRAIN) {
-        gn_block_colsums<3>(p, c, col);          // ty == 0 threads now hold the block's column sums
-        // group sums s1 = sum gamma*A, s2 = sum gamma*B of this block's columns -> p.sums2 (fp64 atomics; zeroed per step)
-        __shared__ float smG[2 * SGV_GN_MAX_GROUPS];
-        if (threadIdx.x < 2 * SGV_GN_MAX_GROUPS) smG[threadIdx.x] = 0.f;
-        __syncthreads();
-        if (c.ty == 0 && c.col_ok) {
-            int gprev = c.c0 / p.Cg;
-            float ga = 0.f, gb = 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const int g = (c.c0 + e) / p.Cg;
-                if (g != gprev) {
-                    atomicAdd(&smG[gprev * 2], ga);
-                    atomicAdd(&smG[gprev * 2 + 1], gb);
-                    ga = 0.f; gb = 0.f; gprev = g;
-                }
-                const float gm = p.gamma[c.c0 + e];
-                ga += gm * col[0][e];
-                gb += gm * col[1][e];
-            }
-            atomicAdd(&smG[gprev * 2], ga);
-            atomicAdd(&smG[gprev * 2 + 1], gb);
-        }
-        __syncthreads();
-        if ((int)threadIdx.x < p.G * 2) {
-            const float v = smG[threadIdx.x];
-            if (v != 0.f) atomicAdd(&p.sums2[(long)c.b * p.G * 2 + threadIdx.x], (double)v);
-        }
-    }
+    if constexpr (TRAIN) gn_block_colsums<3>(p, c, col);      // per-block column sums; gn_bwd_finalize_kernel does the rest
 }
 
-// One thread per (sample, column): combine the row-block partials of gn_bwd_reduce_kernel (A = sum dz, B = sum dz*xhat,
-// X = sum xhat) with the group sums that kernel accumulated in p.sums2 = (s1, s2) = (sum gamma*A, sum gamma*B):
-//   dbeta_c += A_c, dgamma_c += B_c                                  (atomics across the B samples only)
-//   dbias_c += gscale * rstd * (gamma_c*A_c - T*s1/n - (s2/n)*X_c)   (= column sum of dY, analytically)
+// One block per (group, sample): combine the row-block partials of gn_bwd_reduce_kernel (A = sum dz, B = sum dz*xhat,
+// X = sum xhat per column) in a fixed order:
+//   sums2[b][g] = (s1, s2) = (sum_c gamma_c A_c, sum_c gamma_c B_c)                 (plain store: no zero-fill, no atomics)
+//   ptot[b][0..2][c] = A_c, B_c, D_c = gscale * rstd * (gamma_c*A_c - T*s1/n - (s2/n)*X_c)   (D = column sum of dY, analytically)
+// The sums over the samples (dbeta, dgamma, dbias) are taken later by ew_fin_affine.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, int RS) {
-    const int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
-    if (c >= p.C) return;
-    const int g = min(c / p.Cg, p.G - 1);
+    __shared__ double smd[4];
+    const int g = blockIdx.x, b = blockIdx.y;
     const float* part = p.part + ((long)b * RS * 3) * p.C;
-    float A = 0.f, Bv = 0.f, X = 0.f;
-    for (int r = 0; r < RS; ++r) {
-        A += part[((long)r * 3 + 0) * p.C + c];
-        Bv += part[((long)r * 3 + 1) * p.C + c];
-        X += part[((long)r * 3 + 2) * p.C + c];
+    const int c_lo = g * p.Cg, c_hi = g == p.G - 1 ? p.C : (g + 1) * p.Cg;
+    double s1 = 0.0, s2 = 0.0;
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+        float A = 0.f, Bv = 0.f;
+        for (int r = 0; r < RS; ++r) {
+            A += part[((long)r * 3 + 0) * p.C + c];
+            Bv += part[((long)r * 3 + 1) * p.C + c];
+        }
+        const float gm = p.gamma[c];
+        s1 += (double)(gm * A); s2 += (double)(gm * Bv);
     }
-    atomicAdd(p.dbeta + c, A);
-    atomicAdd(p.dgamma + c, Bv);
-    if (p.dbias) {
-        const double n = (double)p.Cg * (double)p.T;
-        const double sm_ = p.sums[((long)b * p.G + g) * 2 + 0], ss_ = p.sums[((long)b * p.G + g) * 2 + 1];
-        const double mean = sm_ / n;
-        double var = ss_ / n - mean * mean;
-        if (var < 0.0) var = 0.0;
-        const float rstd = (float)(1.0 / sqrt(var + 1e-5));
-        const float m1 = (float)(p.sums2[((long)b * p.G + g) * 2 + 0] / n), m2 = (float)(p.sums2[((long)b * p.G + g) * 2 + 1] / n);
-        atomicAdd(p.dbias + c, p.gscale * rstd * (p.gamma[c] * A - (float)p.T * m1 - m2 * X));
+    const double S1 = block_sum_f64(s1, smd), S2 = block_sum_f64(s2, smd);
+    if (threadIdx.x == 0) {
+        p.sums2[((long)b * p.G + g) * 2 + 0] = S1;
+        p.sums2[((long)b * p.G + g) * 2 + 1] = S2;
+    }
+    const double n = (double)p.Cg * (double)p.T;
+    const double sm_ = p.sums[((long)b * p.G + g) * 2 + 0], ss_ = p.sums[((long)b * p.G + g) * 2 + 1];
+    const double mean = sm_ / n;
+    double var = ss_ / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+    const float rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float m1 = (float)(S1 / n), m2 = (float)(S2 / n);
+    float* pt = p.ptot + (long)b * 3 * p.C;
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+        float A = 0.f, Bv = 0.f, X = 0.f;
+        for (int r = 0; r < RS; ++r) {
+            A += part[((long)r * 3 + 0) * p.C + c];
+            Bv += part[((long)r * 3 + 1) * p.C + c];
+            X += part[((long)r * 3 + 2) * p.C + c];
+        }
+        pt[c] = A;
+        pt[(long)p.C + c] = Bv;
+        pt[2L * p.C + c] = p.gscale * rstd * (p.gamma[c] * A - (float)p.T * m1 - m2 * X);
     }
 }
 
@@ -404,6 +396,84 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
         for (int k = 0; k < 16; ++k) t += sm[k][cl];
         out[c] = t;
     }
+}
+
+// out[b*n + j] = scale * sum_{r < R} part[(b*R + r)*n + j]; one block = 16 outputs x 16 row lanes, fixed summation order
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void rowsum_kernel(const TI* part, int R, int n, TO* out, double scale) {
+    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const int j = blockIdx.x * 16 + cl, b = blockIdx.y;
+    double a = 0.0;
+    if (j < n)
+        for (int r = rl; r < R; r += 16) a += (double)part[((long)b * R + r) * n + j];
+    __shared__ double sm[16][17];
+    sm[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && j < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += sm[k][cl];
+        out[(long)b * n + j] = (TO)(t * scale);
+    }
+}
+int ew_rowsum(const float* part, int batches, int R, int n, float* out_f, double* out_d, double scale, hipStream_t s) {
+    if (batches <= 0 || n <= 0) return 0;
+    dim3 grid(cdiv_i(n, 16), batches);
+    if (out_d) hipLaunchKernelGGL((rowsum_kernel<float, double>), grid, dim3(256), 0, s, part, R, n, out_d, scale);
+    else hipLaunchKernelGGL((rowsum_kernel<float, float>), grid, dim3(256), 0, s, part, R, n, out_f, scale);
+    return 0;
+}
+int ew_rowsum_d(const double* part, int R, int n, double* out_d, double scale, hipStream_t s) {
+    if (n <= 0) return 0;
+    hipLaunchKernelGGL((rowsum_kernel<double, double>), dim3(cdiv_i(n, 16), 1), dim3(256), 0, s, part, R, n, out_d, scale);
+    return 0;
+}
+
+// <G, W_eff> scalars: block i sums its item's per-block partials in a fixed order -> dst[0]
+constexpr int FIN_MAX_ITEMS = 64;
+struct FinDotArgs { int n; int pad; FinDot it[FIN_MAX_ITEMS]; };
+__global__ __launch_bounds__(256) void fin_dot_kernel(const FinDotArgs a) {
+    __shared__ float smw[4];
+    const FinDot it = a.it[blockIdx.x];
+    float v = 0.f;
+    for (int i = threadIdx.x; i < it.count; i += 256) v += it.src[i];
+    const float t = block_sum_fixed(v, smw);
+    if (threadIdx.x == 0) it.dst[0] = t;
+}
+int ew_fin_dots(const FinDot* items, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += FIN_MAX_ITEMS) {
+        FinDotArgs a; a.n = std::min(n - i0, FIN_MAX_ITEMS); a.pad = 0;
+        for (int i = 0; i < a.n; ++i) a.it[i] = items[i0 + i];
+        hipLaunchKernelGGL(fin_dot_kernel, dim3(a.n), dim3(256), 0, s, a);
+    }
+    return 0;
+}
+// GroupNorm affine + conv bias gradients: one thread per (item, column) sums the per-sample totals in sample order
+struct FinAffineArgs { int n; int chunk0[FIN_MAX_ITEMS + 1]; FinAffine it[FIN_MAX_ITEMS]; };
+__global__ __launch_bounds__(256) void fin_affine_kernel(const FinAffineArgs a) {
+    int i = 0;
+    while (i + 1 < a.n && (int)blockIdx.x >= a.chunk0[i + 1]) ++i;
+    const FinAffine it = a.it[i];
+    const int c = ((int)blockIdx.x - a.chunk0[i]) * 256 + threadIdx.x;
+    if (c >= it.C) return;
+    float A = 0.f, Bv = 0.f, D = 0.f;
+    for (int b = 0; b < it.B; ++b) {
+        const float* pt = it.ptot + (long)b * 3 * it.C + c;
+        A += pt[0]; Bv += pt[it.C]; D += pt[2L * it.C];
+    }
+    if (it.dbeta) it.dbeta[c] = (it.accum ? it.dbeta[c] : 0.f) + A;
+    if (it.dgamma) it.dgamma[c] = (it.accum ? it.dgamma[c] : 0.f) + Bv;
+    if (it.dbias) it.dbias[c] = (it.accum ? it.dbias[c] : 0.f) + D;
+}
+int ew_fin_affine(const FinAffine* items, int n, hipStream_t s) {
+    for (int i0 = 0; i0 < n; i0 += FIN_MAX_ITEMS) {
+        FinAffineArgs a; a.n = std::min(n - i0, FIN_MAX_ITEMS);
+        int ch = 0;
+        for (int i = 0; i < a.n; ++i) { a.it[i] = items[i0 + i]; a.chunk0[i] = ch; ch += cdiv_i(a.it[i].C, 256); }
+        a.chunk0[a.n] = ch;
+        if (ch > 0) hipLaunchKernelGGL(fin_affine_kernel, dim3(ch), dim3(256), 0, s, a);
+    }
+    return 0;
 }
 
 // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) [* gscale]   (pure streaming pass: read y, dOut; write dY)
@@ -458,7 +528,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const GNParams p) {
             }
         }
     }
-    if (p.cdot) block_atomic_add(dotacc, p.cdot);
+    if (p.cdot_part) block_store_partial(dotacc, p.cdot_part);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -485,16 +555,6 @@ __device__ __forceinline__ GNSlab gn_slab(const GNParams& p) {
     c.c0 = c.g * p.Cg + c.tx * 8;
     return c;
 }
-// sum of one double per thread over the block, result broadcast to every thread (all 256 threads call)
-__device__ __forceinline__ double block_sum_f64(double v, double* sm4) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-    __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
-    __syncthreads();
-    return sm4[0] + sm4[1] + sm4[2] + sm4[3];
-}
-
 // out = [res + rscale *] act(gn(y)), statistics included; p.sums[(b*G+g)*2 + {0,1}] = sum, sum of squares (stored)
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const GNParams p) {
@@ -666,13 +726,14 @@ __global__ __launch_bounds__(GN_BWD_THREADS) void gn_bwd_fused_kernel(const GNPa
         p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
     }
     const float m1 = (float)((double)s1 / n), m2 = (float)((double)s2 / n);
-    if (owner) {
+    if (owner) {      // per-sample column totals (A, B, D): summed over the samples by ew_fin_affine
+        float* pt = p.ptot + (long)b * 3 * p.C + c0;
+        float dcol[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            atomicAdd(p.dbeta + c0 + e, col[0][e]);
-            atomicAdd(p.dgamma + c0 + e, col[1][e]);
-            if (p.dbias) atomicAdd(p.dbias + c0 + e, p.gscale * rstd * (gam[e] * col[0][e] - (float)p.T * m1 - m2 * col[2][e]));
-        }
+        for (int e = 0; e < 8; ++e) dcol[e] = p.gscale * rstd * (gam[e] * col[0][e] - (float)p.T * m1 - m2 * col[2][e]);
+        store8(pt, col[0]);
+        store8(pt + p.C, col[1]);
+        store8(pt + 2L * p.C, dcol);
     }
     // dY = rstd * (gamma*dz - s1/n - xhat*s2/n) * gscale, and <G, W_eff> += sum dY * (y - conv bias)
     float dotacc = 0.f;
@@ -698,7 +759,7 @@ __global__ __launch_bounds__(GN_BWD_THREADS) void gn_bwd_fused_kernel(const GNPa
             }
         }
     }
-    if (p.cdot) {
+    if (p.cdot_part) {
         const float w = wave_sum(dotacc);
         __syncthreads();
         if (lane == 0) smw[wave] = w;
@@ -706,7 +767,7 @@ __global__ __launch_bounds__(GN_BWD_THREADS) void gn_bwd_fused_kernel(const GNPa
         if (threadIdx.x == 0) {
             float tot = 0.f;
             for (int k = 0; k < NW; ++k) tot += smw[k];
-            atomicAdd(p.cdot + ((blockIdx.x + blockIdx.y * gridDim.x) & (SGV_DOT_SLOTS - 1)), tot);
+            p.cdot_part[blockIdx.y * gridDim.x + blockIdx.x] = tot;
         }
     }
 }
@@ -748,7 +809,7 @@ __global__ __launch_bounds__(256) void act_kernel(const GNParams p) {
             if constexpr (MODE != 2) store8(out + m * p.ldout + c.c0, v);
         }
     }
-    if (MODE != 0 && p.cdot) block_atomic_add(dotacc, p.cdot);
+    if (MODE != 0 && p.cdot_part) block_store_partial(dotacc, p.cdot_part);
     if (MODE != 0 && p.part) {
         float col[1][8];
 #pragma unroll
@@ -772,14 +833,41 @@ constexpr int GN_REDUCE_TARGET = 768;
         hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P);             \
     } while (0)
 
+static int grid_total(const dim3& g) { return (int)(g.x * g.y * g.z); }
+// Workspace layout inside p.part (floats): [per-block column sums B*RS*3*C | per-sample totals B*3*C | <G,W_eff> block partials |
+// loss block partials x2]; the forward statistics pass reuses the front for its per-block group sums.
+struct GNWork { size_t ptot, dots, lpart, total; int nblk; };
+static GNWork gn_work(int B, int T, int C) {
+    const GNGeom gr = gn_geom(B, T, C, GN_REDUCE_TARGET), ga = gn_geom(B, T, C);
+    GNWork w;
+    size_t front = (size_t)B * gr.rowsplit * 3 * C;
+    front = std::max(front, (size_t)grid_total(gr.grid) * SGV_GN_MAX_GROUPS * 2);
+    w.ptot = (front + 3) & ~(size_t)3;
+    w.dots = w.ptot + (size_t)B * 3 * C;
+    w.nblk = std::max(std::max(grid_total(gr.grid), grid_total(ga.grid)), SGV_GN_MAX_GROUPS * B);
+    w.lpart = w.dots + w.nblk;
+    w.total = w.lpart + 2 * (size_t)w.nblk;
+    return w;
+}
+size_t ew_gn_part_floats(int B, int T, int C) { return gn_work(B, T, C).total; }
+int ew_gn_max_blocks(int B, int T, int C) { return gn_work(B, T, C).nblk; }
+// deferred mode (p.ptot / p.cdot_part given): only report the partial count; else sum the partials here
+static void gn_fin_immediate(const GNParams& p, bool own_ptot, bool own_dots, int nblk, hipStream_t s) {
+    if (p.cdot_blocks) *p.cdot_blocks = nblk;
+    if (own_ptot) { FinAffine it = {p.ptot, p.dbeta, p.dgamma, p.dbias, p.C, p.B, p.accum_affine, 0}; ew_fin_affine(&it, 1, s); }
+    if (own_dots) { FinDot d = {p.cdot_part, p.cdot, nblk, 0}; ew_fin_dots(&d, 1, s); }
+}
 static void gn_finalize(GNParams p, hipStream_t s) {
     GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(cdiv_i(p.C, 256), p.B), dim3(256), 0, s, p, g_.rowsplit);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, s, p, g_.rowsplit);
 }
+// p.sums[b][g] = (sum, sum of squares), overwritten; p.part = workspace (ew_gn_part_floats)
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
+    if (!p.part) return -1;
     if (dtype == 1) GN_LAUNCH_R((gn_stats_kernel<bf16_t>), p, s);
     else GN_LAUNCH_R((gn_stats_kernel<float>), p, s);
-    return 0;
+    const GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
+    return ew_rowsum(p.part, p.B, (int)(g_.grid.x * g_.grid.y), p.G * 2, nullptr, p.sums, 1.0, s);
 }
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s) {
     if (dtype == 1) {
@@ -846,11 +934,11 @@ static bool gn_fused_bwd_ok(const GNParams& p) {
         hipLaunchKernelGGL(KERN, dim3((P).G, (P).B), dim3(NT), 0, S, P);                     \
     } while (0)
 #define GN_FUSED_LAUNCH(KERN, P, S) GN_FUSED_LAUNCH_N(KERN, 256, P, S)
-// statistics + normalise: p.sums must be zero on entry for the multi-kernel path (the fused one overwrites it)
+// statistics + normalise (p.sums is overwritten); the multi-kernel path needs the workspace p.part
 int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s) {
     if (!gn_fused_ok(p) || !p.out) {
         GNParams q = p;
-        ew_gn_stats(dtype, q, s);
+        if (ew_gn_stats(dtype, q, s)) return -1;
         return p.out ? ew_gn_apply(dtype, act, p, s) : 0;
     }
     if (dtype == 1) {
@@ -866,13 +954,23 @@ int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s) {
     }
     return 0;
 }
-// reduce + finalize + dY for act in {0 none, 1 gelu, 3 relu}; p carries both the reduce and the apply arguments
+// reduce + finalize + dY for act in {0 none, 1 gelu, 3 relu}; p carries both the reduce and the apply arguments.
+// p.part = workspace (ew_gn_part_floats).  p.ptot / p.cdot_part given: deferred mode (the caller runs ew_fin_affine /
+// ew_fin_dots later); else dbeta / dgamma / dbias / cdot[0] are final when this returns.
 int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s) {
+    if (!p.part) return -1;
+    const GNWork w = gn_work(p.B, p.T, p.C);
+    const bool own_ptot = !p.ptot, own_dots = p.cdot && !p.cdot_part;
+    if (own_ptot) p.ptot = p.part + w.ptot;
+    if (own_dots) p.cdot_part = p.part + w.dots;
+    if (!p.cdot) p.cdot_part = nullptr;
     if (!gn_fused_bwd_ok(p)) {
         GNParams q = p;
-        q.out = nullptr; q.cdot = nullptr; q.cbias = nullptr;
+        q.out = nullptr; q.cdot = nullptr; q.cdot_part = nullptr; q.cbias = nullptr;
         ew_gn_bwd_reduce_act(dtype, act, q, s);
-        return ew_gn_bwd_apply_act(dtype, act, p, s);
+        ew_gn_bwd_apply_act(dtype, act, p, s);
+        gn_fin_immediate(p, own_ptot, own_dots, grid_total(gn_geom(p.B, p.T, p.C).grid), s);
+        return 0;
     }
     if (dtype == 1) {
         if (act == 1) GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<bf16_t, 1>), GN_BWD_THREADS, p, s);
@@ -883,13 +981,16 @@ int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s) {
         else if (act == 3) GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<float, 3>), GN_BWD_THREADS, p, s);
         else GN_FUSED_LAUNCH_N((gn_bwd_fused_kernel<float, 0>), GN_BWD_THREADS, p, s);
     }
+    gn_fin_immediate(p, own_ptot, own_dots, p.G * p.B, s);
     return 0;
 }
-size_t ew_gn_part_floats(int B, int T, int C) {
-    GNGeom g_ = gn_geom(B, T, C, GN_REDUCE_TARGET);
-    return (size_t)B * g_.rowsplit * 3 * C;
-}
-int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + loss (+ bwd reduce)
+// tanh + loss (+ backward reduction): p.loss_sums[0..1] = selected loss sum, squared-error sum (overwritten);
+// train: p.sums2 and the unit-weight dbeta / dgamma / dbias are final on return.  p.part = workspace.
+int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {
+    if (!p.part) return -1;
+    const GNWork w = gn_work(p.B, p.T, p.C);
+    p.lpart = p.part + w.lpart;
+    p.ptot = p.part + w.ptot;
     if (dtype == 1 && train) {
         if (p.loss_type == 0) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true, 0>), p, s);
         else if (p.loss_type == 1) GN_LAUNCH_R((gn_bwd_reduce_kernel<bf16_t, 2, true, true, 1>), p, s);
@@ -902,18 +1003,32 @@ int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s) {  // tanh + 
         if (train) GN_LAUNCH_R((gn_bwd_reduce_kernel<float, 2, true, true>), p, s);
         else GN_LAUNCH((gn_bwd_reduce_kernel<float, 2, true, false>), p, s);
     }
-    if (train) gn_finalize(p, s);
+    const int nblk = grid_total(train ? gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET).grid : gn_geom(p.B, p.T, p.C).grid);
+    ew_rowsum(p.lpart, 1, nblk, 2, nullptr, p.loss_sums, 1.0, s);
+    if (train) {
+        gn_finalize(p, s);
+        FinAffine it = {p.ptot, p.dbeta, p.dgamma, p.dbias, p.C, p.B, 0, 0};
+        ew_fin_affine(&it, 1, s);
+    }
     return 0;
 }
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s) {
+    const bool own_dots = p.cdot && !p.cdot_part;
+    if (own_dots) { if (!p.part) return -1; p.cdot_part = p.part + gn_work(p.B, p.T, p.C).dots; }
+    if (!p.cdot) p.cdot_part = nullptr;
     if (dtype == 1) {
         if (p.loss_type == 0) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true, 0>), p, s);
         else if (p.loss_type == 1) GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true, 1>), p, s);
         else GN_LAUNCH((gn_bwd_apply_kernel<bf16_t, 2, true, 2>), p, s);
     } else GN_LAUNCH((gn_bwd_apply_kernel<float, 2, true>), p, s);
+    gn_fin_immediate(p, false, own_dots, grid_total(gn_geom(p.B, p.T, p.C).grid), s);
     return 0;
 }
 int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
+    float* const ws = p.part;
+    const bool own_dots = mode != 0 && p.cdot && !p.cdot_part;
+    if (own_dots) { if (!ws) return -1; p.cdot_part = ws + gn_work(p.B, p.T, p.C).dots; }
+    if (mode == 0 || !p.cdot) p.cdot_part = nullptr;
     if (mode == 0 || !p.dbias) p.part = nullptr;
     if (p.part) {
         if (dtype == 1) { if (mode == 1) GN_LAUNCH_R((act_kernel<bf16_t, 1>), p, s); else GN_LAUNCH_R((act_kernel<bf16_t, 2>), p, s); }
@@ -921,6 +1036,7 @@ int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
         // combine the per-block column sums into the bias gradient
         GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
         hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 16)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
+        gn_fin_immediate(p, false, own_dots, grid_total(g_.grid), s);
         return 0;
     }
     if (dtype == 1) {
@@ -932,6 +1048,7 @@ int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
         else if (mode == 1) GN_LAUNCH((act_kernel<float, 1>), p, s);
         else GN_LAUNCH((act_kernel<float, 2>), p, s);
     }
+    if (mode != 0) gn_fin_immediate(p, false, own_dots, grid_total(gn_geom(p.B, p.T, p.C).grid), s);
     return 0;
 }
 
@@ -1081,7 +1198,7 @@ int ew_latent_bwd(const float* last, const float* eps, const float* dz, float* d
 template <typename T>
 __global__ __launch_bounds__(256) void stage_fwd_kernel(const float* pz, const float* qz, const float* eps,
                                                        const T* dec_out, long ldd, T* zs_next, long ldz, float* zmap,
-                                                       int M, int C, float std_scale, double* kl_sum, float inv_b) {
+                                                       int M, int C, float std_scale, double* kl_part, float inv_b) {
     const long total = (long)M * C;
     float acc = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -1102,7 +1219,7 @@ __global__ __launch_bounds__(256) void stage_fwd_kernel(const float* pz, const f
     const float w = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(kl_sum, (double)(sm[0] + sm[1] + sm[2] + sm[3]) * (double)inv_b);
+    if (threadIdx.x == 0) kl_part[blockIdx.x] = (double)(sm[0] + sm[1] + sm[2] + sm[3]) * (double)inv_b;   // summed by ew_rowsum_d
 }
 // gradients wrt the prior output pz (g_p) and posterior output qz (g_q); coef = beta/B
 template <typename T>
@@ -1137,16 +1254,16 @@ __global__ __launch_bounds__(256) void stage_bwd_kernel(const float* pz, const f
 }
 int ew_stage_fwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dec_out, long ldd,
                  void* zs_next, long ldz, float* zmap, int M, int C, float std_scale, double* kl_sum, float inv_b,
-                 hipStream_t s) {
+                 double* kl_part, hipStream_t s) {
     int blocks = cdiv_i((long)M * C, 256);
     if (blocks > 2048) blocks = 2048;
     if (dtype == 1)
         hipLaunchKernelGGL((stage_fwd_kernel<bf16_t>), dim3(blocks), dim3(256), 0, s, pz, qz, eps, (const bf16_t*)dec_out, ldd,
-                           (bf16_t*)zs_next, ldz, zmap, M, C, std_scale, kl_sum, inv_b);
+                           (bf16_t*)zs_next, ldz, zmap, M, C, std_scale, kl_part, inv_b);
     else
         hipLaunchKernelGGL((stage_fwd_kernel<float>), dim3(blocks), dim3(256), 0, s, pz, qz, eps, (const float*)dec_out, ldd,
-                           (float*)zs_next, ldz, zmap, M, C, std_scale, kl_sum, inv_b);
-    return 0;
+                           (float*)zs_next, ldz, zmap, M, C, std_scale, kl_part, inv_b);
+    return ew_rowsum_d(kl_part, blocks, 1, kl_sum, 1.0, s);
 }
 int ew_stage_bwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dzs, long ldd, void* g_p,
                  void* g_q, int M, int C, float coef, hipStream_t s) {
@@ -1164,7 +1281,7 @@ int ew_stage_bwd(int dtype, const float* pz, const float* qz, const float* eps, 
 // ------------------------------------------------------------------------------------------
 // small Linear layers (fp32 master weights, scale = 1/sigma from the spectral-norm pass)
 // ------------------------------------------------------------------------------------------
-// "head": Y[b][o] (fp32, pre-zeroed) += scale * sum_k X[b][k] W[o][k]  (+ bias once); K large, O small
+// "head": part[kz][b][o] = scale * sum_{k in slice kz} X[b][k] W[o][k]  (+ bias in slice 0); K large, O small; ew_rowsum adds the slices
 template <typename TX>
 __global__ __launch_bounds__(256) void linear_head_fwd_kernel(const TX* X, const float* W, const float* bias,
                                                              const float* scale, float* Y, int B, int K, int O) {
@@ -1203,7 +1320,7 @@ __global__ __launch_bounds__(256) void linear_head_fwd_kernel(const TX* X, const
         if (threadIdx.x < BG && b0 + (int)threadIdx.x < B) {
             float t = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) * sc;
             if (kz == 0 && bias) t += bias[o];
-            atomicAdd(&Y[(long)(b0 + threadIdx.x) * O + o], t);
+            Y[((long)kz * B + (b0 + threadIdx.x)) * O + o] = t;
         }
     }
 }
@@ -1258,15 +1375,14 @@ __global__ __launch_bounds__(256) void linear_head_bwd_dw_kernel(const float* dY
     }
 }
 int ew_linear_head_fwd(int xdtype, const void* X, const float* W, const float* bias, const float* scale, float* Y, int B,
-                       int K, int O, hipStream_t s) {
-    hipMemsetAsync(Y, 0, sizeof(float) * (size_t)B * O, s);
+                       int K, int O, float* part, hipStream_t s) {
     int ks = cdiv_i(K / 8, 512);       // two vectors per thread: the pass is latency-bound, not bandwidth-bound
     if (ks < 1) ks = 1;
     if (ks > 128) ks = 128;
     dim3 grid(O, ks);
-    if (xdtype == 1) hipLaunchKernelGGL((linear_head_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, W, bias, scale, Y, B, K, O);
-    else hipLaunchKernelGGL((linear_head_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)X, W, bias, scale, Y, B, K, O);
-    return 0;
+    if (xdtype == 1) hipLaunchKernelGGL((linear_head_fwd_kernel<bf16_t>), grid, dim3(256), 0, s, (const bf16_t*)X, W, bias, scale, part, B, K, O);
+    else hipLaunchKernelGGL((linear_head_fwd_kernel<float>), grid, dim3(256), 0, s, (const float*)X, W, bias, scale, part, B, K, O);
+    return ew_rowsum(part, 1, ks, B * O, Y, nullptr, 1.0, s);
 }
 int ew_linear_head_bwd(int xdtype, const float* dY, const void* X, const float* W, const float* scale, const void* addend,
                        void* dX, float* dW, float* db, int B, int K, int O, hipStream_t s) {

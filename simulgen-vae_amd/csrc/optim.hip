@@ -8,7 +8,7 @@
 // Weights are [taps][rows][cols] fp32 (cols contiguous); u is [rows], v is [taps*cols].
 #include "sgv_ew.h"
 
-// ---- pass 1: tmp_t[tap][c] += sum_r W[tap][r][c] * u[r] over a 64-row x 1024-col block ----------
+// ---- pass 1: tpart[row block][tap][c] = sum_{r in block} W[tap][r][c] * u[r] over a 64-row x 1024-col block ----------
 __global__ __launch_bounds__(256) void sn_wt_u_kernel(const SNDesc* descs, const WorkItem* items) {
     const WorkItem it = items[blockIdx.x];
     const SNDesc d = descs[it.desc];
@@ -26,8 +26,34 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const SNDesc* descs, const
         const float ur = d.u[r];
         a0 += w.x * ur; a1 += w.y * ur; a2 += w.z * ur; a3 += w.w * ur;
     }
-    float* t = d.tmp_t + (long)tap * d.cols + c;
-    atomicAdd(t + 0, a0); atomicAdd(t + 1, a1); atomicAdd(t + 2, a2); atomicAdd(t + 3, a3);
+    float* t = d.tpart + ((long)(r_lo / SN_ROWS_PER_ITEM) * d.taps + tap) * d.cols + c;
+    *reinterpret_cast<float4*>(t) = make_float4(a0, a1, a2, a3);
+}
+// tmp_t[i] = sum over the row blocks, in block order, of tpart[block][i]; item = (desc, chunk of 1024 elements of taps*cols)
+__global__ __launch_bounds__(256) void sn_tsum_kernel(const SNDesc* descs, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const SNDesc d = descs[it.desc];
+    const long n = (long)d.taps * d.cols;
+    const long i = (long)it.chunk * 1024 + threadIdx.x * 4;
+    if (i >= n) return;
+    const int rb = (d.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int r = 0; r < rb; ++r) {
+        const float4 v = *reinterpret_cast<const float4*>(d.tpart + (long)r * n + i);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    }
+    *reinterpret_cast<float4*>(d.tmp_t + i) = a;
+}
+// tmp_s[r] = sum over the (tap, column block) partials in index order; item = (desc, chunk of 1024 rows)
+__global__ __launch_bounds__(256) void sn_ssum_kernel(const SNDesc* descs, const WorkItem* items) {
+    const WorkItem it = items[blockIdx.x];
+    const SNDesc d = descs[it.desc];
+    const int np = d.taps * ((d.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM);
+    for (int r = it.chunk * 1024 + threadIdx.x; r < min(d.rows, (it.chunk + 1) * 1024); r += 256) {
+        float a = 0.f;
+        for (int k = 0; k < np; ++k) a += d.spart[(long)k * d.rows + r];
+        d.tmp_s[r] = a;
+    }
 }
 
 // ---- pass 2: v = t / max(||t||, 1e-12) ------------------------------------------------------------
@@ -70,7 +96,7 @@ __global__ __launch_bounds__(1024) void sn_norm_v_kernel(const SNDesc* descs, in
     block1024_scale(d.tmp_t, d.v, inv, n);
 }
 
-// ---- pass 3: tmp_s[r] += sum_c W[tap][r][c] * v[tap][c]; one wave per row ---------------------------
+// ---- pass 3: spart[(tap, col block)][r] = sum_{c in block} W[tap][r][c] * v[tap][c]; one wave per row ---------------------------
 __global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const WorkItem* items) {
     const WorkItem it = items[blockIdx.x];
     const SNDesc d = descs[it.desc];
@@ -84,6 +110,7 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const 
     const int r_hi = min(d.rows, r_lo + SN_ROWS_PER_ITEM);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const float* vv = d.v + (long)tap * d.cols;
+    float* sp = d.spart + ((long)tap * cb + (rem % cb)) * d.rows;
     if (d.wc) {   // bf16 engine: the GEMMs multiply by this copy, and it is half the bytes of the master
         const unsigned short* Wc = reinterpret_cast<const unsigned short*>(d.wc);
         for (int r = r_lo + wave; r < r_hi; r += 4) {
@@ -98,7 +125,7 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const 
                      + __uint_as_float(q.w << 16) * x1.z + __uint_as_float(q.w & 0xffff0000u) * x1.w;
             }
             acc = wave_sum(acc);
-            if (lane == 0) atomicAdd(d.tmp_s + r, acc);
+            if (lane == 0) sp[r] = acc;
         }
         return;
     }
@@ -111,7 +138,7 @@ __global__ __launch_bounds__(256) void sn_w_v_kernel(const SNDesc* descs, const 
             acc += w.x * x.x + w.y * x.y + w.z * x.z + w.w * x.w;
         }
         acc = wave_sum(acc);
-        if (lane == 0) atomicAdd(d.tmp_s + r, acc);
+        if (lane == 0) sp[r] = acc;
     }
 }
 
@@ -136,18 +163,20 @@ __global__ __launch_bounds__(1024) void sn_norm_u_kernel(const SNDesc* descs, in
 }
 
 int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,
-                           int ndesc, int train, hipStream_t s) {
+                           const WorkItem* items_ts, int n_ts, const WorkItem* items_ss, int n_ss, int ndesc, int train, hipStream_t s) {
     if (train) {
         if (n1 > 0) hipLaunchKernelGGL(sn_wt_u_kernel, dim3(n1), dim3(256), 0, s, descs_dev, items1);
+        if (n_ts > 0) hipLaunchKernelGGL(sn_tsum_kernel, dim3(n_ts), dim3(256), 0, s, descs_dev, items_ts);
         hipLaunchKernelGGL(sn_norm_v_kernel, dim3(ndesc), dim3(1024), 0, s, descs_dev, ndesc);
     }
     if (n3 > 0) hipLaunchKernelGGL(sn_w_v_kernel, dim3(n3), dim3(256), 0, s, descs_dev, items3);
+    if (n_ss > 0) hipLaunchKernelGGL(sn_ssum_kernel, dim3(n_ss), dim3(256), 0, s, descs_dev, items_ss);
     hipLaunchKernelGGL(sn_norm_u_kernel, dim3(ndesc), dim3(1024), 0, s, descs_dev, train);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ---- <G, W> per spectrally-normalised weight ---------------------------------------------------------
-__global__ __launch_bounds__(256) void sn_grad_dot_kernel(const SNDesc* descs, const WorkItem* items) {
+__global__ __launch_bounds__(256) void sn_grad_dot_kernel(const SNDesc* descs, const WorkItem* items, float* dot_part) {
     const WorkItem it = items[blockIdx.x];
     const SNDesc d = descs[it.desc];
     const long n = (long)d.taps * d.rows * d.cols;
@@ -165,10 +194,10 @@ __global__ __launch_bounds__(256) void sn_grad_dot_kernel(const SNDesc* descs, c
     __syncthreads();
     // <G, W_eff> = <G, W> / sigma.  Only the small Linear layers take this weight-sized route; conv layers get
     // the same number as sum dY*(y - bias) inside their dY-producing kernels (ew.hip).
-    if (threadIdx.x == 0) atomicAdd(d.dot, (sm[0] + sm[1] + sm[2] + sm[3]) * d.sigma[1]);
+    if (threadIdx.x == 0) dot_part[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) * d.sigma[1];
 }
-int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipStream_t s) {
-    if (n > 0) hipLaunchKernelGGL(sn_grad_dot_kernel, dim3(n), dim3(256), 0, s, descs_dev, items);
+int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, float* dot_part, hipStream_t s) {
+    if (n > 0) hipLaunchKernelGGL(sn_grad_dot_kernel, dim3(n), dim3(256), 0, s, descs_dev, items, dot_part);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
@@ -235,12 +264,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
     const float w = wave_sum(nacc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(gnorm_sq, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+    if (threadIdx.x == 0) gnorm_sq[blockIdx.x] = (double)(sm[0] + sm[1] + sm[2] + sm[3]);      // per-item partial, summed in index order later
 }
 // ---- AdamW over 64x64 tiles of the spectrally-normalised conv weights ------------------------------
 // Same update as adamw_kernel, plus everything else that needs the freshly updated weight while it is in
 // registers: the compute-dtype copy wc, the transposed/tap-flipped copy wct (through an LDS tile) and the
-// first half of the NEXT forward's power iteration, tmp_t[tap][c] += sum_r W_new[r][c] * u[r]  (u is only
+// first half of the NEXT forward's power iteration, tpart[row tile][tap][c] = sum_{r in tile} W_new[r][c] * u[r]  (u is only
 // modified by the forward itself).  Saves two full passes over the 1.6 GB of master weights per step.
 template <typename T>
 __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
@@ -312,12 +341,12 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
     const float w = wave_sum(nacc);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = w;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(gnorm_sq, (double)(sm[0] + sm[1] + sm[2] + sm[3]));
+    if (threadIdx.x == 0) gnorm_sq[blockIdx.x] = (double)(sm[0] + sm[1] + sm[2] + sm[3]);      // per-item partial, summed in index order later
     if (threadIdx.x < 64 && c0 + (int)threadIdx.x < a.cols) {
         float t = 0.f;
 #pragma unroll
         for (int k = 0; k < 16; ++k) t += tus[k][threadIdx.x];
-        atomicAdd(d.tmp_t + (long)tap * a.cols + c0 + threadIdx.x, t);
+        d.tpart[((long)(r0 >> 6) * a.taps + tap) * a.cols + c0 + threadIdx.x] = t;
     }
     if (a.wct) {
         T* dst = reinterpret_cast<T*>(a.wct) + (long)(a.taps - 1 - tap) * a.rows * a.cols;

@@ -17,10 +17,11 @@ struct sgv_pset {
     std::vector<AdamDesc> adam;
     std::vector<int> sn_of_entry;                 // entry -> index into sn, or -1
     SNDesc* sn_dev = nullptr; AdamDesc* adam_dev = nullptr;
-    WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr;
-    int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0;
-    float *mv = nullptr, *sigma = nullptr, *dots = nullptr, *tmp = nullptr, *coef = nullptr;
-    double* gnorm = nullptr;
+    WorkItem *items_sn = nullptr, *items_dot = nullptr, *items_adam = nullptr, *items_ts = nullptr, *items_ss = nullptr;
+    int n_items_sn = 0, n_items_dot = 0, n_items_adam = 0, n_items_ts = 0, n_items_ss = 0;
+    float *mv = nullptr, *sigma = nullptr, *dots = nullptr, *tmp = nullptr, *coef = nullptr, *dot_part = nullptr;
+    double *gnorm = nullptr, *gnorm_part = nullptr;      // gnorm_part: one partial per AdamW work item, summed in index order (no atomics)
+    std::vector<FinDot> fin_dots;
     size_t n_tmp = 0, n_dots = 0;
     int step = 0;
 };
@@ -37,7 +38,7 @@ extern "C" {
 
 int sgv_pset_destroy(sgv_pset* ps) {
     if (!ps) return 0;
-    void* ptrs[] = {ps->sn_dev, ps->adam_dev, ps->items_sn, ps->items_dot, ps->items_adam, ps->mv, ps->sigma, ps->dots, ps->tmp, ps->coef, ps->gnorm};
+    void* ptrs[] = {ps->sn_dev, ps->adam_dev, ps->items_sn, ps->items_dot, ps->items_adam, ps->items_ts, ps->items_ss, ps->mv, ps->sigma, ps->dots, ps->tmp, ps->coef, ps->gnorm, ps->dot_part, ps->gnorm_part};
     for (void* p : ptrs) if (p) hipFree(p);
     delete ps;
     return 0;
@@ -60,6 +61,7 @@ int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out) {
             }
             ++n_sn;
             n_tmp += al4(e.cols) + al4(e.rows);
+            n_tmp += al4((size_t)((e.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM) * e.cols) + al4((size_t)((e.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM) * e.rows);
         }
         total += al4(e.n);
     }
@@ -78,7 +80,7 @@ int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out) {
     PS_ALLOC(ps->tmp, n_tmp * sizeof(float));
     PS_ALLOC(ps->coef, 2 * sizeof(float));
     PS_ALLOC(ps->gnorm, sizeof(double));
-    std::vector<WorkItem> i_sn, i_dot, i_adam;
+    std::vector<WorkItem> i_sn, i_dot, i_adam, i_ts, i_ss;
     size_t off = 0, toff = 0;
     ps->sn_of_entry.assign(n, -1);
     for (int i = 0; i < n; ++i) {
@@ -92,6 +94,8 @@ int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out) {
             d.W = e.p; d.u = e.u; d.v = e.v;
             d.tmp_t = ps->tmp + toff; toff += al4(e.cols);
             d.tmp_s = ps->tmp + toff; toff += al4(e.rows);
+            d.tpart = ps->tmp + toff; toff += al4((size_t)((e.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM) * e.cols);
+            d.spart = ps->tmp + toff; toff += al4((size_t)((e.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM) * e.rows);
             d.sigma = ps->sigma + 2 * si; d.dot = ps->dots + (size_t)si * SGV_DOT_SLOTS; d.G = e.g;
             d.taps = 1; d.rows = e.rows; d.cols = e.cols; d.active = 1;
             ps->sn.push_back(d);
@@ -99,6 +103,9 @@ int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out) {
             a.sn = si; a.rows = e.rows; a.cols = e.cols;
             const int rb = (e.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (e.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
             for (int c = 0; c < rb * cb; ++c) i_sn.push_back({si, c});
+            for (int c = 0; c < (e.cols + 1023) / 1024; ++c) i_ts.push_back({si, c});
+            for (int c = 0; c < (e.rows + 1023) / 1024; ++c) i_ss.push_back({si, c});
+            ps->fin_dots.push_back({(const float*)(uintptr_t)i_dot.size(), d.dot, (int)((e.n + OPT_CHUNK - 1) / OPT_CHUNK), 0});
             for (long c = 0; c < (e.n + OPT_CHUNK - 1) / OPT_CHUNK; ++c) i_dot.push_back({si, (int)c});
         }
         const int id = (int)ps->adam.size();
@@ -111,11 +118,16 @@ int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out) {
     };
     if (!up(ps->sn.data(), sizeof(SNDesc) * ps->sn.size(), (void**)&ps->sn_dev) || !up(ps->adam.data(), sizeof(AdamDesc) * ps->adam.size(), (void**)&ps->adam_dev) ||
         !up(i_sn.data(), sizeof(WorkItem) * i_sn.size(), (void**)&ps->items_sn) || !up(i_dot.data(), sizeof(WorkItem) * i_dot.size(), (void**)&ps->items_dot) ||
-        !up(i_adam.data(), sizeof(WorkItem) * i_adam.size(), (void**)&ps->items_adam)) {
+        !up(i_adam.data(), sizeof(WorkItem) * i_adam.size(), (void**)&ps->items_adam) ||
+        !up(i_ts.data(), sizeof(WorkItem) * i_ts.size(), (void**)&ps->items_ts) || !up(i_ss.data(), sizeof(WorkItem) * i_ss.size(), (void**)&ps->items_ss)) {
         sgv_pset_destroy(ps);
         return sgv_set_error(-2, "sgv_pset_create: table upload failed");
     }
     ps->n_items_sn = (int)i_sn.size(); ps->n_items_dot = (int)i_dot.size(); ps->n_items_adam = (int)i_adam.size();
+    ps->n_items_ts = (int)i_ts.size(); ps->n_items_ss = (int)i_ss.size();
+    PS_ALLOC(ps->dot_part, (i_dot.size() ? i_dot.size() : 1) * sizeof(float));
+    PS_ALLOC(ps->gnorm_part, (i_adam.size() ? i_adam.size() : 1) * sizeof(double));
+    for (auto& f : ps->fin_dots) f.src = ps->dot_part + (size_t)(uintptr_t)f.src;
     *out = ps;
     return 0;
 }
@@ -124,8 +136,8 @@ int sgv_pset_power_iteration(sgv_pset* ps, int train, void* stream) {
     if (!ps) return sgv_set_error(-1, "null parameter set");
     if (ps->sn.empty()) return 0;
     hipStream_t s = (hipStream_t)stream;
-    if (hipMemsetAsync(ps->tmp, 0, ps->n_tmp * sizeof(float), s) != hipSuccess) return sgv_set_error(-2, "memset failed");
-    if (opt_sn_power_iteration(ps->sn_dev, ps->items_sn, ps->n_items_sn, ps->items_sn, ps->n_items_sn, (int)ps->sn.size(), train, s))
+    if (opt_sn_power_iteration(ps->sn_dev, ps->items_sn, ps->n_items_sn, ps->items_sn, ps->n_items_sn, ps->items_ts, ps->n_items_ts,
+                               ps->items_ss, ps->n_items_ss, (int)ps->sn.size(), train, s))
         return sgv_set_error(-2, "power-iteration launch failed");
     return 0;
 }
@@ -141,13 +153,13 @@ int sgv_pset_step(sgv_pset* ps, float lr, float weight_decay, float max_norm, fl
     ps->step += 1;
     const double b1 = 0.9, b2 = 0.999;
     const float bc1 = (float)(1.0 - pow(b1, (double)ps->step)), bc2s = (float)sqrt(1.0 - pow(b2, (double)ps->step));
-    if (hipMemsetAsync(ps->dots, 0, ps->n_dots * sizeof(float), s) != hipSuccess || hipMemsetAsync(ps->gnorm, 0, sizeof(double), s) != hipSuccess)
-        return sgv_set_error(-2, "memset failed");
-    if (opt_sn_grad_dot(ps->sn_dev, ps->items_dot, ps->n_items_dot, s)) return sgv_set_error(-2, "grad-dot launch failed");
-    if (opt_grad_norm(ps->adam_dev, ps->sn_dev, ps->items_adam, ps->n_items_adam, ps->gnorm, s)) return sgv_set_error(-2, "grad-norm launch failed");
+    // <G,W>/sigma per spectrally-normalised tensor and the gradient norm: per-work-item partials, summed in a fixed order
+    if (opt_sn_grad_dot(ps->sn_dev, ps->items_dot, ps->n_items_dot, ps->dot_part, s)) return sgv_set_error(-2, "grad-dot launch failed");
+    if (!ps->fin_dots.empty()) ew_fin_dots(ps->fin_dots.data(), (int)ps->fin_dots.size(), s);
+    if (opt_grad_norm(ps->adam_dev, ps->sn_dev, ps->items_adam, ps->n_items_adam, ps->gnorm_part, s)) return sgv_set_error(-2, "grad-norm launch failed");
+    ew_rowsum_d(ps->gnorm_part, ps->n_items_adam, 1, ps->gnorm, 1.0, s);
     hipLaunchKernelGGL(pset_clip_coef_kernel, dim3(1), dim3(1), 0, s, ps->gnorm, max_norm, ps->coef);
-    if (hipMemsetAsync(ps->gnorm, 0, sizeof(double), s) != hipSuccess) return sgv_set_error(-2, "memset failed");
-    if (opt_adamw(ps->adam_dev, ps->sn_dev, ps->items_adam, ps->n_items_adam, lr, (float)b1, (float)b2, 1e-8f, weight_decay, bc1, bc2s, ps->gnorm, 0, s, ps->coef))
+    if (opt_adamw(ps->adam_dev, ps->sn_dev, ps->items_adam, ps->n_items_adam, lr, (float)b1, (float)b2, 1e-8f, weight_decay, bc1, bc2s, ps->gnorm_part, 0, s, ps->coef))
         return sgv_set_error(-2, "adamw launch failed");
     if (total_norm_host) {
         float h[2] = {0.f, 0.f};

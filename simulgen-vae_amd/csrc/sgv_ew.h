@@ -13,12 +13,19 @@ struct GNParams {
     float* dbeta = nullptr;
     float* dbias = nullptr;                        // bias gradient of the producing conv
     float* part = nullptr;                         // workspace for per-block column sums (ew_gn_part_floats)
-    float* cdot = nullptr;                         // += sum dY*(y - cbias) = <G, W_eff> of the producing conv
+    float* cdot = nullptr;                         // <G, W_eff> = sum dY*(y - cbias) of the producing conv (slot 0 of its dot slots)
+    float* cdot_part = nullptr;                    // deferred mode: one partial per block of the dY-producing launch goes here and the
+    int* cdot_blocks = nullptr;                    //   caller sums them later (ew_fin_dots); *cdot_blocks (host) = how many were written.
+                                                   //   null: the launcher sums them into cdot[0] itself (workspace: p.part)
+    float* ptot = nullptr;                         // deferred mode: [B][3][C] per-sample column totals (sum dz, sum dz*xhat, bias-gradient
+                                                   //   term) for ew_fin_affine; null: the launcher finalises dbeta / dgamma / dbias itself
     const float* cbias = nullptr;                  // that conv's bias
     const float* yf32 = nullptr; long ldyf = 0;    // act mode 2: the conv output (fp32) paired with dY in `y`
     double* sums = nullptr;                        // [B*G][2] sum, sum of squares
     double* sums2 = nullptr;                       // [B*G][2] backward group sums
     double* loss_sums = nullptr;                   // [2]
+    int accum_affine = 0;                          // immediate mode: dbeta / dgamma / dbias += instead of =
+    float* lpart = nullptr;                        // recon loss: per-block (selected, squared) partial sums (workspace)
     int B = 0, T = 0, C = 0, G = 1, Cg = 1, CV = 1;
     float rscale = 1.f;                            // residual / incoming-gradient scale
     float gscale = 1.f;                            // output gradient scale (loss weight)
@@ -26,6 +33,16 @@ struct GNParams {
 };
 
 constexpr int SGV_GN_MAX_GROUPS = 32;
+// Deterministic reductions: no kernel of the step accumulates floating-point values with atomics.  Block partials go to
+// workspaces and are summed in a fixed order, either by the launcher itself or, for quantities nobody needs before the
+// optimizer (GroupNorm affine / bias gradients, <G, W_eff>), by two table-driven passes the engine runs once per bucket.
+struct FinDot { const float* src; float* dst; int count; int pad; };                      // dst[0] = sum src[0..count)
+struct FinAffine { const float* ptot; float* dbeta; float* dgamma; float* dbias; int C; int B; int accum; int pad; };   // d*[c] (+)= sum_b ptot[b][k][c]
+int ew_fin_dots(const FinDot* items_host, int n, hipStream_t s);
+int ew_fin_affine(const FinAffine* items_host, int n, hipStream_t s);
+// out[b*n + j] = scale * sum_{r<R} part[(b*R + r)*n + j] in a fixed order (out_f or out_d, the other null)
+int ew_rowsum(const float* part, int batches, int R, int n, float* out_f, double* out_d, double scale, hipStream_t s);
+int ew_rowsum_d(const double* part, int R, int n, double* out_d, double scale, hipStream_t s);
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s);
 // whole GroupNorm passes: one fused launch when a (sample, group) slab is small, else the multi-kernel path
 int ew_gn_fwd(int dtype, int act, GNParams p, hipStream_t s);   // stats (p.sums zeroed by the caller) + apply
@@ -34,6 +51,7 @@ int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // ac
 int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
 size_t ew_gn_part_floats(int B, int T, int C);
+int ew_gn_max_blocks(int B, int T, int C);          // upper bound of the per-block <G,W_eff> partials one launch writes
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s);
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s);
 int ew_act(int dtype, int mode, GNParams p, hipStream_t s);
@@ -46,11 +64,11 @@ int ew_latent_fwd(const float* last, const float* eps, float* z, int B, int Z, d
 int ew_latent_bwd(const float* last, const float* eps, const float* dz, float* dlast, int B, int Z, float coef, hipStream_t s);
 int ew_stage_fwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dec_out, long ldd,
                  void* zs_next, long ldz, float* zmap, int M, int C, float std_scale, double* kl_sum, float inv_b,
-                 hipStream_t s);
+                 double* kl_part, hipStream_t s);      // kl_part: workspace of >= 2048 doubles (per-block partials)
 int ew_stage_bwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dzs, long ldd, void* g_p,
                  void* g_q, int M, int C, float coef, hipStream_t s);
 int ew_linear_head_fwd(int xdtype, const void* X, const float* W, const float* bias, const float* scale, float* Y, int B,
-                       int K, int O, hipStream_t s);
+                       int K, int O, float* part, hipStream_t s);   // part: workspace of >= 128 * B * O floats (K-slice partials)
 int ew_linear_head_bwd(int xdtype, const float* dY, const void* X, const float* W, const float* scale, const void* addend,
                        void* dX, float* dW, float* db, int B, int K, int O, hipStream_t s);
 int ew_linear_expand_fwd(int dtype, const float* X, const float* W, const float* bias, const float* scale, void* Y, int B,
@@ -77,6 +95,8 @@ struct SNDesc {
     float* v;          // [taps*cols], internal order (tap, col)
     float* tmp_t;      // [taps*cols] scratch: W^T u
     float* tmp_s;      // [rows]      scratch: W v
+    float* tpart;      // [ceil(rows/64)][taps*cols] partials of W^T u per 64-row block (summed in block order by sn_tsum_kernel)
+    float* spart;      // [taps*ceil(cols/1024)][rows] partials of W v per (tap, 1024-column block) (summed by sn_ssum_kernel)
     float* sigma;      // [2]: sigma, 1/sigma
     float* dot;        // [SGV_DOT_SLOTS] partial <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
     const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
@@ -100,11 +120,15 @@ struct WorkItem { int desc; int chunk; };
 // (summed by the AdamW pass) so the adds do not serialise on one address.
 constexpr int SGV_DOT_SLOTS = 32;
 
+// items_ts / items_ss: (desc, 1024-element chunk of taps*cols / of rows) for the fixed-order partial sums
 int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,
-                           int ndesc, int train, hipStream_t s);
-int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, hipStream_t s);
+                           const WorkItem* items_ts, int n_ts, const WorkItem* items_ss, int n_ss, int ndesc, int train, hipStream_t s);
+// dot_part[i] = <G, W> / sigma of work item i (summed per layer by ew_fin_dots)
+int opt_sn_grad_dot(const SNDesc* descs_dev, const WorkItem* items, int n, float* dot_part, hipStream_t s);
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
-              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* gscale = nullptr);
+              float eps, float wd, float bc1, float bc2sqrt, double* gnorm_part, int compute_dtype, hipStream_t s, const float* gscale = nullptr);
+// gnorm_part: one double per work item (the block's sum of squared gradients), written at gnorm_part[blockIdx.x]: pass the
+// table base + the offset of `items` in the table; the caller sums the whole table in index order (ew_rowsum_d)
 // 64x64-tile AdamW for spectrally-normalised conv weights; also writes wc/wct and accumulates W_new^T u into tmp_t
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s);

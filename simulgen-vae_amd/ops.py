@@ -40,7 +40,7 @@ def lib():
             "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp, i, vp],
             "sgv_op_gemm_tn_splitk": [i, i, i, i],
             "sgv_op_matvec_t": [vp, vp, vp, i, i, vp],
-            "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp],
+            "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp, vp],
             "sgv_op_gn_workspace_floats": [i, i, i],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
             "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
@@ -162,7 +162,8 @@ def gn_fwd(y, G, gamma, beta, act):
     B, P, Cc = y.shape
     out = torch.empty_like(y)
     sums = torch.empty(B * G * 2, dtype=torch.float64, device=y.device)
-    _ck(lib().sgv_op_gn_fwd(_d(y), act, _p(y), _p(out), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _stream()), "sgv_op_gn_fwd")
+    part = torch.empty(int(lib().sgv_op_gn_workspace_floats(B, P, Cc)), dtype=torch.float32, device=y.device)
+    _ck(lib().sgv_op_gn_fwd(_d(y), act, _p(y), _p(out), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _p(part), _stream()), "sgv_op_gn_fwd")
     return out, sums
 
 

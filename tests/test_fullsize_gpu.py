@@ -24,11 +24,12 @@ BIG = ["encoder.encoder_blocks.0.module_list.0._seq.0.weight_orig", "decoder.rec
        "decoder.recon.0.bias"]
 
 
-# Stated tolerances (rel-L2 on whole gradient tensors).  fp32 compute: run-to-run differences come only from float
-# atomic ordering (~1e-6).  bf16 compute (the bench dtype): a 1e-7 perturbation of a spectral norm flips bf16
-# roundings of stored maps and decorrelates two runs at the bf16 noise floor of this 40-layer net (measured 1.1e-2
-# on the first-layer gradient for two IDENTICAL runs), so bf16 can only be held to 3e-2.
-TOL = {"f32": 1e-3, "bf16": 3e-2}
+# Stated tolerances (rel-L2 on whole gradient tensors).  The step is deterministic (no floating-point atomics: every
+# cross-block sum is a fixed-order reduction of stored partials), so an identical replay is compared BITWISE
+# (test_fullsize_replay_is_bitwise).  Between different-but-equivalent computations (a scaled loss, two half batches)
+# fp32 differs by rounding only; bf16 (the bench dtype) differs by the bf16 rounding of the stored maps, which a different
+# batch split or loss scale re-draws: 1e-2 bounds it at this size.
+TOL = {"f32": 1e-3, "bf16": 1e-2}
 
 
 @pytest.fixture(scope="module", params=["f32", "bf16"])
@@ -62,12 +63,8 @@ def test_fullsize_step_properties(full):
     sc1, g1, n1 = _grads(eng, uv, x, eps, ALPHA, BETA, BIG)
     assert np.isfinite(sc1["recon"]) and all(np.isfinite(k) for k in sc1["kls"]) and np.isfinite(n1) and n1 > 0
     assert sc1["recon"] == sc1["mse"]                       # lossfun == MSE: both reductions are the same number
-    # same inputs, same eps, same u/v -> same scalars (reductions use fp64 atomics: order-insensitive to ~1e-12)
-    sc1b, g1b, n1b = _grads(eng, uv, x, eps, ALPHA, BETA, BIG[:2])
-    assert abs(sc1b["recon"] - sc1["recon"]) <= eng.tol * 1e-2 * abs(sc1["recon"])
-    for k in BIG[:2]:
-        assert rel_l2(g1b[k], g1[k]) < eng.tol, k
-    # backward is linear in (alpha, beta); a factor 2 is exact in floating point up to atomic ordering
+    # backward is linear in (alpha, beta); a factor 2 is exact in floating point (power of two), except for bf16 maps whose
+    # rounding moves with the scale of what they store
     _, g2, n2 = _grads(eng, uv, x, eps, 2 * ALPHA, 2 * BETA, BIG)
     assert abs(n2 - 2 * n1) <= eng.tol * n2
     for k in BIG:
@@ -77,6 +74,19 @@ def test_fullsize_step_properties(full):
     assert abs(eng.last_grad_norm() - n2) <= 1e-4 * n2
     sc3 = eng.forward(train=False)
     assert np.isfinite(sc3["recon"])
+
+
+def test_fullsize_replay_is_bitwise(full):
+    """The same full-size step twice (same weights, u/v, input, eps): every scalar, every gradient tensor checked and the
+    gradient norm are BITWISE equal -- no floating-point atomics anywhere on the path (deterministic
+    two-stage reductions; the reference's CPU path is bit-reproducible too)."""
+    cfg, eng, uv, x, eps = full
+    sc_a, g_a, n_a = _grads(eng, uv, x, eps, ALPHA, BETA, BIG)
+    sc_b, g_b, n_b = _grads(eng, uv, x, eps, ALPHA, BETA, BIG)
+    assert sc_a["recon"] == sc_b["recon"] and sc_a["mse"] == sc_b["mse"] and list(sc_a["kls"]) == list(sc_b["kls"])
+    assert n_a == n_b
+    for k in BIG:
+        assert np.array_equal(g_a[k], g_b[k]), k
 
 
 def test_fullsize_shard_mean_gradient_equals_full_batch(full):
@@ -105,9 +115,9 @@ def test_fullsize_fix_roundtrip_matches_eval_forward(full):
     eng.set_eps([torch.zeros_like(e[:4]).contiguous() for e in eps])
     eng.decode(torch.from_numpy(mu).cuda(), [torch.from_numpy(v).cuda() for v in xs], fix=True)
     xh_dec = eng.xhat()
-    # same kernels on the same inputs; the two runs differ only through float-atomic ordering in the spectral-norm
-    # sigma (eval mode recomputes u.(Wv)), which flips bf16 roundings of stored maps: bounded in the mean, and a few
-    # of the 76 M outputs move by a couple of bf16 ulps of a pre-tanh value
+    # same kernels on the same inputs: the two paths differ only in where a map is rounded to bf16 (encode() exports
+    # mu / xs through fp32 host buffers): bounded in the mean, and a few of the 76 M outputs move by a couple of bf16
+    # ulps of a pre-tanh value
     d = (xh_dec - xh_fwd).abs()
     assert float(d.mean()) < (1e-5 if eng.tol < 1e-2 else 2e-3), float(d.mean())
     assert float(d.max()) < (1e-3 if eng.tol < 1e-2 else 0.15), float(d.max())
