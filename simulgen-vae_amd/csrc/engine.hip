@@ -650,8 +650,8 @@ static int upload_tables(sgv_engine* e) {
         if (l.used) {
             const int rb = (l.cout + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (l.cin + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
             for (int c = 0; c < l.k * rb * cb; ++c) { i_sn.push_back({i, c}); if (!layer_fused_adam(l)) i_sn_unf.push_back({i, c}); }
-            for (int c = 0; c < (l.k * l.cin + 1023) / 1024; ++c) i_ts.push_back({i, c});
-            for (int c = 0; c < (l.cout + 1023) / 1024; ++c) i_ss.push_back({i, c});
+            for (int c = 0; c < (l.k * l.cin + 63) / 64; ++c) i_ts.push_back({i, c});
+            for (int c = 0; c < (l.cout + 63) / 64; ++c) i_ss.push_back({i, c});
         }
         if (l.has_grad && l.op == OP_LINEAR) {   // conv layers get <G,W_eff> from their dY kernels (ew.hip)
             const long nch = (l.nw() + OPT_CHUNK - 1) / OPT_CHUNK;
@@ -1432,9 +1432,7 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
     p.loss_sums = e->scal;
     if (e->write_xhat || !train) { p.out = e->xhat.p; p.ldout = e->xhat.ld; }
     if (train) {
-        HIPCHK(hipMemsetAsync(e->recon_unit, 0, 3L * e->N * 4, e->stream));
         p.sums2 = e->stats + S.sums2; p.dgamma = e->recon_unit; p.dbeta = e->recon_unit + e->N;
-        HIPCHK(hipMemsetAsync(p.sums2, 0, sizeof(double) * 2 * B * g.G, e->stream));   // the reduce pass accumulates into it
         p.dbias = e->recon_unit + 2L * e->N; p.gscale = 1.0f;
     }
     ew_recon_loss(e->dt, train, p, e->stream);
@@ -1460,7 +1458,7 @@ int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
     if (train && mode_fix) return fail(SGV_ERR_ARG, "mode_fix is an inference path");
     if (!e->copies_fresh) CHK(refresh_copies(e));
     const int B = e->batch;
-    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    if (!e->deterministic) HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));   // only the fp64-atomic statistics epilogue accumulates
     HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
     CHK(run_sn(e, train));
     CHK(encoder_fwd(e, B));
@@ -1480,7 +1478,7 @@ int sgv_decode(sgv_engine* e, const float* z_dev, const float* xs_dev, int batch
     if (!e->copies_fresh) CHK(refresh_copies(e));
     const int B = batch;
     e->batch = B;
-    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    if (!e->deterministic) HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));   // only the fp64-atomic statistics epilogue accumulates
     HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
     CHK(run_sn(e, 0));
     HIPCHK(hipMemcpyAsync(e->zlat, z_dev, (size_t)B * e->Z * 4, hipMemcpyDeviceToDevice, e->stream));
@@ -1504,7 +1502,7 @@ int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host
     if (e->batch < 1) return fail(SGV_ERR_STATE, "no input set");
     if (!e->copies_fresh) CHK(refresh_copies(e));
     const int B = e->batch;
-    HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));
+    if (!e->deterministic) HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));   // only the fp64-atomic statistics epilogue accumulates
     CHK(run_sn(e, 0));
     CHK(encoder_fwd(e, B));
     std::vector<float> last((size_t)B * 2 * e->Z);
@@ -1725,14 +1723,8 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     e->fin_dots.clear(); e->fin_affine.clear();
     auto fire = [&]() { flush_fin(false); fire_at(bucket); ++bucket; };
     const int small_bucket = (int)e->buckets.size() - 1;
-    // zero the small-gradient zone (biases / GroupNorm affine use atomics) and the backward group sums
-    HIPCHK(hipMemsetAsync(e->grads + e->n_grads_w, 0, (e->n_grads - e->n_grads_w) * 4, e->stream));
-    {
-        // keep the recon head's sums2 (filled by the forward loss pass): it is the last forward slot
-        Stage& S = e->recon.st[0];
-        const size_t lo = e->n_stats_fwd, hi = e->n_stats_fwd + S.sums;   // all slots before the recon slot
-        HIPCHK(hipMemsetAsync(e->stats + lo, 0, (hi - lo) * 8, e->stream));
-    }
+    // no zero-fills: every gradient of the small zone (biases, GroupNorm affine, <G,W_eff> slot 0) and every backward group sum
+    // is written, not accumulated, by its fixed-order reduction; tensors that get no gradient stay at their initial zero
     // ---- recon head ----
     {
         Stage& S = e->recon.st[0];
@@ -1747,9 +1739,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         p.cdot_part = e->red + L.dot_part; p.cdot_blocks = &e->dot_counts[0];
         ew_recon_bwd_apply(e->dt, p, e->stream);
         e->fin_dots.push_back({p.cdot_part, p.cdot, e->dot_counts[0], 0});
-        ew_axpy(e->grads + g.ggamma, e->recon_unit, gs, e->N, e->stream);
-        ew_axpy(e->grads + g.gbeta, e->recon_unit + e->N, gs, e->N, e->stream);
-        ew_axpy(e->grads + L.gb, e->recon_unit + 2L * e->N, gs, e->N, e->stream);
+        ew_scale3(e->grads + g.ggamma, e->grads + g.gbeta, e->grads + L.gb, e->recon_unit, gs, e->N, e->stream);
         CHK(conv_bwd_dw(e, L, e->dy_recon, e->dec_out[n_st - 1], M));
         CHK(conv_bwd_dx(e, L, e->dy_recon, e->d_out[n_st - 1], nullptr, M));
         fire();

@@ -99,16 +99,18 @@ __device__ __forceinline__ float block_sum_fixed(float v, float* smw) {
     for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += smw[i];
     return t;
 }
-// sum of one double per thread over the block, result broadcast to every thread (all 256 threads call)
-__device__ __forceinline__ double block_sum_f64(double v, double* sm4) {
+// sum of one double per thread over the block (<= 1024 threads, multiple of 64) in a fixed order, result broadcast to every
+// thread (all threads call); sm16: 16 doubles of LDS
+__device__ __forceinline__ double block_sum_f64(double v, double* sm16) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
     __syncthreads();
-    if ((threadIdx.x & 63) == 0) sm4[threadIdx.x >> 6] = v;
+    if ((threadIdx.x & 63) == 0) sm16[threadIdx.x >> 6] = v;
     __syncthreads();
-    return sm4[0] + sm4[1] + sm4[2] + sm4[3];
+    double t = 0.0;
+    for (int i = 0; i < (int)(blockDim.x >> 6); ++i) t += sm16[i];
+    return t;
 }
-
 // linear index of this block in its grid
 __device__ __forceinline__ int block_linear() { return ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x; }
 
@@ -339,13 +341,13 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
 //   sums2[b][g] = (s1, s2) = (sum_c gamma_c A_c, sum_c gamma_c B_c)                 (plain store: no zero-fill, no atomics)
 //   ptot[b][0..2][c] = A_c, B_c, D_c = gscale * rstd * (gamma_c*A_c - T*s1/n - (s2/n)*X_c)   (D = column sum of dY, analytically)
 // The sums over the samples (dbeta, dgamma, dbias) are taken later by ew_fin_affine.
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, int RS) {
-    __shared__ double smd[4];
+__global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const GNParams p, int RS) {
+    __shared__ double smd[16];
     const int g = blockIdx.x, b = blockIdx.y;
     const float* part = p.part + ((long)b * RS * 3) * p.C;
     const int c_lo = g * p.Cg, c_hi = g == p.G - 1 ? p.C : (g + 1) * p.Cg;
     double s1 = 0.0, s2 = 0.0;
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 1024) {
         float A = 0.f, Bv = 0.f;
         for (int r = 0; r < RS; ++r) {
             A += part[((long)r * 3 + 0) * p.C + c];
@@ -367,7 +369,7 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const GNParams p, 
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
     const float m1 = (float)(S1 / n), m2 = (float)(S2 / n);
     float* pt = p.ptot + (long)b * 3 * p.C;
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += 256) {
+    for (int c = c_lo + threadIdx.x; c < c_hi; c += 1024) {
         float A = 0.f, Bv = 0.f, X = 0.f;
         for (int r = 0; r < RS; ++r) {
             A += part[((long)r * 3 + 0) * p.C + c];
@@ -398,34 +400,61 @@ __global__ __launch_bounds__(256) void colsum_finalize_kernel(const float* part,
     }
 }
 
-// out[b*n + j] = scale * sum_{r < R} part[(b*R + r)*n + j]; one block = 16 outputs x 16 row lanes, fixed summation order
-template <typename TI, typename TO>
+// out[b*n + j] = scale * sum_{r < R} part[(b*R + r)*n + j]; one block = CL outputs x 256/CL row lanes (few outputs: many lanes),
+// fixed summation order: lane-strided partial sums, then the lanes in index order
+template <typename TI, typename TO, int CL>
 __global__ __launch_bounds__(256) void rowsum_kernel(const TI* part, int R, int n, TO* out, double scale) {
-    const int cl = threadIdx.x & 15, rl = threadIdx.x >> 4;
-    const int j = blockIdx.x * 16 + cl, b = blockIdx.y;
+    constexpr int RLN = 256 / CL;
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const int j = blockIdx.x * CL + cl, b = blockIdx.y;
     double a = 0.0;
     if (j < n)
-        for (int r = rl; r < R; r += 16) a += (double)part[((long)b * R + r) * n + j];
-    __shared__ double sm[16][17];
+        for (int r = rl; r < R; r += RLN) a += (double)part[((long)b * R + r) * n + j];
+    __shared__ double sm[RLN][CL + 1];
     sm[rl][cl] = a;
+    __syncthreads();
+    // two-level fixed-order combine: 16 threads per output sum RLN/16 lanes each, then one thread sums those
+    __shared__ double sm2[16][CL + 1];
+    if (rl < 16) {
+        double t = 0.0;
+        for (int k = rl; k < RLN; k += 16) t += sm[k][cl];
+        sm2[rl][cl] = t;
+    }
     __syncthreads();
     if (rl == 0 && j < n) {
         double t = 0.0;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t += sm[k][cl];
+        for (int k = 0; k < 16; ++k) t += sm2[k][cl];
         out[(long)b * n + j] = (TO)(t * scale);
     }
 }
+// one output, many rows (gradient-norm and KL partials): 1024 threads, four loads in flight per thread, fixed order
+template <typename TI, typename TO>
+__global__ __launch_bounds__(1024) void rowsum1_kernel(const TI* part, int R, TO* out, double scale) {
+    __shared__ double sm16[16];
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    int r = threadIdx.x;
+    for (; r + 3072 < R; r += 4096) { a0 += (double)part[r]; a1 += (double)part[r + 1024]; a2 += (double)part[r + 2048]; a3 += (double)part[r + 3072]; }
+    for (; r < R; r += 1024) a0 += (double)part[r];
+    const double t = block_sum_f64((a0 + a1) + (a2 + a3), sm16);
+    if (threadIdx.x == 0) out[0] = (TO)(t * scale);
+}
+template <typename TI, typename TO>
+static void rowsum_launch(const TI* part, int batches, int R, int n, TO* out, double scale, hipStream_t s) {
+    if (n == 1 && batches == 1) hipLaunchKernelGGL((rowsum1_kernel<TI, TO>), dim3(1), dim3(1024), 0, s, part, R, out, scale);
+    else if (n <= 1) hipLaunchKernelGGL((rowsum_kernel<TI, TO, 1>), dim3(n, batches), dim3(256), 0, s, part, R, n, out, scale);
+    else if (n <= 4) hipLaunchKernelGGL((rowsum_kernel<TI, TO, 4>), dim3(cdiv_i(n, 4), batches), dim3(256), 0, s, part, R, n, out, scale);
+    else hipLaunchKernelGGL((rowsum_kernel<TI, TO, 16>), dim3(cdiv_i(n, 16), batches), dim3(256), 0, s, part, R, n, out, scale);
+}
 int ew_rowsum(const float* part, int batches, int R, int n, float* out_f, double* out_d, double scale, hipStream_t s) {
     if (batches <= 0 || n <= 0) return 0;
-    dim3 grid(cdiv_i(n, 16), batches);
-    if (out_d) hipLaunchKernelGGL((rowsum_kernel<float, double>), grid, dim3(256), 0, s, part, R, n, out_d, scale);
-    else hipLaunchKernelGGL((rowsum_kernel<float, float>), grid, dim3(256), 0, s, part, R, n, out_f, scale);
+    if (out_d) rowsum_launch<float, double>(part, batches, R, n, out_d, scale, s);
+    else rowsum_launch<float, float>(part, batches, R, n, out_f, scale, s);
     return 0;
 }
 int ew_rowsum_d(const double* part, int R, int n, double* out_d, double scale, hipStream_t s) {
     if (n <= 0) return 0;
-    hipLaunchKernelGGL((rowsum_kernel<double, double>), dim3(cdiv_i(n, 16), 1), dim3(256), 0, s, part, R, n, out_d, scale);
+    rowsum_launch<double, double>(part, 1, R, n, out_d, scale, s);
     return 0;
 }
 
@@ -558,7 +587,7 @@ __device__ __forceinline__ GNSlab gn_slab(const GNParams& p) {
 // out = [res + rscale *] act(gn(y)), statistics included; p.sums[(b*G+g)*2 + {0,1}] = sum, sum of squares (stored)
 template <typename T, int ACT>
 __global__ __launch_bounds__(256) void gn_fwd_fused_kernel(const GNParams p) {
-    __shared__ double sm4[4];
+    __shared__ double sm4[16];
     const GNSlab c = gn_slab(p);
     const T* y = reinterpret_cast<const T*>(p.y) + (long)c.b * p.T * p.ldy + c.c0;
     const T* res = p.res ? reinterpret_cast<const T*>(p.res) + (long)c.b * p.T * p.ldres + c.c0 : nullptr;
@@ -859,7 +888,7 @@ static void gn_fin_immediate(const GNParams& p, bool own_ptot, bool own_dots, in
 }
 static void gn_finalize(GNParams p, hipStream_t s) {
     GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(256), 0, s, p, g_.rowsplit);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(1024), 0, s, p, g_.rowsplit);
 }
 // p.sums[b][g] = (sum, sum of squares), overwritten; p.part = workspace (ew_gn_part_floats)
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
@@ -1513,6 +1542,19 @@ int ew_augment(int dtype, const void* data, void* out, long sample_elems, int ba
 // y[i] += a * x[i]  (fp32, small arrays)
 __global__ void axpy_kernel(float* y, const float* x, float a, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] += a * x[i];
+}
+// d0 = a*x[0..n), d1 = a*x[n..2n), d2 = a*x[2n..3n)   (recon head: unit-weight affine / bias gradients -> weighted, written not added)
+__global__ void scale3_kernel(float* d0, float* d1, float* d2, const float* x, float a, long n) {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < 3 * n; i += (long)gridDim.x * 256) {
+        const float v = a * x[i];
+        if (i < n) d0[i] = v; else if (i < 2 * n) d1[i - n] = v; else d2[i - 2 * n] = v;
+    }
+}
+int ew_scale3(float* d0, float* d1, float* d2, const float* x, float a, long n, hipStream_t s) {
+    int blocks = cdiv_i(3 * n, 256);
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(scale3_kernel, dim3(blocks), dim3(256), 0, s, d0, d1, d2, x, a, n);
+    return 0;
 }
 __global__ __launch_bounds__(256) void fill_from_scalar_kernel(float* dst, const float* src, long n) {
     const float v = *src;

@@ -29,31 +29,46 @@ __global__ __launch_bounds__(256) void sn_wt_u_kernel(const SNDesc* descs, const
     float* t = d.tpart + ((long)(r_lo / SN_ROWS_PER_ITEM) * d.taps + tap) * d.cols + c;
     *reinterpret_cast<float4*>(t) = make_float4(a0, a1, a2, a3);
 }
-// tmp_t[i] = sum over the row blocks, in block order, of tpart[block][i]; item = (desc, chunk of 1024 elements of taps*cols)
+// tmp_t[i] = sum over the row blocks of tpart[block][i] in a fixed order; item = (desc, chunk of 64 elements of taps*cols);
+// 16 lanes x 16 float4 columns: lane l sums blocks l, l+16, ..., then the lanes are added in index order
 __global__ __launch_bounds__(256) void sn_tsum_kernel(const SNDesc* descs, const WorkItem* items) {
+    __shared__ float4 sm[16][17];
     const WorkItem it = items[blockIdx.x];
     const SNDesc d = descs[it.desc];
     const long n = (long)d.taps * d.cols;
-    const long i = (long)it.chunk * 1024 + threadIdx.x * 4;
-    if (i >= n) return;
+    const int cq = threadIdx.x & 15, rl = threadIdx.x >> 4;
+    const long i = (long)it.chunk * 64 + cq * 4;
     const int rb = (d.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int r = 0; r < rb; ++r) {
-        const float4 v = *reinterpret_cast<const float4*>(d.tpart + (long)r * n + i);
-        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+    if (i < n)
+        for (int r = rl; r < rb; r += 16) {
+            const float4 v = *reinterpret_cast<const float4*>(d.tpart + (long)r * n + i);
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+    sm[rl][cq] = a;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        float4 t = sm[0][cq];
+#pragma unroll
+        for (int k = 1; k < 16; ++k) { const float4 v = sm[k][cq]; t.x += v.x; t.y += v.y; t.z += v.z; t.w += v.w; }
+        *reinterpret_cast<float4*>(d.tmp_t + i) = t;
     }
-    *reinterpret_cast<float4*>(d.tmp_t + i) = a;
 }
-// tmp_s[r] = sum over the (tap, column block) partials in index order; item = (desc, chunk of 1024 rows)
+// tmp_s[r] = sum over the (tap, column block) partials in a fixed order; item = (desc, chunk of 64 rows): 4 lanes x 64 rows,
+// lane l sums partials l, l+4, ..., then the lanes are added in index order
 __global__ __launch_bounds__(256) void sn_ssum_kernel(const SNDesc* descs, const WorkItem* items) {
+    __shared__ float sm[4][64];
     const WorkItem it = items[blockIdx.x];
     const SNDesc d = descs[it.desc];
     const int np = d.taps * ((d.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM);
-    for (int r = it.chunk * 1024 + threadIdx.x; r < min(d.rows, (it.chunk + 1) * 1024); r += 256) {
-        float a = 0.f;
-        for (int k = 0; k < np; ++k) a += d.spart[(long)k * d.rows + r];
-        d.tmp_s[r] = a;
-    }
+    const int rq = threadIdx.x & 63, kl = threadIdx.x >> 6;
+    const int r = it.chunk * 64 + rq;
+    float a = 0.f;
+    if (r < d.rows)
+        for (int k = kl; k < np; k += 4) a += d.spart[(long)k * d.rows + r];
+    sm[kl][rq] = a;
+    __syncthreads();
+    if (kl == 0 && r < d.rows) d.tmp_s[r] = ((sm[0][rq] + sm[1][rq]) + sm[2][rq]) + sm[3][rq];
 }
 
 // ---- pass 2: v = t / max(||t||, 1e-12) ------------------------------------------------------------

@@ -103,8 +103,8 @@ int sgv_pset_create(const sgv_pset_entry* entries, int n, sgv_pset** out) {
             a.sn = si; a.rows = e.rows; a.cols = e.cols;
             const int rb = (e.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM, cb = (e.cols + SN_COLS_PER_ITEM - 1) / SN_COLS_PER_ITEM;
             for (int c = 0; c < rb * cb; ++c) i_sn.push_back({si, c});
-            for (int c = 0; c < (e.cols + 1023) / 1024; ++c) i_ts.push_back({si, c});
-            for (int c = 0; c < (e.rows + 1023) / 1024; ++c) i_ss.push_back({si, c});
+            for (int c = 0; c < (e.cols + 63) / 64; ++c) i_ts.push_back({si, c});
+            for (int c = 0; c < (e.rows + 63) / 64; ++c) i_ss.push_back({si, c});
             ps->fin_dots.push_back({(const float*)(uintptr_t)i_dot.size(), d.dot, (int)((e.n + OPT_CHUNK - 1) / OPT_CHUNK), 0});
             for (long c = 0; c < (e.n + OPT_CHUNK - 1) / OPT_CHUNK; ++c) i_dot.push_back({si, (int)c});
         }

@@ -78,6 +78,7 @@ int ew_linear_expand_bwd(int dtype, const void* dY, const float* X, const float*
 int ew_augment(int dtype, const void* data, void* out, long sample_elems, int batch, const int* idx,
                const unsigned long long* noise_seed, const float* scale, const int* mix_idx, const float* lam, hipStream_t s);
 int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s);
+int ew_scale3(float* d0, float* d1, float* d2, const float* x, float a, long n, hipStream_t s);   // d_k = a * x[k*n .. (k+1)*n)
 int ew_fill_from_scalar(float* dst, const float* src_scalar, long n, hipStream_t s);   // dst[i] = *src_scalar
 int ew_scale(float* y, float a, long n, hipStream_t s);
 // input pipeline
@@ -120,7 +121,7 @@ struct WorkItem { int desc; int chunk; };
 // (summed by the AdamW pass) so the adds do not serialise on one address.
 constexpr int SGV_DOT_SLOTS = 32;
 
-// items_ts / items_ss: (desc, 1024-element chunk of taps*cols / of rows) for the fixed-order partial sums
+// items_ts / items_ss: (desc, 64-element chunk of taps*cols / 1024-row chunk) for the fixed-order partial sums
 int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,
                            const WorkItem* items_ts, int n_ts, const WorkItem* items_ss, int n_ss, int ndesc, int train, hipStream_t s);
 // dot_part[i] = <G, W> / sigma of work item i (summed per layer by ew_fin_dots)
