@@ -69,10 +69,16 @@ class ResidentLoader:
     """DataLoader stand-in: iterating yields [B, num_node, num_time] tensors like the reference's loader;
     modules.train.train instead asks for `batch_plans()` and feeds them to the fused device kernel."""
 
-    def __init__(self, dataset: AugmentedDataset, indices, batch_size, shuffle, augment, rank=0, world=1):
+    def __init__(self, dataset: AugmentedDataset, indices, batch_size, shuffle, augment, rank=0, world=1, shuffle_seed=None):
         self.dataset, self.indices = dataset, list(int(i) for i in indices)
         self.batch_size, self.shuffle, self.augment = int(batch_size), shuffle, augment
         self.rank, self.world = rank, world
+        # data-parallel runs: the per-epoch permutation comes from a generator of its own, seeded with a value every rank
+        # shares (drawn on rank 0, broadcast by create_augmented_dataloaders) -- never from the process-global `random`,
+        # whose state differs between ranks (urandom seeding under torchrun, and the augmentation draws consume a
+        # data-dependent number of values)
+        self.shuffle_seed = shuffle_seed
+        self.epoch = 0
         self._resident = None   # (engine id, device buffer)
 
     def __len__(self):
@@ -82,7 +88,11 @@ class ResidentLoader:
     def _epoch_indices(self):
         idx = list(self.indices)
         if self.shuffle:
-            random.shuffle(idx)          # every rank draws the same permutation (same python seed)
+            if self.shuffle_seed is not None:
+                random.Random(self.shuffle_seed + self.epoch).shuffle(idx)     # identical on every rank
+            else:
+                random.shuffle(idx)                                             # single process: the reference's global stream
+        self.epoch += 1
         if self.world > 1:
             idx = shard_indices(idx, self.rank, self.world, self.batch_size)
         return idx
@@ -142,10 +152,18 @@ def create_augmented_dataloaders(x_data, batch_size, load_all=False, augmentatio
     dataset_size = len(x_data)
     val_size = int(dataset_size * val_split)
     train_size = dataset_size - val_size
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
     indices = torch.randperm(dataset_size)
+    shuffle_seed = None
+    if world > 1:
+        # one split and one shuffle seed for the whole job: rank 0's draws, broadcast (the reference seeds nothing, so every
+        # rank's own draws would differ: validation samples of one rank would be trained on by another)
+        box = [indices.tolist(), random.getrandbits(48)] if rank == 0 else [None, None]
+        dist.broadcast_object_list(box, src=0)
+        indices, shuffle_seed = torch.tensor(box[0], dtype=torch.long), int(box[1])
     train_indices, val_indices = indices[:train_size].tolist(), indices[train_size:].tolist()
     full = AugmentedDataset(x_data, load_all, augmentation_config)
-    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
-    train_loader = ResidentLoader(full, train_indices, batch_size, shuffle=True, augment=True, rank=rank, world=world)
+    train_loader = ResidentLoader(full, train_indices, batch_size, shuffle=True, augment=True, rank=rank, world=world,
+                                  shuffle_seed=shuffle_seed)
     val_loader = ResidentLoader(full, val_indices, batch_size, shuffle=False, augment=False)
     return train_loader, val_loader

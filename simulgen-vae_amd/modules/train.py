@@ -158,6 +158,27 @@ class NativeAllReduce:
             self.comm = None
 
 
+def broadcast_replica_state(engine, group=None, src=0):
+    """Every rank takes rank `src`'s parameters and spectral-norm u / v (all state_dict entries), tensor by tensor; returns a
+    noise seed that rank `src` drew.  Replicas built from the same init seed are identical already; a state loaded from a
+    file on one rank, or a different torch / numpy version on another, is not -- and nothing re-synchronises replicas later:
+    the deterministic step keeps identical replicas bitwise identical, it does not repair different ones."""
+    import random
+    cuda = dist.get_backend(group) == "nccl"
+    state = engine.state_dict()
+    out = {}
+    for k in sorted(state):
+        t = torch.from_numpy(np.ascontiguousarray(state[k]))
+        t = t.cuda() if cuda else t
+        dist.broadcast(t, src=src, group=group)
+        out[k] = t.cpu().numpy()
+    if dist.get_rank(group) != src:
+        engine.load_state(out)
+    box = [random.getrandbits(48)]
+    dist.broadcast_object_list(box, src=src, group=group)
+    return int(box[0])
+
+
 def make_allreduce(engine, group=None):
     """GradAllReduce (torch.distributed issues the bucket collectives) or, with SGV_DDP_NATIVE=1, NativeAllReduce."""
     return NativeAllReduce(engine, group) if os.environ.get("SGV_DDP_NATIVE") == "1" else GradAllReduce(engine, group)
@@ -180,6 +201,8 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
     eng.set_option("write_xhat", 0)
     warmup_kl = WarmupKLLoss(epochs, 1e-4, int(epochs * 0.3), int(epochs * 0.8), 1)   # init_beta hard-coded
     allreduce = make_allreduce(eng) if world > 1 else None
+    if world > 1:
+        eng.seed(broadcast_replica_state(eng) + rank)      # identical replicas, rank-distinct reparameterisation / noise streams
     fused = hasattr(train_dataloader, "batch_plans")
     data = train_dataloader.resident(eng) if fused else None
 

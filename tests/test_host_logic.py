@@ -183,6 +183,48 @@ def test_two_rank_mean_gradient_equals_full_batch(tmp_path):
     assert np.abs(got - ref).max() / np.abs(ref).max() < 2e-5
 
 
+def _loader_worker(rank, world, port, out_dir):
+    """Unseeded ranks (each process keeps its own urandom-seeded `random` / torch generators, as under torchrun)."""
+    import os
+    import random
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    random.seed(1000 + 17 * rank)          # deliberately DIFFERENT global streams per rank
+    torch.manual_seed(2000 + 31 * rank)
+    from simulgen_vae_amd.modules.augmentation import create_augmented_dataloaders
+    x = np.zeros((40, 6, 4), np.float32)
+    tl, vl = create_augmented_dataloaders(x, batch_size=4, load_all=False)
+    epochs = []
+    for _ in range(3):
+        epochs.append([b for b, *_ in tl.batch_plans()])       # also consumes augmentation draws (rank-dependent amounts)
+    np.save(os.path.join(out_dir, f"r{rank}.npy"), np.array([tl.indices, vl.indices, epochs], dtype=object), allow_pickle=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_loaders_share_split_and_disjoint_shards(tmp_path):
+    """without any external seeding, both ranks must hold the SAME train/validation split and, every epoch,
+    disjoint shards of the SAME permutation (rank 0's split and shuffle seed are broadcast; the permutation does not come
+    from the process-global `random`, whose state diverges between ranks)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_loader_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    r0 = np.load(tmp_path / "r0.npy", allow_pickle=True)
+    r1 = np.load(tmp_path / "r1.npy", allow_pickle=True)
+    assert list(r0[0]) == list(r1[0]) and list(r0[1]) == list(r1[1])             # identical split
+    assert not set(r0[0]) & set(r0[1]) and len(r0[0]) == 32 and len(r0[1]) == 8
+    seen = []
+    for e0, e1 in zip(r0[2], r1[2]):
+        a = [i for b in e0 for i in b]
+        b = [i for bb in e1 for i in bb]
+        assert len(a) == len(b) == 16 and not set(a) & set(b)                    # disjoint, equal-sized shards
+        assert set(a) | set(b) == set(r0[0])                                      # together: the whole training set
+        seen.append(tuple(a))
+    assert len(set(seen)) == 3                                                    # a new permutation every epoch
+
+
 def test_input_pipeline_host_side_matches_reference_fixture():
     """SURVEY 8(f) N3, host half: reduce_dataset and the seeded row sampling of data_scaler against the fixture
     recorded from the reference (tests/golden/gen_fixtures.py scaler)."""
