@@ -180,6 +180,12 @@ int sgv_bucket_count(const sgv_engine* e);
 /* Gradient 2-norm accumulated by the AdamW pass(es) of the current step (same value sgv_grad_norm computes in a
  * separate pass).  [sync] */
 int sgv_last_grad_norm(sgv_engine* e, double* out);
+/* Epoch statistics without a host round trip per step (the reference's loop reads .item() scalars after every step,
+ * modules/train.py:156-161,171-174).  sgv_scalars_accumulate: enqueue "add the scalars of the step that has just been
+ * enqueued (forward + optimizer) to the device-side accumulator"; sgv_scalars_read: the accumulator, host16 =
+ * [sum recon, sum kl, sum kl2_0.., ..., [8] sum mse, [9] sum of gradient norms, [10] steps]; reset != 0 clears it. */
+int sgv_scalars_accumulate(sgv_engine* e);
+int sgv_scalars_read(sgv_engine* e, double* host16, int reset);
 
 /* AugmentedDataset.__getitem__ x batch + default collate (augmentation.py:43-124) on a dataset
  * resident in HBM in the engine's internal layout: builds the input batch directly.

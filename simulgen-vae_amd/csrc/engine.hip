@@ -1908,6 +1908,33 @@ int sgv_last_grad_norm(sgv_engine* e, double* out) {
     return SGV_OK;
 }
 
+// ---- per-epoch statistics without a host sync per step (reference loop: modules/train.py:171-174 reads four scalars and
+// one gradient norm per parameter tensor with .item() after every step; here the step's scalars are added to a device-side
+// accumulator by a one-thread kernel and read once per epoch) ----
+__global__ void scalars_accumulate_kernel(const double* scal, double* acc, int n_st, double numel) {
+    // acc: [0] recon (selected loss, mean), [1] kl, [2..] kl2 per stage, [8] mse, [9] gradient norm, [10] steps
+    acc[0] += scal[0] / numel;
+    acc[1] += scal[2];
+    for (int i = 0; i + 1 < n_st; ++i) acc[2 + i] += scal[3 + i];
+    acc[8] += scal[1] / numel;
+    acc[9] += sqrt(scal[15]);
+    acc[10] += 1.0;
+}
+int sgv_scalars_accumulate(sgv_engine* e) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (e->batch < 1) return fail(SGV_ERR_STATE, "no step to accumulate");
+    hipLaunchKernelGGL(scalars_accumulate_kernel, dim3(1), dim3(1), 0, e->stream, e->scal, e->scal + 16, e->n_st,
+                       (double)e->batch * e->T * e->N);
+    return SGV_OK;
+}
+int sgv_scalars_read(sgv_engine* e, double* host16, int reset) {
+    if (!e || !host16) return fail(SGV_ERR_ARG, "null argument");
+    HIPCHK(hipMemcpyAsync(host16, e->scal + 16, 16 * 8, hipMemcpyDeviceToHost, e->stream));
+    if (reset) HIPCHK(hipMemsetAsync(e->scal + 16, 0, 16 * 8, e->stream));
+    HIPCHK(hipStreamSynchronize(e->stream));
+    return SGV_OK;
+}
+
 // ---- input pipeline (stateless: no engine needed) ----------------------------------------------------
 int sgv_minmax_fit(const float* rows_dev, long n_rows, int n_node, float* min_dev, float* max_dev, int accumulate, void* stream) {
     if (!rows_dev || !min_dev || !max_dev) return fail(SGV_ERR_ARG, "null argument");

@@ -222,29 +222,30 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
         model.train(True)
         beta, _ = warmup_kl.get_loss(epoch, [])
         lr = cosine_warm_restarts_lr(LR, epochs, epoch)
-        loss_save = recon_save = kl_save = 0.0
-        grad_sum, nb = 0.0, 0
         batches = train_dataloader.batch_plans() if fused else iter(train_dataloader)
+        eng.read_accumulated(reset=True)
         for item in batches:
             if fused:
                 idx, seeds, scale, mix, lam = item
                 eng.augment_collate(data, idx, seeds, scale, mix, lam)
             else:
                 eng.set_input(model._prep(item))
-            sc = eng.forward(train=True)
-            if allreduce is not None:
+            eng.forward(train=True, sync=False)          # nothing in the step waits for the host: the step's scalars and its
+            if allreduce is not None:                   # gradient norm (train.py:156-161,171-174) are added up on the device
                 eng.backward(alpha, beta)
                 allreduce.step(eng, lr)
             else:
                 eng.backward_step(alpha, beta, lr)
-            grad_sum += eng.last_grad_norm()     # accumulated inside the AdamW pass (train.py:156-161 value)
-            l, r, k = run_forward_losses(sc, beta)
-            loss_save += l
-            recon_save += r
-            kl_save += k
-            nb += 1
+            eng.accumulate_scalars()
+        acc = eng.read_accumulated(reset=True)           # one read-back per epoch
+        nb = acc["steps"]
         if nb == 0:
             raise ZeroDivisionError("empty training loader")
+        # alpha and beta are constant within an epoch, so the epoch sums of the per-step losses follow from the summed scalars
+        recon_save = acc["recon"] * alpha
+        kl_save = float(sum(acc["kls"])) * beta
+        loss_save = recon_save + kl_save
+        grad_sum = acc["grad_norm"]
         if epoch % 20 == 0 or epoch == epochs - 1:
             model.eval()
             vl = vr = 0.0
