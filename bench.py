@@ -139,6 +139,37 @@ def bench_latent_conditioner(args):
            "config": {"workload": f"LatentConditionerImg training step, {side}x{side} images, batch {B} (BASELINE.json configs[4])",
                       "filters": filters, "image": side, "per_gpu_batch": B},
            "step_tflops": round(3 * fwd_gf * (B / 16) / (el / args.steps) / 1e3, 2) if fwd_gf else None, "roofline": None, "cpu_baseline": None}
+    # roofline of the dominant GEMM class: events on torch's current stream (the operators' stream) around every GEMM operator
+    # call of two extra steps; algorithmic FLOPs 2*M*N*K per call (convolutions = im2col rows x K = kh*kw*Cin)
+    from simulgen_vae_amd import ops as _ops
+    _ops.GEMM_TIMING = []
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    cls = {}
+    for c, fl, e0, e1 in _ops.GEMM_TIMING:
+        st = cls.setdefault(c, [0.0, 0.0, 0])
+        st[0] += fl; st[1] += e0.elapsed_time(e1); st[2] += 1
+    _ops.GEMM_TIMING = None
+    names = {"gemm_nt": "gemm_nt_t256_kernel / gemm_nt_kernel (convolution forward and input-gradient GEMMs on im2col rows, sgv_op_gemm_nt)",
+             "gemm_tn": "gemm_tn_w2_kernel / gemm_tn_kernel (weight-gradient GEMMs: a million rows reduced into a small matrix, split-K slabs)"}
+    traffic = load_traffic()
+    for c, (fl, tms, calls) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
+        ach = fl / (tms * 1e-3) / 1e12
+        o = {"kernel": names[c], "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF,
+             "unit": "TFLOP/s", "frac": round(ach / (MFMA_BF16_PEAK_TF if args.dtype == "bf16" else MFMA_F32_PEAK_TF), 4), "traffic": None,
+             "launches_per_step": calls // 2, "avg_launch_ms": round(tms / calls, 4), "ms_per_step": round(tms / 2, 3),
+             "flop_per_launch": round(fl / calls),
+             "note": "achieved = sum of 2*M*N*K over the class's operator calls / sum of their event durations (operator = main kernel + its "
+                     "split-K combine); traffic = (FETCH_SIZE x2 + WRITE_SIZE) per launch from the committed rocprofv3 --pmc passes of this command"}
+        t = (traffic or {}).get("lc_" + c)
+        if t and t.get("launches"):
+            o["traffic"] = round((t["fetch_bytes"] + t["write_bytes"]) / t["launches"])
+            o["traffic_source"] = traffic.get("_source")
+        if res["roofline"] is None:
+            res["roofline"] = o
+        else:
+            res["roofline_" + c] = o
     if args.cpu_baseline == "auto":
         # the CPU restatement (oracle/lc_torch_port.py, PyTorch-CPU fp32) on the host cores: 1 untimed + 1 timed training
         # step at the same image size, batch 4

@@ -957,7 +957,7 @@ int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float
     p.M = M; p.N = N; p.K = K; p.taps = 1; p.pad = 0; p.Tlen = M; p.splitk = 1; p.out_f32 = out_f32;
     // library path (csrc/vendor.hip) for the shapes it wins; its device-side scale is a vector: N copies of *scale in a
     // per-stream scratch buffer, written by one small kernel in front of the GEMM
-    static const int lib_on = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 1;
+    static const int lib_on = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 0;   // comparator only (tests/micro)
     if (lib_on && dtype == 1 && !out_f32) {
         p.vendor = 1;
         if (scale) {
@@ -978,7 +978,14 @@ int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float
             p.vendor = 0; p.scale_vec = nullptr;
         }
     }
-    const int r = launch_gemm_nt(dtype, p, ST(stream));
+    int r;
+    if (p.vendor) r = launch_gemm_nt(dtype, p, ST(stream));
+    else {
+        // the engine's kernel choice (gemm256.hip): 256x256 persistent kernel for the big products, 128-row kernels otherwise;
+        // this stateless entry point has no split-K workspace, so every plan is split-K 1
+        const GemmPlan pl = gemm_nt_plan(dtype, p, 0, 0);
+        r = launch_gemm_nt_planned(dtype, p, pl, ST(stream));
+    }
     if (r) return sgv_set_error(-1, "sgv_op_gemm_nt: launch rejected (%d) for M=%d N=%d K=%d", r, M, N, K);
     return 0;
 }

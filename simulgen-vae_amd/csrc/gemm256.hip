@@ -725,7 +725,8 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
     GemmPlan pl = {0, 1, 1, p.M, 0};
     const long total_kt = (long)p.taps * t256_cdiv(p.K, 64);
     const double gf = 2.0e-9 * p.M * p.N * p.K * p.taps;
-    const bool big = gemm_nt256_eligible(dtype, p) && p.N >= 1024 && gf >= min_gf && !p.out_f32 && total_kt >= 8;
+    const long tiles256 = (long)t256_cdiv(p.M, 256) * t256_cdiv(p.N, 256);
+    const bool big = gemm_nt256_eligible(dtype, p) && (p.N >= 1024 || tiles256 >= 200) && gf >= min_gf && !p.out_f32 && total_kt >= 8;
     if (!big) {
         pl.sk_main = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, dtype);
         if ((size_t)pl.sk_main * p.M * p.N > partial_floats) pl.sk_main = 1;

@@ -141,7 +141,7 @@ class LatentConditionerImg:
     def state_dict(self):
         out = {}
         for name, shape, kind in self._spec():
-            t = self.P[name].detach().cpu().clone()
+            t = self.P[name].detach().cpu().clone().reshape(tuple(shape))      # () for num_batches_tracked, as torch exports it
             out[name] = t.to(torch.int64) if name.endswith("num_batches_tracked") else t
         return out
 
@@ -157,7 +157,7 @@ class LatentConditionerImg:
                 a = torch.as_tensor(np.asarray(v.detach().cpu() if torch.is_tensor(v) else v), dtype=torch.float32)
                 if tuple(a.shape) != tuple(shape):
                     raise RuntimeError(f"size mismatch for {name}: {tuple(a.shape)} vs {tuple(shape)}")
-                self.P[name] = a.contiguous().cuda()
+                self.P[name] = a.reshape(max(1, a.numel())).contiguous().cuda() if a.dim() == 0 else a.contiguous().cuda()
         self.pset = None            # parameter tensors were replaced: rebuild the tables on next use
         return self
 

@@ -136,13 +136,29 @@ def col2im(dcol, shape, KH, KW, stride, pad):
     return dx
 
 
+# bench.py --workload lc: per-class GEMM timing with events on torch's current stream (the stream these operators run on).
+# None = off; a list collects (class, flops, start event, end event).
+GEMM_TIMING = None
+
+
+def _timed(cls, flops, fn):
+    if GEMM_TIMING is None:
+        return fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    r = fn()
+    e1.record()
+    GEMM_TIMING.append((cls, flops, e0, e1))
+    return r
+
+
 def gemm_nt(A, W, bias=None, scale=None, addend=None, out_f32=False):
     """A [M, K] . W [N, K]^T -> [M, N]."""
     M, K = A.shape
     N = W.shape[0]
     out = torch.empty((M, N), dtype=torch.float32 if out_f32 else A.dtype, device=A.device)
-    _ck(lib().sgv_op_gemm_nt(_d(A), _p(A), _p(W), _p(out), _p(bias), _p(scale), _p(addend), M, N, K, int(out_f32), _stream()),
-        "sgv_op_gemm_nt")
+    _timed("gemm_nt", 2.0 * M * N * K, lambda: _ck(lib().sgv_op_gemm_nt(_d(A), _p(A), _p(W), _p(out), _p(bias), _p(scale), _p(addend), M, N, K,
+                                                                         int(out_f32), _stream()), "sgv_op_gemm_nt"))
     return out
 
 
@@ -153,7 +169,8 @@ def gemm_tn(A, Bm):
     out = torch.empty((N1, N2), dtype=torch.float32, device=A.device)
     sk = int(lib().sgv_op_gemm_tn_splitk(_d(A), M, N1, N2))
     slabs = torch.empty((sk, N1, N2), dtype=torch.float32, device=A.device) if sk > 1 else None
-    _ck(lib().sgv_op_gemm_tn(_d(A), _p(A), _p(Bm), _p(out), M, N1, N2, _p(slabs), sk, _stream()), "sgv_op_gemm_tn")
+    _timed("gemm_tn", 2.0 * M * N1 * N2, lambda: _ck(lib().sgv_op_gemm_tn(_d(A), _p(A), _p(Bm), _p(out), M, N1, N2, _p(slabs), sk, _stream()),
+                                                     "sgv_op_gemm_tn"))
     return out
 
 

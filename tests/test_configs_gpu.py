@@ -1,0 +1,106 @@
+"""BASELINE.json configs[3] and configs[4] at their stated sizes on the GPU (one MI355X's share of each):
+
+  configs[3]  preset 1 `--size large` (second convolution in every encoder / residual block), [P x 200 x 95008] bf16,
+              per-GPU batch 16 -- one step of the large model at full size;
+  configs[4]  image latent conditioner (LatentConditionerImg, preset filters 32..1024) on 512 x 512 images, batch 16.
+
+The CPU oracle cannot run these sizes in test time, so -- like tests/test_fullsize_gpu.py -- parity is carried by
+size-independent properties of the path: finiteness, bitwise replay (the VAE step has no floating-point atomics), linearity of
+the backward pass in the loss weights, and (VAE only: GroupNorm is per sample, every loss term a batch mean) the data-parallel
+identity "mean of the shard gradients == gradient of the whole batch".  The numerics of both models are pinned against the
+reference at small size (tests/golden/g0_large_MSE.npz, lc_small.npz)."""
+import numpy as np
+import pytest
+import torch
+
+import simulgen_vae_amd  # noqa: F401
+from simulgen_vae_amd import engine as E
+from simulgen_vae_amd.init import init_state
+from simulgen_vae_amd.spec import VAEConfig
+from tests.gpu_common import rel_l2
+
+pytestmark = pytest.mark.gpu
+ENC = [1024, 512, 256, 128]
+BIG = ["encoder.encoder_blocks.0.module_list.0._seq.0.weight_orig", "encoder.encoder_blocks.0.module_list.1._seq.0.weight_orig",
+       "decoder.recon.0.weight_orig", "decoder.decoder_residual_blocks.2.seq.6.weight_orig", "decoder.recon.1.weight"]
+
+
+def test_config3_large_fullsize_batch16():
+    N, T, B = 95008, 200, 16
+    cfg = VAEConfig(32, 8, ENC, ENC[::-1], N, T, "MSE", False)
+    state = init_state(cfg, 7, reference_init=True)
+    names = [n for n in BIG if n in state]
+    assert len(names) >= 4, names
+    eng = E.Engine(cfg, max_batch=B, compute_dtype="bf16")
+    eng.load_state(state)
+    uv = {k: v for k, v in state.items() if k.endswith("weight_u") or k.endswith("weight_v")}
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = torch.rand((B, N, T), generator=g, device="cuda") * 1.4 - 0.7
+    dec = cfg.num_filter_dec
+    eps = [torch.randn((B, cfg.latent_dim), generator=g, device="cuda")] + \
+          [torch.randn((B, dec[i + 1], T), generator=g, device="cuda") for i in range(len(dec) - 2)]
+
+    def grads(xb, eb, alpha, beta):
+        eng.load_state(uv, partial=True)
+        eng.set_input(xb.contiguous())
+        eng.set_eps([e.contiguous() for e in eb])
+        sc = eng.forward(train=True)
+        eng.backward(alpha, beta)
+        return sc, {k: eng.grad(k) for k in names}, eng.grad_norm()
+
+    sc1, g1, n1 = grads(x, eps, 1e6, 1e-4)
+    assert np.isfinite(sc1["recon"]) and all(np.isfinite(k) for k in sc1["kls"]) and np.isfinite(n1) and n1 > 0
+    sc1b, g1b, n1b = grads(x, eps, 1e6, 1e-4)
+    assert sc1b["recon"] == sc1["recon"] and n1b == n1                      # bitwise replay
+    for k in names:
+        assert np.array_equal(g1[k], g1b[k]), k
+    _, g2, n2 = grads(x, eps, 2e6, 2e-4)                                     # linear in (alpha, beta)
+    assert abs(n2 - 2 * n1) <= 1e-2 * n2
+    for k in names:
+        assert rel_l2(g2[k], 2.0 * g1[k]) < 1e-2, k
+    h = B // 2                                                               # mean of the shard gradients == whole-batch gradient
+    _, ga, _ = grads(x[:h], [e[:h] for e in eps], 1e6, 1e-4)
+    _, gb, _ = grads(x[h:], [e[h:] for e in eps], 1e6, 1e-4)
+    for k in names:
+        # bf16 maps are re-rounded when the batch is split: 1.5e-2 measured on the first-layer gradient (the deepest path), < 1e-2 elsewhere
+        assert rel_l2(0.5 * (ga[k] + gb[k]), g1[k]) < 2.5e-2, (k, rel_l2(0.5 * (ga[k] + gb[k]), g1[k]))
+    eng.adamw_step(1e-3)
+    sc3 = eng.forward(train=False)
+    assert np.isfinite(sc3["recon"])
+    eng.close()
+
+
+def test_config4_latent_conditioner_512_batch16():
+    from simulgen_vae_amd.modules.latent_conditioner_model_cnn import LatentConditionerImg
+    filters = [32, 64, 128, 256, 512, 1024]
+    B, side = 16, 512
+    # dropout off: two passes must see the same network for the linearity check (the dropout path is pinned at small size)
+    m = LatentConditionerImg(filters, 32, (1, side, side), 8, 3, (side, side), dropout_rate=0.0, use_attention=True, compute_dtype="bf16")
+    m.train()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    x = torch.rand((B, side * side), generator=g, device="cuda")
+    y1 = torch.randn((B, 32), generator=g, device="cuda") * 0.3
+    y2 = torch.randn((B, 3, 8), generator=g, device="cuda") * 0.3
+
+    from simulgen_vae_amd.modules.latent_conditioner import LCOptimizer
+    opt = LCOptimizer(m, 1e-3, 1e-5)
+    sd0 = {k: v.clone() for k, v in m.state_dict().items()}
+    m.load_state_dict(sd0)                                   # state_dict round trip (scalar buffers included)
+    losses = []
+    for it in range(6):
+        opt.zero_grad()
+        loss, A, Bv = m.loss_backward(x, y1, y2, w1=10.0, w2=1.0)
+        assert np.isfinite(loss) and A > 0 and Bv > 0
+        assert abs(loss - (10.0 * A + Bv)) <= 1e-6 * abs(loss)
+        if it == 0:
+            assert len(m.grads) >= 90
+            for k, v in m.grads.items():
+                assert torch.isfinite(v.float()).all(), k
+        gn = opt.clip_and_step(10.0, 1e-3)
+        assert np.isfinite(gn) and gn > 0
+        losses.append(loss)
+    # Two training forwards of this randomly initialised net are not comparable number by number: its BatchNorm heads normalise
+    # a batch of nearly identical features, which amplifies the 1e-7 float-atomic noise of the pooling kernels (measured: 20 %
+    # differences in the head outputs between two forwards from one restored state, tests/micro/lc_repro.py), so the
+    # full-size check is the optimisation itself: six AdamW steps on one batch must reduce the loss.
+    assert min(losses[3:]) < 0.9 * losses[0], losses
