@@ -177,6 +177,11 @@ int sgv_adamw_step(sgv_engine* e, float lr);
  * optimisation step, last=1 on the final one; every bucket must be covered exactly once per step. */
 int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last);
 int sgv_bucket_count(const sgv_engine* e);
+/* Device memory held by the engine, bytes: out[0] fp32 master parameters, [1] gradient arena, [2] Adam moments, [3] compute-dtype
+ * weight copies, [4] activations of forward + backward at max_batch (everything stays resident: the reference's
+ * use_checkpointing flag is forced to False in its code, modules/VAE_network.py:68, and no recompute exists here either),
+ * [5] split-K / reduction workspaces. */
+int sgv_memory_info(const sgv_engine* e, size_t out[6]);
 /* Gradient 2-norm accumulated by the AdamW pass(es) of the current step (same value sgv_grad_norm computes in a
  * separate pass).  [sync] */
 int sgv_last_grad_norm(sgv_engine* e, double* out);

@@ -1603,12 +1603,14 @@ int sgv_rccl_unique_id(void* id128) {
     const int rc = g_rccl.GetUniqueId(id128);
     return rc ? rccl_fail("ncclGetUniqueId", rc) : SGV_OK;
 }
+static std::map<void*, int> g_comm_ranks;      // communicator -> number of ranks (one rank: the mean is the identity, nothing is issued)
 int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank) {
     if (!comm_out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(SGV_ERR_ARG, "bad argument");
     CHK(rccl_load());
     RcclApi::Id128 id;
     memcpy(id.b, id128, 128);
     const int rc = g_rccl.CommInitRank(comm_out, nranks, id, rank);
+    if (!rc) g_comm_ranks[*comm_out] = nranks;
     return rc ? rccl_fail("ncclCommInitRank", rc) : SGV_OK;
 }
 int sgv_rccl_comm_destroy(void* comm) {
@@ -1624,8 +1626,11 @@ static int rccl_bucket(sgv_engine* e, void* comm, hipStream_t cs, int b, hipEven
     HIPCHK(hipEventRecord(ev, e->stream));
     HIPCHK(hipStreamWaitEvent(cs, ev, 0));
     float* g = e->grads + e->buckets[b].first;
-    const int rc = g_rccl.AllReduce(g, g, e->buckets[b].second, kNcclFloat32, kNcclAvg, comm, cs);
-    if (rc) return rccl_fail("ncclAllReduce", rc);
+    auto it = g_comm_ranks.find(comm);
+    if (it == g_comm_ranks.end() || it->second != 1) {
+        const int rc = g_rccl.AllReduce(g, g, e->buckets[b].second, kNcclFloat32, kNcclAvg, comm, cs);
+        if (rc) return rccl_fail("ncclAllReduce", rc);
+    }
     if (done) HIPCHK(hipEventRecord(done, cs));
     return 0;
 }
@@ -1899,6 +1904,14 @@ int sgv_adamw_step(sgv_engine* e, float lr) {
     return sgv_adamw_step_range(e, lr, 0, nbk, 1, 1);
 }
 int sgv_bucket_count(const sgv_engine* e) { return e ? (int)e->buckets.size() : 0; }
+// device memory held by the engine, bytes: [0] fp32 master parameters, [1] gradient arena, [2] Adam m + v, [3] compute-dtype weight
+// copies, [4] activations (every map of forward and backward at max_batch: nothing is recomputed), [5] split-K / reduction workspaces
+int sgv_memory_info(const sgv_engine* e, size_t out[6]) {
+    if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
+    out[0] = e->n_params * 4; out[1] = e->n_grads * 4; out[2] = e->n_grads * 8; out[3] = e->n_copies * e->esz; out[4] = e->act_bytes;
+    out[5] = (e->partial_floats + e->partial_tn_floats + e->colpart_floats + e->red_floats + e->gn_part_floats + e->n_sn_tmp + e->xpose_floats) * 4;
+    return SGV_OK;
+}
 int sgv_last_grad_norm(sgv_engine* e, double* out) {
     if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
     double h = 0.0;

@@ -27,7 +27,13 @@ class VAE:
                              num_time, lossfun, bool(small))
         self.latent_dim = latent_dim
         self.lossfun = self.cfg.lossfun
-        self.use_checkpointing = False          # accepted and ignored, as in the reference (VAE_network.py:68)
+        # The reference accepts the flag and forces it to False (VAE_network.py:60,68: no recompute exists in its code).  False is
+        # accepted here; True is refused loudly rather than silently ignored: the engine keeps every activation resident
+        # (large model, batch 16, full size: see DESIGN.md section 12 for the measured bytes against the 288 GB of one MI355X)
+        if use_checkpointing:
+            raise NotImplementedError("use_checkpointing=True: activation recompute is not implemented; all activations of a step stay "
+                                      "resident in HBM (Engine.memory_info() reports the bytes); pass use_checkpointing=False")
+        self.use_checkpointing = False
         self.batch_size = int(batch_size)
         self.compute_dtype = compute_dtype
         self.training = True

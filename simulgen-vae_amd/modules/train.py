@@ -70,6 +70,11 @@ class _SumThenScale:
         self.seg.mul_(self.inv)
 
 
+class _Done:
+    def wait(self):
+        pass
+
+
 class GradAllReduce:
     """Bucketed mean all-reduce of the engine's flat gradient arena over RCCL, overlapped with backward (the
     engine calls `_on_bucket` as soon as the kernels producing a bucket are enqueued) and with AdamW (`step`
@@ -82,12 +87,16 @@ class GradAllReduce:
         self.group = group
         self.native_avg = dist.get_backend(group) == "nccl"
         self.inv_world = 1.0 / dist.get_world_size(group)
+        self.single = dist.get_world_size(group) == 1      # one rank: the mean over ranks is the identity, no collective is issued
         self.pending = []          # (bucket, work) in issue order == completion order on the RCCL stream
         self.nb = engine.bucket_count()
         engine.set_bucket_callback(self._on_bucket)
 
     def _on_bucket(self, b, off, cnt):
         seg = self.flat[off:off + cnt]
+        if self.single:
+            self.pending.append((b, _Done()))
+            return
         if self.native_avg:
             w = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
         else:

@@ -33,6 +33,10 @@ def test_config3_large_fullsize_batch16():
     assert len(names) >= 4, names
     eng = E.Engine(cfg, max_batch=B, compute_dtype="bf16")
     eng.load_state(state)
+    mem = eng.memory_info()
+    print("[configs[3] large, batch 16] device bytes:", {k: round(v / 2 ** 30, 2) for k, v in mem.items()}, "GiB; total",
+          round(sum(mem.values()) / 2 ** 30, 1), "GiB of 288")
+    assert sum(mem.values()) < 144 * 2 ** 30          # everything resident, no recompute: under half of one MI355X's HBM
     uv = {k: v for k, v in state.items() if k.endswith("weight_u") or k.endswith("weight_v")}
     g = torch.Generator(device="cuda").manual_seed(3)
     x = torch.rand((B, N, T), generator=g, device="cuda") * 1.4 - 0.7

@@ -290,3 +290,13 @@ def test_e2e_cosine_schedule_and_latent_scaler(tmp_path):
     assert load_scaler(str(tmp_path / "missing.pkl")) is None
     with pytest.raises(ValueError, match="Empty data array"):
         latent_conditioner_scaler(np.zeros((0, 4)), str(tmp_path / "c.pkl"))
+
+
+def test_use_checkpointing_true_is_refused_loudly():
+    """The reference forces use_checkpointing to False (VAE_network.py:60,68); the mirror accepts False and refuses True instead
+    of silently ignoring it (no recompute path exists: every activation stays resident)."""
+    from simulgen_vae_amd.modules.VAE_network import VAE
+    enc = [32, 16, 8, 8]
+    VAE(32, 8, enc, enc[::-1], 72, 10, use_checkpointing=False)
+    with pytest.raises(NotImplementedError, match="recompute"):
+        VAE(32, 8, enc, enc[::-1], 72, 10, use_checkpointing=True)
