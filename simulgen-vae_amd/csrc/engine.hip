@@ -172,6 +172,12 @@ struct sgv_engine {
     float* gn_part = nullptr; size_t gn_part_floats = 0;   // per-(tile, wave) GroupNorm partial sums of the 256x256 GEMM epilogue
     // deterministic reductions: block partials that nobody needs before the optimizer (GroupNorm affine / bias gradients,
     // <G,W_eff>) stay in this arena until the bucket they belong to is released, then two table-driven passes sum them
+    // second compute lane: the posterior branch of a decoder stage (xs lift, condition_xz) is independent of the prior branch
+    // (condition_z) between the residual block and the KL / reparameterisation kernel, in forward and in backward; both are chains
+    // of small kernels that leave most of the chip idle, so they run side by side on two streams with workspaces of their own
+    hipStream_t lane2 = nullptr; float* partial2 = nullptr; float* colpart2 = nullptr; float* gn_part2 = nullptr;
+    hipEvent_t lane_fork = nullptr, lane_join = nullptr;
+    int use_lanes = getenv("SGV_LANES") ? atoi(getenv("SGV_LANES")) : 1;
     float* red = nullptr; size_t red_floats = 0;
     std::vector<FinDot> fin_dots; std::vector<FinAffine> fin_affine;
     int dot_counts[512];
@@ -946,6 +952,27 @@ static GNParams gn_base(sgv_engine* e, const GNLayer& g, int B) {
     return p;
 }
 
+// Scope that runs the calls it encloses on the second compute lane (stream + split-K / reduction workspaces swapped in); the lane
+// first waits for everything enqueued on the main stream so far.  lane2_join() makes the main stream wait for the lane.
+struct Lane2 {
+    sgv_engine* e; hipStream_t s0; float* p0; float* c0; float* g0; bool on;
+    explicit Lane2(sgv_engine* e_) : e(e_), s0(e_->stream), p0(e_->partial), c0(e_->colpart), g0(e_->gn_part) {
+        on = e->use_lanes && e->lane2 && !e->timing;
+        if (!on) return;
+        hipEventRecord(e->lane_fork, e->stream);
+        hipStreamWaitEvent(e->lane2, e->lane_fork, 0);
+        e->stream = e->lane2; e->partial = e->partial2; e->colpart = e->colpart2; e->gn_part = e->gn_part2;
+    }
+    ~Lane2() {
+        if (!on) return;
+        hipEventRecord(e->lane_join, e->lane2);
+        e->stream = s0; e->partial = p0; e->colpart = c0; e->gn_part = g0;
+    }
+};
+static void lane2_join(sgv_engine* e) {
+    if (e->use_lanes && e->lane2 && !e->timing) hipStreamWaitEvent(e->stream, e->lane_join, 0);
+}
+
 static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
     const long M = (long)B * e->T;
     Tensor x = in;
@@ -1121,6 +1148,13 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     e->gn_part_floats = 0;
     for (auto& l : e->layers) if (l.used && l.op != OP_LINEAR) e->gn_part_floats = std::max(e->gn_part_floats, gemm_nt256_part_floats((int)M, l.cout, 1));
     ALLOC(e->gn_part, e->gn_part_floats * 4);
+    if (e->use_lanes && hipStreamCreateWithFlags(&e->lane2, hipStreamNonBlocking) == hipSuccess &&
+        hipEventCreateWithFlags(&e->lane_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->lane_join, hipEventDisableTiming) == hipSuccess) {
+        ALLOC(e->partial2, e->partial_floats * 4);
+        ALLOC(e->gn_part2, e->gn_part_floats * 4);
+    } else {
+        e->use_lanes = 0;
+    }
     {
         size_t nr = 0;
         for (auto& g : e->gns) { g.ptot = nr; nr += align_up((size_t)e->maxB * 3 * g.C, 4); }
@@ -1132,6 +1166,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
     ALLOC(e->colpart, e->colpart_floats * 4);
+    if (e->use_lanes) ALLOC(e->colpart2, e->colpart_floats * 4);
 #undef ALLOC
     rebase_all(e);
     if ((r = upload_tables(e))) { sgv_destroy(e); return r; }
@@ -1144,10 +1179,13 @@ int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
     void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_alpha, e->sn_dot_dummy,
-                    e->scal, e->partial, e->partial_tn, e->gn_part, e->red, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
+                    e->scal, e->partial, e->partial_tn, e->partial2, e->colpart2, e->gn_part2, e->gn_part, e->red, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
                     e->items_sn_unf, e->items_adam_flat, e->items_adam_2d, e->items_ts, e->items_ss, e->lin_dot_part, e->gnorm_part};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
+    if (e->lane2) { hipStreamSynchronize(e->lane2); hipStreamDestroy(e->lane2); }
+    if (e->lane_fork) hipEventDestroy(e->lane_fork);
+    if (e->lane_join) hipEventDestroy(e->lane_join);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     delete e;
@@ -1403,16 +1441,18 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
         CHK(block_fwd(e, e->decD[i], e->decU[i].st.back().a, B));
         if (i == n_st - 1) break;
         const int C = e->dec[i + 1];
-        CHK(block_fwd(e, e->decP1[i], e->dec_out[i], B));
-        CHK(block_fwd(e, e->decP2[i], e->decP1[i].st.back().a, B));
-        {
+        {   // posterior branch (xs lift -> condition_xz) on the second lane, beside the prior branch below
+            Lane2 lane(e);
             const Layer& l = e->layers[e->xs_exp[i]];
             const int lvl = n - 2 - i;
             ew_linear_expand_fwd(e->dt, e->xs_raw[lvl], e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xl[i].p, B, l.cin, l.cout, e->stream);
+            CHK(block_fwd(e, e->decX[i], e->xl[i], B));
+            CHK(block_fwd(e, e->decQ1[i], e->cat[i], B));
+            CHK(block_fwd(e, e->decQ2[i], e->decQ1[i].st.back().a, B));
         }
-        CHK(block_fwd(e, e->decX[i], e->xl[i], B));
-        CHK(block_fwd(e, e->decQ1[i], e->cat[i], B));
-        CHK(block_fwd(e, e->decQ2[i], e->decQ1[i].st.back().a, B));
+        CHK(block_fwd(e, e->decP1[i], e->dec_out[i], B));
+        CHK(block_fwd(e, e->decP2[i], e->decP1[i].st.back().a, B));
+        lane2_join(e);
         ew_stage_fwd(e->dt, (const float*)e->decP2[i].st[0].y.p, (const float*)e->decQ2[i].st[0].y.p, e->eps[i + 1], e->dec_out[i].p, e->dec_out[i].ld,
                      e->zs[i + 1].p, e->zs[i + 1].ld, e->zmap[i], (int)M, C, mode_fix ? 1e-10f : 1.0f, e->scal + 3 + i, 1.0f / B, (double*)e->colpart, e->stream);
     }
@@ -1755,12 +1795,13 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         if (i < n_st - 1) {
             ew_stage_bwd(e->dt, (const float*)e->decP2[i].st[0].y.p, (const float*)e->decQ2[i].st[0].y.p, e->eps[i + 1], e->dzs[i + 1].p, e->dzs[i + 1].ld,
                          e->gp[i].p, e->gq[i].p, (int)M, C, coefB, e->stream);
-            CHK(block_bwd(e, e->decQ2[i], e->decQ1[i].st.back().a, e->gq[i], &e->d_qres[i], B));
-            CHK(block_bwd(e, e->decQ1[i], e->cat[i], e->d_qres[i], &e->dcat[i], B));
             Tensor d_xs = e->dcat[i]; d_xs.C = C;
             Tensor d_oq = e->dcat[i]; d_oq.C = C; d_oq.p = (char*)d_oq.p + (size_t)C * e->esz;
-            CHK(block_bwd(e, e->decX[i], e->xl[i], d_xs, &e->d_xl[i], B));
-            {
+            {   // posterior branch on the second lane, beside the prior branch below (they meet in the add3 after the join)
+                Lane2 lane(e);
+                CHK(block_bwd(e, e->decQ2[i], e->decQ1[i].st.back().a, e->gq[i], &e->d_qres[i], B));
+                CHK(block_bwd(e, e->decQ1[i], e->cat[i], e->d_qres[i], &e->dcat[i], B));
+                CHK(block_bwd(e, e->decX[i], e->xl[i], d_xs, &e->d_xl[i], B));
                 const Layer& l = e->layers[e->xs_exp[i]];
                 const int lvl = n - 2 - i;
                 ew_linear_expand_bwd(e->dt, e->d_xl[i].p, e->xs_raw[lvl], e->params + l.w, e->sn_sigma + 2 * l.sn + 1, e->d_xs_raw[lvl],
@@ -1768,6 +1809,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             }
             CHK(block_bwd(e, e->decP2[i], e->decP1[i].st.back().a, e->gp[i], &e->d_pres[i], B));
             CHK(block_bwd(e, e->decP1[i], e->dec_out[i], e->d_pres[i], &e->d_outp[i], B));
+            lane2_join(e);
             ew_add3(e->dt, e->d_outp[i].p, e->d_outp[i].ld, e->dzs[i + 1].p, e->dzs[i + 1].ld, d_oq.p, d_oq.ld, e->d_out[i].p, e->d_out[i].ld, (int)M, C, e->stream);
         }
         CHK(block_bwd(e, e->decD[i], e->decU[i].st.back().a, e->d_out[i], &e->d_u[i], B));
@@ -1909,7 +1951,7 @@ int sgv_bucket_count(const sgv_engine* e) { return e ? (int)e->buckets.size() : 
 int sgv_memory_info(const sgv_engine* e, size_t out[6]) {
     if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
     out[0] = e->n_params * 4; out[1] = e->n_grads * 4; out[2] = e->n_grads * 8; out[3] = e->n_copies * e->esz; out[4] = e->act_bytes;
-    out[5] = (e->partial_floats + e->partial_tn_floats + e->colpart_floats + e->red_floats + e->gn_part_floats + e->n_sn_tmp + e->xpose_floats) * 4;
+    out[5] = ((e->use_lanes ? 2 : 1) * (e->partial_floats + e->colpart_floats + e->gn_part_floats) + e->partial_tn_floats + e->red_floats + e->n_sn_tmp + e->xpose_floats) * 4;
     return SGV_OK;
 }
 int sgv_last_grad_norm(sgv_engine* e, double* out) {
