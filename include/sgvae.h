@@ -177,6 +177,18 @@ int sgv_adamw_step(sgv_engine* e, float lr);
  * optimisation step, last=1 on the final one; every bucket must be covered exactly once per step. */
 int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last);
 int sgv_bucket_count(const sgv_engine* e);
+/* Wire format of the data-parallel gradient exchange (the reference's DDP all-reduces fp32 gradients, modules/utils.py:209-238
+ * sets the process group up and torch does the rest; this is the build's own choice for bf16 engines).  SGV_DTYPE_F32: the
+ * buckets are ranges of the fp32 arena (default).  SGV_DTYPE_BF16: at its fire point every weight bucket is rounded (RNE) into a
+ * bf16 copy at the same element offset of the payload buffer; the collective averages THAT range (the bucket callback receives
+ * the same offset / count; with sgv_set_rccl the engine issues ncclAllReduce on it), and sgv_adamw_step / _range write it back
+ * into the fp32 arena in front of the bucket's update.  The last (small) bucket -- biases, GroupNorm affine, <G,W> scalars --
+ * always travels in fp32.  Halves the bytes on the xGMI links (0.80 of 1.61 GB per step for preset 1).
+ * sgv_grad_payload_unpack writes back every bucket still packed (use before reading gradients with sgv_grad_norm / sgv_get_grad
+ * when no optimiser step follows). */
+int sgv_set_grad_payload(sgv_engine* e, int dtype);
+int sgv_grad_payload_buffer(sgv_engine* e, void** dev_ptr, size_t* count_elems);
+int sgv_grad_payload_unpack(sgv_engine* e);
 /* Device memory held by the engine, bytes: out[0] fp32 master parameters, [1] gradient arena, [2] Adam moments, [3] compute-dtype
  * weight copies, [4] activations of forward + backward at max_batch (everything stays resident: the reference's
  * use_checkpointing flag is forced to False in its code, modules/VAE_network.py:68, and no recompute exists here either),

@@ -141,6 +141,9 @@ struct sgv_engine {
     std::vector<char> aug_host[4]; int aug_turn = 0;                  // staging of sgv_augment_collate's control arrays
     void* comm = nullptr; hipStream_t comm_stream = nullptr;          // native RCCL path (sgv_set_rccl)
     std::vector<hipEvent_t> bucket_done; std::vector<char> bucket_pending;
+    // data-parallel wire format of the weight buckets: 0 = the fp32 arena itself, 1 = a bf16 copy (packed at the bucket's fire point,
+    // averaged by the collective, unpacked into the arena in front of the bucket's AdamW).  The small bucket always travels in fp32.
+    int payload_bf16 = 0; void* grads_lp = nullptr; std::vector<char> bucket_packed;
     float* partial_tn = nullptr; size_t partial_tn_floats = 0;
     std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
     bool use_side = true, side_dirty = false;
@@ -1188,6 +1191,7 @@ int sgv_destroy(sgv_engine* e) {
     if (e->lane_join) hipEventDestroy(e->lane_join);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
+    if (e->grads_lp) hipFree(e->grads_lp);
     delete e;
     return SGV_OK;
 }
@@ -1615,7 +1619,7 @@ struct RcclApi {
     const char* (*GetErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
-const int kNcclFloat32 = 7, kNcclAvg = 4;      // ncclDataType_t / ncclRedOp_t values of rccl.h (NCCL >= 2.10 ABI)
+const int kNcclFloat32 = 7, kNcclBfloat16 = 9, kNcclAvg = 4;      // ncclDataType_t / ncclRedOp_t values of rccl.h (NCCL >= 2.10 ABI)
 int rccl_load() {
     if (g_rccl.h) return 0;
     const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
@@ -1644,6 +1648,7 @@ int sgv_rccl_unique_id(void* id128) {
     return rc ? rccl_fail("ncclGetUniqueId", rc) : SGV_OK;
 }
 static std::map<void*, int> g_comm_ranks;      // communicator -> number of ranks (one rank: the mean is the identity, nothing is issued)
+static bool comm_is_single(void* comm) { auto it = g_comm_ranks.find(comm); return it != g_comm_ranks.end() && it->second == 1; }
 int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank) {
     if (!comm_out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(SGV_ERR_ARG, "bad argument");
     CHK(rccl_load());
@@ -1668,7 +1673,9 @@ static int rccl_bucket(sgv_engine* e, void* comm, hipStream_t cs, int b, hipEven
     float* g = e->grads + e->buckets[b].first;
     auto it = g_comm_ranks.find(comm);
     if (it == g_comm_ranks.end() || it->second != 1) {
-        const int rc = g_rccl.AllReduce(g, g, e->buckets[b].second, kNcclFloat32, kNcclAvg, comm, cs);
+        const bool lp = b < (int)e->bucket_packed.size() && e->bucket_packed[b];
+        void* w = lp ? (void*)((char*)e->grads_lp + 2 * e->buckets[b].first) : (void*)g;
+        const int rc = g_rccl.AllReduce(w, w, e->buckets[b].second, lp ? kNcclBfloat16 : kNcclFloat32, kNcclAvg, comm, cs);
         if (rc) return rccl_fail("ncclAllReduce", rc);
     }
     if (done) HIPCHK(hipEventRecord(done, cs));
@@ -1744,6 +1751,11 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     int early_err = 0;
     auto fire_at = [&](int b) {
         if (b < 0 || b >= (int)e->buckets.size()) return;
+        if (e->payload_bf16 && (e->comm || e->cb) && b != (int)e->buckets.size() - 1 && !(e->comm && comm_is_single(e->comm))) {
+            if (join_side(e)) { early_err = 1; return; }
+            ew_pack_bf16(e->grads + e->buckets[b].first, (char*)e->grads_lp + 2 * e->buckets[b].first, (long)e->buckets[b].second, e->stream);
+            e->bucket_packed[b] = 1;
+        }
         if (e->comm) {
             if (join_side(e) || rccl_bucket(e, e->comm, e->comm_stream, b, e->bucket_done[b])) { early_err = 1; return; }
             e->bucket_pending[b] = 1;
@@ -1907,6 +1919,11 @@ static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, in
             HIPCHK(hipStreamWaitEvent(st, e->bucket_done[b], 0));
             e->bucket_pending[b] = 0;
         }
+    for (int b = bucket_lo; b < bucket_hi && b < (int)e->bucket_packed.size(); ++b)
+        if (e->bucket_packed[b]) {      // the averaged bf16 wire copy back into the fp32 arena AdamW reads
+            ew_unpack_bf16((const char*)e->grads_lp + 2 * e->buckets[b].first, e->grads + e->buckets[b].first, (long)e->buckets[b].second, st);
+            e->bucket_packed[b] = 0;
+        }
     const double b1 = 0.9, b2 = 0.999;
     const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
     const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
@@ -1946,6 +1963,31 @@ int sgv_adamw_step(sgv_engine* e, float lr) {
     return sgv_adamw_step_range(e, lr, 0, nbk, 1, 1);
 }
 int sgv_bucket_count(const sgv_engine* e) { return e ? (int)e->buckets.size() : 0; }
+int sgv_set_grad_payload(sgv_engine* e, int dtype) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (dtype != SGV_DTYPE_F32 && dtype != SGV_DTYPE_BF16) return fail(SGV_ERR_ARG, "gradient payload must be f32 or bf16");
+    for (char c : e->bucket_packed) if (c) return fail(SGV_ERR_STATE, "a packed bucket is in flight: change the payload between steps");
+    if (dtype == SGV_DTYPE_BF16 && !e->grads_lp) HIPCHK(hipMalloc(&e->grads_lp, e->n_grads * 2));
+    e->payload_bf16 = dtype == SGV_DTYPE_BF16;
+    e->bucket_packed.assign(e->buckets.size(), 0);
+    return SGV_OK;
+}
+int sgv_grad_payload_buffer(sgv_engine* e, void** ptr, size_t* count) {
+    if (!e || !ptr || !count) return fail(SGV_ERR_ARG, "null argument");
+    if (!e->payload_bf16) return fail(SGV_ERR_STATE, "the gradient payload is the fp32 arena (sgv_grad_buffer)");
+    *ptr = e->grads_lp; *count = e->n_grads;
+    return SGV_OK;
+}
+int sgv_grad_payload_unpack(sgv_engine* e) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    for (int b = 0; b < (int)e->bucket_packed.size(); ++b)
+        if (e->bucket_packed[b]) {
+            if (b < (int)e->bucket_pending.size() && e->bucket_pending[b]) { HIPCHK(hipStreamWaitEvent(e->stream, e->bucket_done[b], 0)); e->bucket_pending[b] = 0; }
+            ew_unpack_bf16((const char*)e->grads_lp + 2 * e->buckets[b].first, e->grads + e->buckets[b].first, (long)e->buckets[b].second, e->stream);
+            e->bucket_packed[b] = 0;
+        }
+    return SGV_OK;
+}
 // device memory held by the engine, bytes: [0] fp32 master parameters, [1] gradient arena, [2] Adam m + v, [3] compute-dtype weight
 // copies, [4] activations (every map of forward and backward at max_batch: nothing is recomputed), [5] split-K / reduction workspaces
 int sgv_memory_info(const sgv_engine* e, size_t out[6]) {

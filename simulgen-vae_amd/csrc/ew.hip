@@ -1566,6 +1566,50 @@ int ew_fill_from_scalar(float* dst, const float* src_scalar, long n, hipStream_t
     hipLaunchKernelGGL(fill_from_scalar_kernel, dim3(blocks), dim3(256), 0, s, dst, src_scalar, n);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
+// gradient payload of the data-parallel step: fp32 arena range <-> bf16 wire copy (round to nearest even), 8 elements per thread
+template <bool VEC>
+__global__ __launch_bounds__(256) void pack_bf16_kernel(const float* __restrict__ src, bf16_t* __restrict__ dst, long n) {
+    const long step = (long)gridDim.x * 256 * 8;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += step) {
+        if (VEC && i + 8 <= n) {
+            const float4 a = *reinterpret_cast<const float4*>(src + i), b = *reinterpret_cast<const float4*>(src + i + 4);
+            const float v[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+            store8(dst + i, v);
+        } else {
+            for (long j = i; j < i + 8 && j < n; ++j) dst[j] = from_f32<bf16_t>(src[j]);
+        }
+    }
+}
+template <bool VEC>
+__global__ __launch_bounds__(256) void unpack_bf16_kernel(const bf16_t* __restrict__ src, float* __restrict__ dst, long n) {
+    const long step = (long)gridDim.x * 256 * 8;
+    for (long i = ((long)blockIdx.x * 256 + threadIdx.x) * 8; i < n; i += step) {
+        if (VEC && i + 8 <= n) {
+            float v[8];
+            load8(src + i, v);
+            *reinterpret_cast<float4*>(dst + i) = make_float4(v[0], v[1], v[2], v[3]);
+            *reinterpret_cast<float4*>(dst + i + 4) = make_float4(v[4], v[5], v[6], v[7]);
+        } else {
+            for (long j = i; j < i + 8 && j < n; ++j) dst[j] = to_f32(src[j]);
+        }
+    }
+}
+int ew_pack_bf16(const float* src, void* dst, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    int blocks = (int)std::min<long>((n + 2047) / 2048, 4096);
+    const bool vec = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    if (vec) hipLaunchKernelGGL(pack_bf16_kernel<true>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, n);
+    else hipLaunchKernelGGL(pack_bf16_kernel<false>, dim3(blocks), dim3(256), 0, s, src, (bf16_t*)dst, n);
+    return 0;
+}
+int ew_unpack_bf16(const void* src, float* dst, long n, hipStream_t s) {
+    if (n <= 0) return 0;
+    int blocks = (int)std::min<long>((n + 2047) / 2048, 4096);
+    const bool vec = ((uintptr_t)src % 16 == 0) && ((uintptr_t)dst % 16 == 0);
+    if (vec) hipLaunchKernelGGL(unpack_bf16_kernel<true>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, dst, n);
+    else hipLaunchKernelGGL(unpack_bf16_kernel<false>, dim3(blocks), dim3(256), 0, s, (const bf16_t*)src, dst, n);
+    return 0;
+}
 int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s) {
     int blocks = cdiv_i(n, 256);
     if (blocks > 2048) blocks = 2048;

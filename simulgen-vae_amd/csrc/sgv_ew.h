@@ -77,6 +77,8 @@ int ew_linear_expand_bwd(int dtype, const void* dY, const float* X, const float*
                          float* db, int B, int K, int O, hipStream_t s);
 int ew_augment(int dtype, const void* data, void* out, long sample_elems, int batch, const int* idx,
                const unsigned long long* noise_seed, const float* scale, const int* mix_idx, const float* lam, hipStream_t s);
+int ew_pack_bf16(const float* src, void* dst_bf16, long n, hipStream_t s);     // data-parallel gradient payload: fp32 -> bf16 (RNE)
+int ew_unpack_bf16(const void* src_bf16, float* dst, long n, hipStream_t s);
 int ew_axpy(float* y, const float* x, float a, long n, hipStream_t s);
 int ew_scale3(float* d0, float* d1, float* d2, const float* x, float a, long n, hipStream_t s);   // d_k = a * x[k*n .. (k+1)*n)
 int ew_fill_from_scalar(float* dst, const float* src_scalar, long n, hipStream_t s);   // dst[i] = *src_scalar

@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
-    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
+    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_rccl_unique_id", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_lib", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_gemm_tn",
@@ -88,6 +88,9 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_backward_step.argtypes = [vp, f32, f32, f32]
     lib.sgv_adamw_step_range.argtypes = [vp, f32, i32, i32, i32, i32]
     lib.sgv_bucket_count.argtypes = [vp]
+    lib.sgv_set_grad_payload.argtypes = [vp, C.c_int]
+    lib.sgv_grad_payload_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
+    lib.sgv_grad_payload_unpack.argtypes = [vp]
     lib.sgv_rccl_unique_id.argtypes = [vp]
     lib.sgv_rccl_comm_init.argtypes = [C.POINTER(vp), i32, vp, i32]
     lib.sgv_rccl_comm_destroy.argtypes = [vp]
@@ -325,6 +328,19 @@ class Engine:
         p, n = C.c_void_p(), C.c_size_t()
         _check(self.lib, self.lib.sgv_grad_buffer(self.h, C.byref(p), C.byref(n)), "sgv_grad_buffer")
         return p.value, n.value
+
+    def set_grad_payload(self, dtype: str):
+        """Wire format of the data-parallel weight buckets: "f32" (the arena itself) or "bf16" (include/sgvae.h: sgv_set_grad_payload)."""
+        _check(self.lib, self.lib.sgv_set_grad_payload(self.h, DTYPES[dtype]), "sgv_set_grad_payload")
+
+    def grad_payload_buffer(self):
+        """(device pointer, element count) of the bf16 payload buffer (same element offsets as the fp32 arena)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        _check(self.lib, self.lib.sgv_grad_payload_buffer(self.h, C.byref(p), C.byref(n)), "sgv_grad_payload_buffer")
+        return p.value, n.value
+
+    def grad_payload_unpack(self):
+        _check(self.lib, self.lib.sgv_grad_payload_unpack(self.h), "sgv_grad_payload_unpack")
 
     def scale_grads(self, f: float):
         _check(self.lib, self.lib.sgv_scale_grads(self.h, float(f)), "sgv_scale_grads")

@@ -55,8 +55,17 @@ def cosine_warm_restarts_lr(base_lr, epochs, epoch, t_mult=2, eta_min_factor=1e-
 
 
 class _DevArray:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f4", "data": (ptr, False), "version": 2}
+    def __init__(self, ptr, n, typestr="<f4"):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def grad_payload_dtype(engine):
+    """Wire format of the weight-gradient buckets: SGV_GRAD_PAYLOAD=f32|bf16, default bf16 for a bf16 engine (its gradients
+    carry bf16 rounding already; the all-reduce is link-bound) and f32 for an fp32 engine."""
+    v = os.environ.get("SGV_GRAD_PAYLOAD", "").lower()
+    if v in ("f32", "fp32", "bf16"):
+        return "bf16" if v == "bf16" else "f32"
+    return "bf16" if engine.compute_dtype in ("bf16", "bfloat16") else "f32"
 
 
 class _SumThenScale:
@@ -81,7 +90,7 @@ class GradAllReduce:
     updates every layer whose bucket has arrived while the last, first-encoder-layer bucket is still in flight).
     Under a gloo group (tests, debugging) the mean is SUM followed by a scale, same bucket order."""
 
-    def __init__(self, engine, group=None):
+    def __init__(self, engine, group=None, payload=None):
         ptr, n = engine.grad_buffer()
         self.flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         self.group = group
@@ -90,10 +99,16 @@ class GradAllReduce:
         self.single = dist.get_world_size(group) == 1      # one rank: the mean over ranks is the identity, no collective is issued
         self.pending = []          # (bucket, work) in issue order == completion order on the RCCL stream
         self.nb = engine.bucket_count()
+        # bf16 wire copy of the weight buckets (the engine packs at the fire point and unpacks in front of the bucket's AdamW)
+        self.flat_lp = None
+        if (payload or grad_payload_dtype(engine)) == "bf16" and not self.single:
+            engine.set_grad_payload("bf16")
+            lp_ptr, lp_n = engine.grad_payload_buffer()
+            self.flat_lp = torch.as_tensor(_DevArray(lp_ptr, lp_n, "<i2"), device="cuda").view(torch.bfloat16)
         engine.set_bucket_callback(self._on_bucket)
 
     def _on_bucket(self, b, off, cnt):
-        seg = self.flat[off:off + cnt]
+        seg = self.flat[off:off + cnt] if self.flat_lp is None or b == self.nb - 1 else self.flat_lp[off:off + cnt]
         if self.single:
             self.pending.append((b, _Done()))
             return
@@ -108,6 +123,8 @@ class GradAllReduce:
         for _, w in self.pending:
             w.wait()
         self.pending.clear()
+        if self.flat_lp is not None:
+            engine.grad_payload_unpack()
 
     def step(self, engine, lr):
         """wait(all but the final bucket) -> AdamW on those -> wait(final) -> AdamW on it.  The waits are
@@ -151,6 +168,8 @@ class NativeAllReduce:
         if lib.sgv_rccl_comm_init(C.byref(comm), world, ident, rank) != 0:
             raise RuntimeError(lib.sgv_last_error().decode())
         self.comm = comm.value
+        if world > 1 and grad_payload_dtype(engine) == "bf16":
+            engine.set_grad_payload("bf16")      # the engine packs, all-reduces the bf16 copy and unpacks by itself
         self.stream = torch.cuda.Stream()
         engine.set_rccl(self.comm, self.stream.cuda_stream)
 

@@ -1,5 +1,5 @@
 """Standalone GEMM microbenchmark through the C ABI (for rocprofv3 counter passes).
-   python tests/micro/gemm_bench.py nt M N K taps [reps]   |   tn M N1 N2 taps [reps]"""
+   python tests/micro/gemm_bench.py {nt,nt256} M N K taps [reps]   |   tn M N1 N2 taps [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
@@ -11,14 +11,17 @@ a, b, c, taps = (int(v) for v in sys.argv[2:6])
 reps = int(sys.argv[6]) if len(sys.argv) > 6 else 5
 T = 200
 torch.manual_seed(0)
-if kind == "nt":
+if kind in ("nt", "nt256"):
     M, N, K = a, b, c
     A = torch.randn(M, K, device="cuda").to(torch.bfloat16)
     W = (torch.randn(taps, N, K, device="cuda") * 0.05).to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     sk = int(os.environ.get("SPLITK", "1"))
     def run():
-        rc = lib.sgv_test_gemm_nt(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, None)
+        if kind == "nt256":     # the planner's choice for the shape (256x256 persistent kernel + 128-row tail); the call allocates its workspaces
+            rc = lib.sgv_test_gemm_nt256(A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, 1, 0, None, None, None)
+        else:
+            rc = lib.sgv_test_gemm_nt(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, None)
         assert rc == 0, lib.sgv_last_error()
     flops = 2.0 * M * N * K * taps
 else:

@@ -308,7 +308,7 @@ def test_native_rccl_path_equals_plain_step():
             dist.destroy_process_group()
 
 
-def _two_rank_worker(rank, world, port, out_dir):
+def _two_rank_worker(rank, world, port, out_dir, payload="f32"):
     """One data-parallel rank of test_two_rank_data_parallel_steps: real engine on cuda:0, gloo group (RCCL refuses two
     ranks on one device), modules.train.GradAllReduce exactly as train() uses it."""
     import torch.distributed as dist
@@ -324,7 +324,8 @@ def _two_rank_worker(rank, world, port, out_dir):
     eng = Engine(cfg, max_batch=B, compute_dtype="f32")
     eng.load_state(init_state(cfg, 11, reference_init=True))
     eng.seed(100 + rank)
-    ar = GradAllReduce(eng)
+    ar = GradAllReduce(eng, payload=payload)
+    assert (ar.flat_lp is not None) == (payload == "bf16")
     norms = []
     for step in range(3):
         eng.set_input(x)
@@ -340,11 +341,15 @@ def _two_rank_worker(rank, world, port, out_dir):
     dist.destroy_process_group()
 
 
-def test_two_rank_data_parallel_steps(tmp_path):
+@pytest.mark.parametrize("payload", ["f32", "bf16"])
+def test_two_rank_data_parallel_steps(tmp_path, payload):
     """SURVEY 8(e) with two real ranks: two processes, each with its own engine and its own shard / noise seed, average
     their gradient buckets through modules.train.GradAllReduce (bucket callbacks during backward, bucket-ranged AdamW).
     Expected state: the same three steps in ONE process, where the two shards' gradient arenas are averaged by hand
-    before AdamW.  Both ranks must end with the same parameters."""
+    before AdamW.  Both ranks must end with the same parameters.
+    payload "bf16": the weight buckets travel as bf16 copies (sgv_set_grad_payload); the hand average then rounds each
+    rank's weight-bucket gradients to bf16, adds them in bf16 and halves (what the collective computes), the small bucket
+    stays fp32 -- same tolerance, because the expectation models the wire format."""
     import socket
     import torch.multiprocessing as mp
     from simulgen_vae_amd.engine import Engine
@@ -355,7 +360,7 @@ def test_two_rank_data_parallel_steps(tmp_path):
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, port, str(tmp_path), payload), nprocs=2, join=True)
     got = [dict(np.load(tmp_path / f"rank{r}.npz")) for r in range(2)]
 
     cfg = make_cfg(G1)
@@ -370,12 +375,23 @@ def test_two_rank_data_parallel_steps(tmp_path):
         flats.append(torch.as_tensor(_DevArray(ptr, n), device="cuda"))
         xs.append(torch.from_numpy(synthetic_samples(5, range(r * B, (r + 1) * B), cfg.num_node, cfg.num_time)).cuda())
     norms = []
+    ranges = []
+    engs[0].set_bucket_callback(lambda b, off, cnt: ranges.append((b, off, cnt)))
     for step in range(3):
         for e, x in zip(engs, xs):
             e.set_input(x)
             e.forward(train=True)
             e.backward(1e6, 1e-4)
+        if step == 0:
+            engs[0].set_bucket_callback(None)
+            assert sorted(b for b, _, _ in ranges) == list(range(engs[0].bucket_count()))
         mean = (flats[0] + flats[1]) * 0.5
+        if payload == "bf16":
+            small = engs[0].bucket_count() - 1
+            for b, off, cnt in ranges:
+                if b != small:
+                    sl = slice(off, off + cnt)
+                    mean[sl] = ((flats[0][sl].bfloat16() + flats[1][sl].bfloat16()) * 0.5).float()
         for e, f in zip(engs, flats):
             f.copy_(mean)
             e.adamw_step(1e-3)

@@ -64,18 +64,45 @@ def traffic(fetch_csv, write_csv):
         corr = 2.0 if name == "FETCH_SIZE" else 1.0
         for x in step:
             k = x["Kernel_Name"]
-            fam = next((n for n in ("gemm_nt_wide64p_kernel", "gemm_nt_reduce_kernel", "gemm_nt_kernel", "gemm_tn_w2_kernel", "gemm_tn_kernel",
-                                    "sum_slabs_kernel", "adamw_sn_kernel") if n in k), None)
+            fam = next((n for n in ("gemm_nt_t256_kernel", "t256_reduce_kernel", "gemm_nt_wide64p_kernel", "gemm_nt_reduce", "gemm_nt_kernel",
+                                    "gemm_tn_w2_kernel", "gemm_tn_kernel", "sum_slabs_kernel", "adamw_sn_kernel") if n in k), None)
             if fam is None:
                 continue
+            aux = fam in ("t256_reduce_kernel",)    # the 256x256 kernel's split-K combine: bytes of its class, not a launch of it
             if fam == "gemm_tn_kernel":
                 fam = "gemm_tn_w2_kernel"      # one weight-gradient class (bench.py's roofline_gemm_tn covers both kernels)
+            if fam == "t256_reduce_kernel":
+                fam = "gemm_nt_t256_kernel"
             d = out.setdefault(fam, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
             d["fetch_bytes" if name == "FETCH_SIZE" else "write_bytes"] += float(x["Counter_Value"]) * 1024 * corr
-            if name == "FETCH_SIZE":
+            if name == "FETCH_SIZE" and not aux:
                 d["launches"] += 1
     out["note"] = ("one training step of bench.py (batch 16, bf16) under rocprofv3 --pmc; FETCH_SIZE x2 (gfx950 correction, "
                    "MI355X_MICROARCH.md HBM section), WRITE_SIZE x1, counters in KiB")
+    print(json.dumps(out, indent=1))
+
+
+def traffic_lc(fetch_csv, write_csv):
+    """Latent-conditioner bench (bench.py --workload lc): bytes of the two GEMM operator classes over the whole profiled run
+    (every step is the same), keys lc_gemm_nt / lc_gemm_tn; a launch = one main kernel (its split-K combine adds bytes only)."""
+    import json
+    out = {}
+    for path in (fetch_csv, write_csv):
+        rows = list(csv.DictReader(open(path)))
+        name = rows[0]["Counter_Name"]
+        corr = 2.0 if name == "FETCH_SIZE" else 1.0
+        for x in rows:
+            k = x["Kernel_Name"]
+            if "gemm_tn" in k or "sum_slabs" in k:
+                fam, main = "lc_gemm_tn", "gemm_tn" in k
+            elif "gemm_nt" in k or "t256_reduce" in k:
+                fam, main = "lc_gemm_nt", ("reduce" not in k)
+            else:
+                continue
+            d = out.setdefault(fam, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
+            d["fetch_bytes" if name == "FETCH_SIZE" else "write_bytes"] += float(x["Counter_Value"]) * 1024 * corr
+            if name == "FETCH_SIZE" and main:
+                d["launches"] += 1
     print(json.dumps(out, indent=1))
 
 
@@ -84,5 +111,7 @@ if __name__ == "__main__":
         stats(sys.argv[2], int(sys.argv[3]))
     elif sys.argv[1] == "traffic":
         traffic(sys.argv[2], sys.argv[3])
+    elif sys.argv[1] == "traffic_lc":
+        traffic_lc(sys.argv[2], sys.argv[3])
     else:
         pmc(sys.argv[2])
