@@ -58,3 +58,47 @@ def synthetic_eps(seed: int, step: int, cfg: VAEConfig, batch: int):
     dec = cfg.num_filter_dec
     shapes = [(batch, cfg.latent_dim)] + [(batch, dec[i + 1], cfg.num_time) for i in range(len(dec) - 2)]
     return [_rng(seed, step * 16 + i).standard_normal(s).astype(np.float32) for i, s in enumerate(shapes)]
+
+
+def lc_init_state(shapes: dict, seed: int) -> dict:
+    """Seeded state for the image latent conditioner, keyed like its state_dict (`shapes`: name -> shape): He-uniform
+    weights, unit-norm spectral-norm vectors, norm scales near one, small biases, fresh BatchNorm buffers.  Used by the
+    loop fixtures (tests/golden/gen_lc_loop_fixtures.py loads it into the REFERENCE model, tests/test_lc_loop_gpu.py into
+    the mirror), so that both start from the same numbers without the fixture carrying any weights."""
+    out = {}
+    for idx, name in enumerate(sorted(shapes)):
+        shape = tuple(int(d) for d in shapes[name])
+        rng = _rng(seed, 5000 + idx)
+        if name.endswith("num_batches_tracked"):
+            out[name] = np.zeros(shape, np.int64)
+        elif name.endswith("running_mean"):
+            out[name] = np.zeros(shape, np.float32)
+        elif name.endswith("running_var"):
+            out[name] = np.ones(shape, np.float32)
+        elif name.endswith("weight_u") or name.endswith("weight_v"):
+            v = rng.standard_normal(shape)
+            out[name] = (v / np.linalg.norm(v)).astype(np.float32)
+        elif len(shape) >= 2:
+            fan_in = int(np.prod(shape[1:]))
+            b = float(np.sqrt(6.0 / fan_in))
+            out[name] = rng.uniform(-b, b, shape).astype(np.float32)
+        elif name.endswith("bias"):
+            out[name] = (0.05 * rng.standard_normal(shape)).astype(np.float32)
+        else:
+            out[name] = (1.0 + 0.1 * rng.standard_normal(shape)).astype(np.float32)
+    return out
+
+
+def lc_synthetic(seed: int, P: int, pixels: int, latent_dim_end: int, size2: int, latent_dim: int):
+    """Synthetic conditioner data set: images U[0,1) [P, pixels], main latents N(0, .5) [P, latent_dim_end], hierarchical
+    latents N(0, .5) [P, size2, latent_dim]."""
+    x = _rng(seed, 1).random((P, pixels), dtype=np.float32)
+    y1 = (0.5 * _rng(seed, 2).standard_normal((P, latent_dim_end))).astype(np.float32)
+    y2 = (0.5 * _rng(seed, 3).standard_normal((P, size2, latent_dim))).astype(np.float32)
+    return x, y1, y2
+
+
+def noise_call(seed: int, k: int, shape) -> np.ndarray:
+    """The k-th standard-normal draw of a run with injected noise (flat order, any shape of that size)."""
+    n = int(np.prod(shape))
+    return _rng(seed, 100000 + k).standard_normal(n).astype(np.float32).reshape(tuple(shape))

@@ -189,7 +189,7 @@ def train_latent_conditioner(latent_conditioner_epoch, latent_conditioner_datalo
             else:
                 patience_counter += 1
         epoch_duration = time.time() - start_time
-        current_lr = sched(epoch + 1) if epoch + 1 < latent_conditioner_epoch else lr       # after this epoch's scheduler.step()
+        current_lr = sched(epoch + 1)       # after this epoch's scheduler.step() (the reference steps it in the last epoch too)
         scheduler_info = "Warmup" if epoch < warmup_epochs else "Cosine"
         print("[%d/%d]\tTrain: %.4E (y1:%.4E, y2:%.4E), Val: %.4E (y1:%.4E, y2:%.4E), LR: %.2E (%s), ETA: %.2f h, Patience: %d/%d" %
               (epoch, latent_conditioner_epoch, avg_train_loss, avg_train_loss_y1, avg_train_loss_y2, avg_val_loss, avg_val_loss_y1,

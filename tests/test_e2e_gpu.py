@@ -1,8 +1,9 @@
 """SURVEY 8(f) N4 on the GPU: the end-to-end conditioner -> frozen decoder loop and ReconstructionEvaluator against an
 oracle COMPOSED of parts that are each pinned by a reference-recorded fixture (conditioner: oracle/lc_torch_port.py <-
 tests/golden/lc_small.npz; decoder: oracle/torch_port.py <- tests/golden/g0_*.npz; scalers: sklearn's own MinMaxScaler;
-losses: torch.nn.functional).  The reference's loop module itself is not importable here (cv2 / natsort / torchinfo /
-tensorboard are absent), so the loop logic is restated from its text: parity of the loop as a whole is "unpinned"."""
+losses: torch.nn.functional).  The loop as a whole is pinned separately against a run of the reference's own loop
+(tests/test_lc_loop_gpu.py <- tests/golden/loop_e2e.npz); this file covers the cases that fixture does not hold (other loss
+kinds, the evaluator, error paths) against the composed oracle."""
 import math
 import os
 import pickle
