@@ -1185,8 +1185,8 @@ int sgv_destroy(sgv_engine* e) {
                     e->scal, e->partial, e->partial_tn, e->partial2, e->colpart2, e->gn_part2, e->gn_part, e->red, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
                     e->items_sn_unf, e->items_adam_flat, e->items_adam_2d, e->items_ts, e->items_ss, e->lin_dot_part, e->gnorm_part};
     for (void* p : ptrs) if (p) hipFree(p);
-    if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
-    if (e->lane2) { hipStreamSynchronize(e->lane2); hipStreamDestroy(e->lane2); }
+    if (e->side) { hipStreamSynchronize(e->side); gemm_nt_vendor_release_stream(e->side); hipStreamDestroy(e->side); }
+    if (e->lane2) { hipStreamSynchronize(e->lane2); gemm_nt_vendor_release_stream(e->lane2); hipStreamDestroy(e->lane2); }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
     if (e->lane_join) hipEventDestroy(e->lane_join);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);

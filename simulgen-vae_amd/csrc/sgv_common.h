@@ -167,6 +167,7 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
 int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s);
 bool gemm_nt_vendor_eligible(int dtype, const GemmNT& p);
 int launch_gemm_nt_vendor(const GemmNT& p, hipStream_t s);   // 0 launched, 1 unavailable, < 0 error
+void gemm_nt_vendor_release_stream(hipStream_t s);
 bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);
 struct GemmTN {
     const void* A; long lda;        // dY [M][lda], N1 columns used

@@ -27,6 +27,8 @@ struct LtApi {
     decltype(&hipblasLtMatmulPreferenceCreate) PrefCreate = nullptr;
     decltype(&hipblasLtMatmulPreferenceSetAttribute) PrefSet = nullptr;
     decltype(&hipblasLtMatmulPreferenceDestroy) PrefDestroy = nullptr;
+    decltype(&hipblasLtMatmulDescDestroy) DescDestroy = nullptr;
+    decltype(&hipblasLtMatrixLayoutDestroy) LayoutDestroy = nullptr;
     decltype(&hipblasLtMatmulAlgoGetHeuristic) Heuristic = nullptr;
     decltype(&hipblasLtMatmul) Matmul = nullptr;
     hipblasLtHandle_t handle = nullptr;
@@ -65,6 +67,8 @@ bool lt_load() {
     SGV_LT_SYM(PrefCreate, "hipblasLtMatmulPreferenceCreate")
     SGV_LT_SYM(PrefSet, "hipblasLtMatmulPreferenceSetAttribute")
     SGV_LT_SYM(PrefDestroy, "hipblasLtMatmulPreferenceDestroy")
+    SGV_LT_SYM(DescDestroy, "hipblasLtMatmulDescDestroy")
+    SGV_LT_SYM(LayoutDestroy, "hipblasLtMatrixLayoutDestroy")
     SGV_LT_SYM(Heuristic, "hipblasLtMatmulAlgoGetHeuristic")
     SGV_LT_SYM(Matmul, "hipblasLtMatmul")
 #undef SGV_LT_SYM
@@ -78,6 +82,20 @@ Plan* get_plan(const GemmNT& p) {
     const PlanKey key(p.W, p.bias, p.scale_vec != nullptr, p.M, p.N, p.K, p.lda, p.ldw, p.ldc, p.addend ? p.ldadd : 0L);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) return &it->second;
+    // plans are keyed by the weight / bias addresses: a caller that re-allocates its tensors (the operator API is handed torch
+    // tensors) would otherwise grow the cache without bound -- past kMaxPlans the cache is dropped and rebuilt on demand
+    constexpr size_t kMaxPlans = 512;
+    if (g_plans.size() >= kMaxPlans) {
+        for (auto& kv : g_plans) {
+            Plan& q = kv.second;
+            if (q.lc && q.lc != q.ld) g_lt.LayoutDestroy(q.lc);
+            if (q.la) g_lt.LayoutDestroy(q.la);
+            if (q.lb) g_lt.LayoutDestroy(q.lb);
+            if (q.ld) g_lt.LayoutDestroy(q.ld);
+            if (q.desc) g_lt.DescDestroy(q.desc);
+        }
+        g_plans.clear();
+    }
     Plan pl;
     const int32_t opT = HIPBLAS_OP_T, opN = HIPBLAS_OP_N;
     const int32_t mode = p.scale_vec ? HIPBLASLT_POINTER_MODE_ALPHA_DEVICE_VECTOR_BETA_HOST : HIPBLASLT_POINTER_MODE_HOST;
@@ -128,6 +146,15 @@ bool gemm_nt_vendor_eligible(int dtype, const GemmNT& p) {
 }
 
 // 0: launched; 1: library or plan unavailable (caller uses its own kernel); < 0: launch error
+// frees the per-stream workspace of a stream that is about to be destroyed (sgv_destroy)
+void gemm_nt_vendor_release_stream(hipStream_t s) {
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_ws.find(s);
+    if (it == g_ws.end()) return;
+    if (it->second) hipFree(it->second);
+    g_ws.erase(it);
+}
+
 int launch_gemm_nt_vendor(const GemmNT& p, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_mu);
     if (!lt_load()) return 1;
