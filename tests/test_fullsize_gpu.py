@@ -124,3 +124,41 @@ def test_fullsize_fix_roundtrip_matches_eval_forward(full):
     mse = float(torch.mean((xh_dec - xb) ** 2))
     assert abs(mse - sc["mse"]) <= 2e-3 * abs(sc["mse"])
     assert float(xh_dec.abs().max()) <= 1.0                  # tanh head
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "f32"])
+def test_fullsize_fused_step_is_bitwise_equal_to_separate_calls(dtype):
+    """sgv_backward_step at full size -- AdamW of finished buckets on the side stream under the rest of backward, posterior /
+    prior branches on two lanes -- leaves BITWISE the state of sgv_backward + sgv_adamw_step: the schedule changes, the
+    arithmetic does not.  Two steps, so the second forward consumes what the overlapped optimizer pass wrote (weight copies,
+    W^T u partials)."""
+    cfg = VAEConfig(32, 8, ENC, ENC[::-1], N, T, "MSE", True)
+    state = init_state(cfg, 7, reference_init=True)
+    Bs = 2
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand((Bs, N, T), generator=g, device="cuda") * 1.4 - 0.7
+    dec = cfg.num_filter_dec
+    eps = [torch.randn((Bs, cfg.latent_dim), generator=g, device="cuda")] + \
+          [torch.randn((Bs, dec[i + 1], T), generator=g, device="cuda") for i in range(len(dec) - 2)]
+    names = BIG + ["encoder.encoder_blocks.0.module_list.0._seq.0.weight_u", "encoder.encoder_blocks.0.module_list.0._seq.0.weight_v"]
+    out = []
+    for fused in (True, False):
+        eng = E.Engine(cfg, max_batch=Bs, compute_dtype=dtype)
+        eng.load_state(state)
+        rec = []
+        for step in range(2):
+            eng.set_input(x)
+            eng.set_eps([e.contiguous() for e in eps])
+            sc = eng.forward(train=True)
+            if fused:
+                eng.backward_step(ALPHA, BETA, 1e-3)
+            else:
+                eng.backward(ALPHA, BETA)
+                eng.adamw_step(1e-3)
+            rec.append((sc["recon"], tuple(sc["kls"]), eng.last_grad_norm()))
+        sd = eng.state_dict()
+        out.append((rec, {k: sd[k] for k in names}))
+        eng.close()
+    assert out[0][0] == out[1][0], (out[0][0], out[1][0])
+    for k in names:
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
