@@ -137,8 +137,29 @@ __device__ __forceinline__ void gn_block_group_partials(const GNParams& p, const
         }
     }
     float* dst = gpart + (long)block_linear() * p.G * 2;
-    const int g_lo = min((int)(blockIdx.x * p.CV * 8) / p.Cg, p.G - 1);
-    const int g_hi = min((int)(min((long)(blockIdx.x + 1) * p.CV * 8, (long)p.C) - 1) / p.Cg, p.G - 1);
+    const int blk_lo = blockIdx.x * p.CV * 8, blk_hi = (int)min((long)(blockIdx.x + 1) * p.CV * 8, (long)p.C);
+    const int g_lo = min(blk_lo / p.Cg, p.G - 1);
+    const int g_hi = min((blk_hi - 1) / p.Cg, p.G - 1);
+    if (g_hi - g_lo > 3 && p.Cg <= 64) {
+        // many narrow groups in one block (the image conditioner: 32 groups of 1-32 channels): the owners' column sums go back
+        // to LDS in channel order and thread g adds the channels of group g in index order -- one barrier instead of two
+        // block-wide reductions per group
+        __syncthreads();
+        if (owner) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { smA[c.tx * 8 + e] = colA[e]; smB[c.tx * 8 + e] = colB[e]; }
+        }
+        __syncthreads();
+        for (int g = threadIdx.x; g < p.G; g += 256) {
+            float ga = 0.f, gb = 0.f;
+            if (g >= g_lo && g <= g_hi) {
+                const int lo = max(g * p.Cg, blk_lo), hi = min(g == p.G - 1 ? p.C : (g + 1) * p.Cg, blk_hi);
+                for (int ch = lo; ch < hi; ++ch) { ga += smA[ch - blk_lo]; gb += smB[ch - blk_lo]; }
+            }
+            dst[g * 2] = ga; dst[g * 2 + 1] = gb;
+        }
+        return;
+    }
     for (int g = 0; g < p.G; ++g) {
         float ga = 0.f, gb = 0.f;
         if (g >= g_lo && g <= g_hi) {            // block-uniform
@@ -343,18 +364,60 @@ __global__ __launch_bounds__(256) void gn_bwd_reduce_kernel(const GNParams p) {
 // The sums over the samples (dbeta, dgamma, dbias) are taken later by ew_fin_affine.
 __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const GNParams p, int RS) {
     __shared__ double smd[16];
+    __shared__ float smr[3][1024];
     const int g = blockIdx.x, b = blockIdx.y;
     const float* part = p.part + ((long)b * RS * 3) * p.C;
     const int c_lo = g * p.Cg, c_hi = g == p.G - 1 ? p.C : (g + 1) * p.Cg;
+    const int ncol = c_hi - c_lo;
+    constexpr int MAXC = 12;                 // columns per thread kept in registers (recon head: 11876 / 1024 -> 12)
+    float rA[MAXC], rB[MAXC], rX[MAXC];
     double s1 = 0.0, s2 = 0.0;
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += 1024) {
-        float A = 0.f, Bv = 0.f;
-        for (int r = 0; r < RS; ++r) {
-            A += part[((long)r * 3 + 0) * p.C + c];
-            Bv += part[((long)r * 3 + 1) * p.C + c];
+    const bool lanes = ncol <= 128;          // narrow groups (image conditioner): the row blocks are split over the threads too
+    if (lanes) {
+        int ncp = 1;
+        while (ncp < ncol) ncp <<= 1;
+        const int RLn = 1024 / ncp, ci = threadIdx.x % ncp, rl = threadIdx.x / ncp;
+        float A = 0.f, Bv = 0.f, X = 0.f;
+        if (ci < ncol)
+            for (int r = rl; r < RS; r += RLn) {
+                A += part[((long)r * 3 + 0) * p.C + c_lo + ci];
+                Bv += part[((long)r * 3 + 1) * p.C + c_lo + ci];
+                X += part[((long)r * 3 + 2) * p.C + c_lo + ci];
+            }
+        smr[0][threadIdx.x] = A; smr[1][threadIdx.x] = Bv; smr[2][threadIdx.x] = X;
+        __syncthreads();
+        A = Bv = X = 0.f;
+        if (rl == 0 && ci < ncol) {
+            for (int k = 0; k < RLn; ++k) { A += smr[0][k * ncp + ci]; Bv += smr[1][k * ncp + ci]; X += smr[2][k * ncp + ci]; }
+            const float gm = p.gamma[c_lo + ci];
+            s1 = (double)(gm * A); s2 = (double)(gm * Bv);
         }
-        const float gm = p.gamma[c];
-        s1 += (double)(gm * A); s2 += (double)(gm * Bv);
+        rA[0] = A; rB[0] = Bv; rX[0] = X;
+    } else {
+#pragma unroll
+        for (int k = 0; k < MAXC; ++k) {         // compile-time register indices (a run-time index would demote the arrays to scratch)
+            const int c = c_lo + (int)threadIdx.x + k * 1024;
+            float A = 0.f, Bv = 0.f, X = 0.f;
+            if (c < c_hi) {
+                for (int r = 0; r < RS; ++r) {
+                    A += part[((long)r * 3 + 0) * p.C + c];
+                    Bv += part[((long)r * 3 + 1) * p.C + c];
+                    X += part[((long)r * 3 + 2) * p.C + c];
+                }
+                const float gm = p.gamma[c];
+                s1 += (double)(gm * A); s2 += (double)(gm * Bv);
+            }
+            rA[k] = A; rB[k] = Bv; rX[k] = X;
+        }
+        for (int c = c_lo + (int)threadIdx.x + MAXC * 1024; c < c_hi; c += 1024) {      // wider groups than the register file holds
+            float A = 0.f, Bv = 0.f;
+            for (int r = 0; r < RS; ++r) {
+                A += part[((long)r * 3 + 0) * p.C + c];
+                Bv += part[((long)r * 3 + 1) * p.C + c];
+            }
+            const float gm = p.gamma[c];
+            s1 += (double)(gm * A); s2 += (double)(gm * Bv);
+        }
     }
     const double S1 = block_sum_f64(s1, smd), S2 = block_sum_f64(s2, smd);
     if (threadIdx.x == 0) {
@@ -369,7 +432,25 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const GNParams p,
     const float rstd = (float)(1.0 / sqrt(var + 1e-5));
     const float m1 = (float)(S1 / n), m2 = (float)(S2 / n);
     float* pt = p.ptot + (long)b * 3 * p.C;
-    for (int c = c_lo + threadIdx.x; c < c_hi; c += 1024) {
+    if (lanes) {
+        if (threadIdx.x < ncol) {
+            const int c = c_lo + threadIdx.x;
+            pt[c] = rA[0];
+            pt[(long)p.C + c] = rB[0];
+            pt[2L * p.C + c] = p.gscale * rstd * (p.gamma[c] * rA[0] - (float)p.T * m1 - m2 * rX[0]);
+        }
+        return;
+    }
+#pragma unroll
+    for (int k = 0; k < MAXC; ++k) {
+        const int c = c_lo + (int)threadIdx.x + k * 1024;
+        if (c < c_hi) {
+            pt[c] = rA[k];
+            pt[(long)p.C + c] = rB[k];
+            pt[2L * p.C + c] = p.gscale * rstd * (p.gamma[c] * rA[k] - (float)p.T * m1 - m2 * rX[k]);
+        }
+    }
+    for (int c = c_lo + (int)threadIdx.x + MAXC * 1024; c < c_hi; c += 1024) {
         float A = 0.f, Bv = 0.f, X = 0.f;
         for (int r = 0; r < RS; ++r) {
             A += part[((long)r * 3 + 0) * p.C + c];
