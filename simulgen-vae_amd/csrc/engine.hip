@@ -1411,7 +1411,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     return SGV_OK;
 }
 
-static int encoder_fwd(sgv_engine* e, int B) {
+static int encoder_fwd(sgv_engine* e, int B, bool join_lane) {
     const int n = e->n;
     Tensor x = e->x_in;
     for (int i = 0; i < n; ++i) {
@@ -1419,12 +1419,16 @@ static int encoder_fwd(sgv_engine* e, int B) {
         CHK(block_fwd(e, e->encR[i], e->encA[i].st.back().a, B));
         x = e->enc_h[i];
         if (i < n - 1) {
+            // the xs head of this level feeds only the decoder's posterior branch, which runs on the second lane: it goes there
+            // too, beside the next encoder block (in-order on that lane, so the posterior branch needs no extra wait)
+            Lane2 lane(e);
             const Layer& l = e->layers[e->xs_lin[i]];
             ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xs_raw[i], B, l.cin, l.cout, e->colpart, e->stream);
         }
     }
     const Layer& l = e->layers[e->last_lin];
     ew_linear_head_fwd(e->dt, x.p, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->last, B, l.cin, l.cout, e->colpart, e->stream);
+    if (join_lane) lane2_join(e);
     return 0;
 }
 
@@ -1505,7 +1509,7 @@ int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
     if (!e->deterministic) HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));   // only the fp64-atomic statistics epilogue accumulates
     HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
     CHK(run_sn(e, train));
-    CHK(encoder_fwd(e, B));
+    CHK(encoder_fwd(e, B, false));
     if (!e->eps_set[0]) ew_randn(e->eps[0], (long)B * e->Z, e->seed, (e->draw++) * 8, e->stream);
     ew_latent_fwd(e->last, e->eps[0], e->zlat, B, e->Z, e->scal + 2, e->stream);
     CHK(decoder_fwd(e, B, train, mode_fix));
@@ -1548,7 +1552,7 @@ int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host
     const int B = e->batch;
     if (!e->deterministic) HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));   // only the fp64-atomic statistics epilogue accumulates
     CHK(run_sn(e, 0));
-    CHK(encoder_fwd(e, B));
+    CHK(encoder_fwd(e, B, true));
     std::vector<float> last((size_t)B * 2 * e->Z);
     HIPCHK(hipMemcpyAsync(last.data(), e->last, last.size() * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
