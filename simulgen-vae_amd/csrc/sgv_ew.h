@@ -119,8 +119,9 @@ struct AdamDesc {
     int taps;
 };
 struct WorkItem { int desc; int chunk; };
-// <G,W_eff> is accumulated with float atomics from every block of the dY kernels: spread over this many slots
-// (summed by the AdamW pass) so the adds do not serialise on one address.
+// <G,W_eff> of a layer lives in this many slots of the gradient arena's small zone; the AdamW pass adds them up.  The
+// fixed-order finalize (ew_fin_dots) writes the whole value to slot 0, the other slots stay at their initial zero -- the slot count is the arena
+// layout round 1's atomic accumulation chose, kept so that checkpoints and the all-reduced arena keep their offsets.
 constexpr int SGV_DOT_SLOTS = 32;
 
 // items_ts / items_ss: (desc, 64-element chunk of taps*cols / 1024-row chunk) for the fixed-order partial sums
