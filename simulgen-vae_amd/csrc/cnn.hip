@@ -285,7 +285,57 @@ __global__ __launch_bounds__(256) void ew2_kernel(const T* a, const T* b, T* out
 static inline long vec8_count(long n, const void* a, const void* b, const void* c) {
     return ((((uintptr_t)a | (uintptr_t)b | (uintptr_t)c) & 31) == 0) ? n / 8 : 0;      // 32-byte alignment covers fp32 too
 }
-// y[b][c] += (1/P) sum_{p in chunk} x[b][p][c]   (grid (C/64, B, chunks); 64 channels x 4 row lanes; y zeroed by the launcher)
+// ---- cross-block sums without floating-point atomics ---------------------------------------------------------------------
+// A kernel whose blocks each hold a partial of the same output writes it (plain store) to part[r][i] in a per-stream
+// workspace; fin_rows_kernel then adds the R partials of every output in index order.  Two launches of the same operator on
+// the same inputs give bitwise the same result.
+namespace {
+struct LcWorkspace { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_lc_ws_mu;
+std::map<hipStream_t, LcWorkspace> g_lc_ws;
+void* lc_workspace(hipStream_t s, size_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lc_ws_mu);
+    LcWorkspace& w = g_lc_ws[s];
+    if (w.bytes < bytes) {
+        if (w.p) { hipStreamSynchronize(s); hipFree(w.p); w.p = nullptr; w.bytes = 0; }   // the old buffer may still be read by queued kernels
+        const size_t nb = std::max(bytes, (size_t)4 << 20);
+        if (hipMalloc(&w.p, nb) != hipSuccess) { w.p = nullptr; return nullptr; }
+        w.bytes = nb;
+    }
+    return w.p;
+}
+}  // namespace
+// out[i] (= | +=) sum_{r < R} part[r * n + i]; one block = CL outputs x (256 / CL) row lanes, lane partials added in lane order
+template <typename TP, typename TO, bool ACC, int CL>
+__global__ __launch_bounds__(256) void fin_rows_kernel(const TP* part, int R, long n, TO* out) {
+    constexpr int RLN = 256 / CL;
+    __shared__ double sm[RLN][CL + 1];
+    const int cl = threadIdx.x % CL, rl = threadIdx.x / CL;
+    const long i = (long)blockIdx.x * CL + cl;
+    double a = 0.0;
+    if (i < n) for (int r = rl; r < R; r += RLN) a += (double)part[(long)r * n + i];
+    sm[rl][cl] = a;
+    __syncthreads();
+    if (rl == 0 && i < n) {
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < RLN; ++k) t += sm[k][cl];
+        out[i] = (TO)((ACC ? (double)out[i] : 0.0) + t);
+    }
+}
+template <typename TP, typename TO>
+static void fin_rows(const TP* part, int R, long n, TO* out, bool acc, hipStream_t s) {
+    if (n >= 64) {
+        const dim3 g((unsigned)((n + 63) / 64));
+        if (acc) hipLaunchKernelGGL((fin_rows_kernel<TP, TO, true, 64>), g, dim3(256), 0, s, part, R, n, out);
+        else hipLaunchKernelGGL((fin_rows_kernel<TP, TO, false, 64>), g, dim3(256), 0, s, part, R, n, out);
+    } else {
+        const dim3 g((unsigned)n);
+        if (acc) hipLaunchKernelGGL((fin_rows_kernel<TP, TO, true, 1>), g, dim3(256), 0, s, part, R, n, out);
+        else hipLaunchKernelGGL((fin_rows_kernel<TP, TO, false, 1>), g, dim3(256), 0, s, part, R, n, out);
+    }
+}
+// part[chunk][b][c] = (1/P) sum_{p in chunk} x[b][p][c]   (grid (C/64, B, chunks); 64 channels x 4 row lanes)
 template <typename T>
 __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, float* y, int P, int C, int chunk) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
@@ -295,7 +345,7 @@ __global__ __launch_bounds__(256) void avgpool_fwd_kernel(const T* x, float* y, 
     __shared__ float sm[4][64];
     sm[rl][threadIdx.x & 63] = a;
     __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(y + (long)b * C + c, (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)P);
+    if (rl == 0 && c < C) y[((long)blockIdx.z * gridDim.y + b) * C + c] = (sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]) / (float)P;
 }
 // dx[b][p][c] (+)= dy[b][c] / P
 template <typename T>
@@ -344,7 +394,7 @@ __global__ __launch_bounds__(256) void chan_scale_fwd_kernel(const T* x, const f
         out[i] = from_f32<T>(to_f32(x[i]) * s[(long)b * C + c]);
     }
 }
-// dx = dout * s ; ds[b][c] += sum_{p in chunk} dout * x   (grid (C/64, B, chunks); ds zeroed by the launcher)
+// dx = dout * s ; part[chunk][b][c] = sum_{p in chunk} dout * x   (grid (C/64, B, chunks))
 template <typename T>
 __global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* x, const float* s, const T* dout, T* dx, float* ds, int P, int C, int chunk) {
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), rl = threadIdx.x >> 6, b = blockIdx.y;
@@ -362,7 +412,7 @@ __global__ __launch_bounds__(256) void chan_scale_bwd_kernel(const T* x, const f
     __shared__ float sm[4][64];
     sm[rl][threadIdx.x & 63] = a;
     __syncthreads();
-    if (rl == 0 && c < C) atomicAdd(ds + (long)b * C + c, sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x]);
+    if (rl == 0 && c < C) ds[((long)blockIdx.z * gridDim.y + b) * C + c] = sm[0][threadIdx.x] + sm[1][threadIdx.x] + sm[2][threadIdx.x] + sm[3][threadIdx.x];
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -394,7 +444,7 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const float* y, const floa
 __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* dz, const float* W, const float* scale, float* dx, int K, int O,
                                                            int B, int ochunk) {
     // block = 64 columns k x 8 batch rows x one chunk of outputs: every W element is read once per 8 rows, the chunks run
-    // in parallel and meet in dx through float atomics (dx holds zeros or the value to accumulate onto)
+    // in parallel; each writes its partial to part[chunk][b][k] and fin_rows_kernel adds the chunks in order (onto dx or not)
     constexpr int BG = 8;
     const int kl = threadIdx.x & 63, ol = threadIdx.x >> 6;
     const int k = blockIdx.x * 64 + kl, b0 = blockIdx.y * BG;
@@ -417,7 +467,7 @@ __global__ __launch_bounds__(256) void linear_bwd_dx_kernel(const float* dz, con
         const float sc = scale ? *scale : 1.f;
 #pragma unroll
         for (int j = 0; j < BG; ++j)
-            if (b0 + j < B) atomicAdd(dx + (long)(b0 + j) * K + k, (sm[0][j][kl] + sm[1][j][kl] + sm[2][j][kl] + sm[3][j][kl]) * sc);
+            if (b0 + j < B) dx[((long)blockIdx.z * B + b0 + j) * K + k] = (sm[0][j][kl] + sm[1][j][kl] + sm[2][j][kl] + sm[3][j][kl]) * sc;
     }
 }
 // dW[o][k] = scale * sum_b dz[b][o] x[b][k]; db[o] = sum_b dz[b][o]; grid (ceil(K/256), O)
@@ -447,7 +497,7 @@ __global__ __launch_bounds__(64) void layernorm_fwd_kernel(const float* x, const
     for (int k = threadIdx.x; k < K; k += 64) y[(long)b * K + k] = (x[(long)b * K + k] - mean) * rstd * gamma[k] + beta[k];
     if (threadIdx.x == 0) { stat[2 * b] = mean; stat[2 * b + 1] = rstd; }
 }
-// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); dgamma/dbeta via per-row atomics
+// dx = rstd * (g*dy - mean(g*dy) - xhat * mean(g*dy*xhat)); per-row terms of dgamma / dbeta to pg[b][k] / pb[b][k] (summed over b by fin_rows_kernel)
 __global__ __launch_bounds__(64) void layernorm_bwd_kernel(const float* x, const float* gamma, const float* stat, const float* dy, float* dx,
                                                           float* dgamma, float* dbeta, int K) {
     const int b = blockIdx.x;
@@ -461,8 +511,8 @@ __global__ __launch_bounds__(64) void layernorm_bwd_kernel(const float* x, const
     for (int k = threadIdx.x; k < K; k += 64) {
         const float xh = (x[(long)b * K + k] - mean) * rstd, d = dy[(long)b * K + k];
         dx[(long)b * K + k] = rstd * (gamma[k] * d - s1 - xh * s2);
-        atomicAdd(dgamma + k, d * xh);
-        atomicAdd(dbeta + k, d);
+        dgamma[(long)b * K + k] = d * xh;
+        dbeta[(long)b * K + k] = d;
     }
 }
 // BatchNorm1d over the batch dimension; train: batch statistics (biased variance for normalisation, unbiased for the
@@ -506,8 +556,9 @@ __global__ __launch_bounds__(256) void mask_scale_kernel(const float* a, const f
 __global__ __launch_bounds__(256) void addf_kernel(const float* a, const float* b, float* out, long n) {
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) out[i] = a[i] + b[i];
 }
-// loss = mean((pred - target)^2) -> loss[0] (atomic double), dpred = gscale * 2 (pred - target) / n
+// loss = mean((pred - target)^2): block partials to loss[blockIdx.x] (summed by fin_rows_kernel), dpred = gscale * 2 (pred - target) / n
 __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float* target, double* loss, float* dpred, float gscale, long n) {
+    __shared__ float smw[4];
     float a = 0.f;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
         const float d = pred[i] - target[i];
@@ -515,7 +566,9 @@ __global__ __launch_bounds__(256) void mse_kernel(const float* pred, const float
         if (dpred) dpred[i] = gscale * 2.f * d / (float)n;
     }
     a = wave_sum(a);
-    if ((threadIdx.x & 63) == 0) atomicAdd(loss, (double)a / (double)n);
+    if ((threadIdx.x & 63) == 0) smw[threadIdx.x >> 6] = a;
+    __syncthreads();
+    if (threadIdx.x == 0) loss[blockIdx.x] = ((double)smw[0] + (double)smw[1] + (double)smw[2] + (double)smw[3]) / (double)n;
 }
 // value of nn.MSELoss / L1Loss / HuberLoss(delta) / SmoothL1Loss(beta) with mean reduction (no gradient): the
 // reconstruction term of the end-to-end conditioner loop, which the reference cuts off from the graph
@@ -542,7 +595,7 @@ __global__ __launch_bounds__(256) void loss_value_kernel(const float* a, const f
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(loss, (sm[0] + sm[1] + sm[2] + sm[3]) / (double)n);
+    if (threadIdx.x == 0) loss[blockIdx.x] = (sm[0] + sm[1] + sm[2] + sm[3]) / (double)n;
 }
 // sklearn MinMaxScaler.inverse_transform on [rows][cols]: (x - min_[c]) / scale_[c]
 __global__ __launch_bounds__(256) void cols_sub_div_kernel(const float* x, const float* mn, const float* sc, float* y, long rows, int cols) {
@@ -576,20 +629,20 @@ __global__ __launch_bounds__(256) void dot_partial_kernel(const float* a, const 
     x = wave_sum_d(x);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = x;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, sm[0] + sm[1] + sm[2] + sm[3]);
+    if (threadIdx.x == 0) acc[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];
 }
 __global__ void dot_final_kernel(float* out4) {
     const float d = (float)*reinterpret_cast<double*>(out4 + 2);
     out4[0] = d; out4[1] = 1.f / d;
 }
-// out[c] += sum_{r in block} W[r][c] * x[r]   (W^T x; grid (cols/256, rows/64), out zeroed by the caller)
+// part[rowblock][c] = sum_{r in block} W[r][c] * x[r]   (W^T x; grid (cols/256, rows/64))
 __global__ __launch_bounds__(256) void matvec_t_kernel(const float* W, const float* x, float* out, int rows, int cols) {
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= cols) return;
     const int r0 = blockIdx.y * 64, r1 = min(rows, r0 + 64);
     float a = 0.f;
     for (int r = r0; r < r1; ++r) a += W[(long)r * cols + c] * x[r];
-    atomicAdd(out + c, a);
+    out[(long)blockIdx.y * cols + c] = a;
 }
 // g_orig[r][c] = (G[r][c] - (gw[0] * sig[1]) * u[r] * v[c]) * sig[1]    (sig = {sigma, 1/sigma}, gw[0] = <G, W_orig>)
 __global__ __launch_bounds__(256) void sn_grad_kernel(const float* G, const float* u, const float* v, const float* gw, const float* sig,
@@ -626,7 +679,7 @@ __global__ __launch_bounds__(256) void sumsq_kernel(const float* g, long n, doub
     a = wave_sum_d(a);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = a;
     __syncthreads();
-    if (threadIdx.x == 0) atomicAdd(acc, sm[0] + sm[1] + sm[2] + sm[3]);      // one atomic per block, <= 256 blocks
+    if (threadIdx.x == 0) acc[blockIdx.x] = sm[0] + sm[1] + sm[2] + sm[3];      // block partial; fin_rows_kernel adds them onto the running total
 }
 // torch.nn.utils.clip_grad_norm_: coef = min(1, max_norm / (total_norm + 1e-6)); out = {coef, total_norm}
 __global__ void clip_coef_kernel(const double* sumsq, float max_norm, float* out) {
@@ -794,9 +847,11 @@ int sgv_op_add(int dtype, const void* a, const void* b, void* out, long n, void*
 }
 int sgv_op_avgpool_fwd(int dtype, const void* x, float* y, int B, int P, int C, void* stream) {
     OPCHK(x && y && B > 0 && P > 0 && C > 0, "sgv_op_avgpool_fwd: bad argument");
-    if (hipMemsetAsync(y, 0, sizeof(float) * B * C, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
-    const int chunk = P > 512 ? 256 : P;
-    ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(cdivi(C, 64), B, cdivi(P, chunk)), dim3(256), 0, ST(stream), CPT(x), y, P, C, chunk));
+    const int chunk = P > 512 ? 256 : P, chunks = cdivi(P, chunk);
+    float* part = chunks > 1 ? (float*)lc_workspace(ST(stream), sizeof(float) * (size_t)chunks * B * C) : y;     // one chunk: the block's value is the result
+    OPCHK(part, "sgv_op_avgpool_fwd: workspace allocation failed");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(avgpool_fwd_kernel<T>, dim3(cdivi(C, 64), B, chunks), dim3(256), 0, ST(stream), CPT(x), part, P, C, chunk));
+    if (chunks > 1) fin_rows(part, chunks, (long)B * C, y, false, ST(stream));
     return OPLAUNCH_OK();
 }
 int sgv_op_avgpool_bwd(int dtype, const float* dy, void* dx, int B, int P, int C, int accumulate, void* stream) {
@@ -821,9 +876,11 @@ int sgv_op_chan_scale_fwd(int dtype, const void* x, const float* s, void* out, i
 }
 int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* dout, void* dx, float* ds, int B, int P, int C, void* stream) {
     OPCHK(x && s && dout && dx && ds && B > 0 && P > 0 && C > 0, "sgv_op_chan_scale_bwd: bad argument");
-    if (hipMemsetAsync(ds, 0, sizeof(float) * B * C, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
-    const int chunk = P > 512 ? 256 : P;
-    ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_bwd_kernel<T>, dim3(cdivi(C, 64), B, cdivi(P, chunk)), dim3(256), 0, ST(stream), CPT(x), s, CPT(dout), PT(dx), ds, P, C, chunk));
+    const int chunk = P > 512 ? 256 : P, chunks = cdivi(P, chunk);
+    float* part = chunks > 1 ? (float*)lc_workspace(ST(stream), sizeof(float) * (size_t)chunks * B * C) : ds;
+    OPCHK(part, "sgv_op_chan_scale_bwd: workspace allocation failed");
+    ON_DTYPE(dtype, hipLaunchKernelGGL(chan_scale_bwd_kernel<T>, dim3(cdivi(C, 64), B, chunks), dim3(256), 0, ST(stream), CPT(x), s, CPT(dout), PT(dx), part, P, C, chunk));
+    if (chunks > 1) fin_rows(part, chunks, (long)B * C, ds, false, ST(stream));
     return OPLAUNCH_OK();
 }
 
@@ -872,14 +929,17 @@ int sgv_op_linear_bwd(const float* dz, const float* x, const float* W, const flo
                       int B, int K, int O, void* stream) {
     OPCHK(dz && x && W && dW && B > 0 && K > 0 && O > 0, "sgv_op_linear_bwd: bad argument");
     if (dx) {
-        if (!accumulate_dx && hipMemsetAsync(dx, 0, sizeof(float) * (size_t)B * K, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
         // enough output chunks for ~1000 blocks, at least 32 outputs each
         const int kb = cdivi(K, 64), bb = cdivi(B, 8);
         int chunks = cdivi(1024, kb * bb);
         if (chunks > cdivi(O, 32)) chunks = cdivi(O, 32);
         if (chunks < 1) chunks = 1;
         const int ochunk = cdivi(cdivi(O, chunks), 4) * 4;
-        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(kb, bb, cdivi(O, ochunk)), dim3(256), 0, ST(stream), dz, W, scale, dx, K, O, B, ochunk);
+        const int nch = cdivi(O, ochunk);
+        float* part = (nch > 1 || accumulate_dx) ? (float*)lc_workspace(ST(stream), sizeof(float) * (size_t)nch * B * K) : dx;
+        OPCHK(part, "sgv_op_linear_bwd: workspace allocation failed");
+        hipLaunchKernelGGL(linear_bwd_dx_kernel, dim3(kb, bb, nch), dim3(256), 0, ST(stream), dz, W, scale, part, K, O, B, ochunk);
+        if (part != dx) fin_rows(part, nch, (long)B * K, dx, accumulate_dx != 0, ST(stream));
     }
     hipLaunchKernelGGL(linear_bwd_dw_kernel, dim3(cdivi(K, 256), O), dim3(256), 0, ST(stream), dz, x, scale, dW, db, B, K, O);
     return OPLAUNCH_OK();
@@ -892,9 +952,11 @@ int sgv_op_layernorm_fwd(const float* x, const float* gamma, const float* beta, 
 int sgv_op_layernorm_bwd(const float* x, const float* gamma, const float* stat, const float* dy, float* dx, float* dgamma, float* dbeta,
                          int B, int K, void* stream) {
     OPCHK(x && gamma && stat && dy && dx && dgamma && dbeta && B > 0 && K > 0, "sgv_op_layernorm_bwd: bad argument");
-    if (hipMemsetAsync(dgamma, 0, sizeof(float) * K, ST(stream)) != hipSuccess || hipMemsetAsync(dbeta, 0, sizeof(float) * K, ST(stream)) != hipSuccess)
-        return sgv_set_error(-2, "memset failed");
-    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), x, gamma, stat, dy, dx, dgamma, dbeta, K);
+    float* part = (float*)lc_workspace(ST(stream), sizeof(float) * 2 * (size_t)B * K);
+    OPCHK(part, "sgv_op_layernorm_bwd: workspace allocation failed");
+    hipLaunchKernelGGL(layernorm_bwd_kernel, dim3(B), dim3(64), 0, ST(stream), x, gamma, stat, dy, dx, part, part + (size_t)B * K, K);
+    fin_rows(part, B, (long)K, dgamma, false, ST(stream));
+    fin_rows(part + (size_t)B * K, B, (long)K, dbeta, false, ST(stream));
     return OPLAUNCH_OK();
 }
 int sgv_op_batchnorm_fwd(const float* x, const float* gamma, const float* beta, float* run_mean, float* run_var, float* y, float* stat,
@@ -922,23 +984,28 @@ int sgv_op_addf(const float* a, const float* b, float* out, long n, void* stream
 }
 int sgv_op_mse(const float* pred, const float* target, double* loss_dev, float* dpred, float gscale, long n, void* stream) {
     OPCHK(pred && target && loss_dev && n > 0, "sgv_op_mse: bad argument");
-    if (hipMemsetAsync(loss_dev, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
-    hipLaunchKernelGGL(mse_kernel, grid1(n), dim3(256), 0, ST(stream), pred, target, loss_dev, dpred, gscale, n);
+    const dim3 g = grid1(n);
+    double* part = g.x > 1 ? (double*)lc_workspace(ST(stream), sizeof(double) * g.x) : loss_dev;
+    OPCHK(part, "sgv_op_mse: workspace allocation failed");
+    hipLaunchKernelGGL(mse_kernel, g, dim3(256), 0, ST(stream), pred, target, part, dpred, gscale, n);
+    if (g.x > 1) fin_rows(part, (int)g.x, 1L, loss_dev, false, ST(stream));
     return OPLAUNCH_OK();
 }
 int sgv_op_loss_value(int kind, const float* a, const float* b, double* loss_dev, float delta, long n, void* stream) {
     OPCHK(a && b && loss_dev && n > 0 && kind >= 0 && kind <= 3, "sgv_op_loss_value: bad argument");
     OPCHK((((uintptr_t)a | (uintptr_t)b) & 15) == 0, "sgv_op_loss_value: operands must be 16-byte aligned");
     OPCHK(kind < 2 || delta > 0.f, "sgv_op_loss_value: delta / beta must be positive");
-    if (hipMemsetAsync(loss_dev, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     long blocks = ((n >> 2) + 255) / 256;
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
     const dim3 g((unsigned)blocks);
-    if (kind == 0) hipLaunchKernelGGL(loss_value_kernel<0>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
-    else if (kind == 1) hipLaunchKernelGGL(loss_value_kernel<1>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
-    else if (kind == 2) hipLaunchKernelGGL(loss_value_kernel<2>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
-    else hipLaunchKernelGGL(loss_value_kernel<3>, g, dim3(256), 0, ST(stream), a, b, loss_dev, delta, n);
+    double* part = blocks > 1 ? (double*)lc_workspace(ST(stream), sizeof(double) * blocks) : loss_dev;
+    OPCHK(part, "sgv_op_loss_value: workspace allocation failed");
+    if (kind == 0) hipLaunchKernelGGL(loss_value_kernel<0>, g, dim3(256), 0, ST(stream), a, b, part, delta, n);
+    else if (kind == 1) hipLaunchKernelGGL(loss_value_kernel<1>, g, dim3(256), 0, ST(stream), a, b, part, delta, n);
+    else if (kind == 2) hipLaunchKernelGGL(loss_value_kernel<2>, g, dim3(256), 0, ST(stream), a, b, part, delta, n);
+    else hipLaunchKernelGGL(loss_value_kernel<3>, g, dim3(256), 0, ST(stream), a, b, part, delta, n);
+    if (blocks > 1) fin_rows(part, (int)blocks, 1L, loss_dev, false, ST(stream));
     return OPLAUNCH_OK();
 }
 int sgv_op_cols_sub_div(const float* x, const float* col_min, const float* col_scale, float* y, long rows, int cols, void* stream) {
@@ -1072,16 +1139,21 @@ int sgv_op_l2_normalize(const float* x, float* out, long n, float eps, void* str
 int sgv_op_dot(const float* a, const float* b, float* out4, long n, void* stream) {
     OPCHK(a && b && out4 && n > 0, "sgv_op_dot: bad argument");
     OPCHK(((uintptr_t)out4 & 7) == 0, "sgv_op_dot: out4 must be 8-byte aligned");
-    if (hipMemsetAsync(out4 + 2, 0, sizeof(double), ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
     long blocks = (n + 8191) / 8192; if (blocks > 512) blocks = 512; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), a, b, reinterpret_cast<double*>(out4 + 2), n);
+    double* part = blocks > 1 ? (double*)lc_workspace(ST(stream), sizeof(double) * blocks) : reinterpret_cast<double*>(out4 + 2);
+    OPCHK(part, "sgv_op_dot: workspace allocation failed");
+    hipLaunchKernelGGL(dot_partial_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), a, b, part, n);
+    if (blocks > 1) fin_rows(part, (int)blocks, 1L, reinterpret_cast<double*>(out4 + 2), false, ST(stream));
     hipLaunchKernelGGL(dot_final_kernel, dim3(1), dim3(1), 0, ST(stream), out4);
     return OPLAUNCH_OK();
 }
 int sgv_op_matvec_t(const float* W, const float* x, float* out, int rows, int cols, void* stream) {
     OPCHK(W && x && out && rows > 0 && cols > 0, "sgv_op_matvec_t: bad argument");
-    if (hipMemsetAsync(out, 0, sizeof(float) * cols, ST(stream)) != hipSuccess) return sgv_set_error(-2, "memset failed");
-    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdivi(cols, 256), cdivi(rows, 64)), dim3(256), 0, ST(stream), W, x, out, rows, cols);
+    const int rb = cdivi(rows, 64);
+    float* part = rb > 1 ? (float*)lc_workspace(ST(stream), sizeof(float) * (size_t)rb * cols) : out;
+    OPCHK(part, "sgv_op_matvec_t: workspace allocation failed");
+    hipLaunchKernelGGL(matvec_t_kernel, dim3(cdivi(cols, 256), rb), dim3(256), 0, ST(stream), W, x, part, rows, cols);
+    if (rb > 1) fin_rows(part, rb, (long)cols, out, false, ST(stream));
     return OPLAUNCH_OK();
 }
 int sgv_op_sn_grad(const float* G, const float* u, const float* v, const float* gw, const float* sigma2, float* out, int rows, int cols,
@@ -1105,7 +1177,10 @@ int sgv_op_conv_weight_unpack(const float* packed, float* w, int Cout, int Cin, 
 int sgv_op_sumsq(const float* g, long n, double* acc, void* stream) {
     OPCHK(g && acc && n > 0, "sgv_op_sumsq: bad argument");
     long blocks = (n + 4095) / 4096; if (blocks > 256) blocks = 256; if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), g, n, acc);
+    double* part = (double*)lc_workspace(ST(stream), sizeof(double) * blocks);
+    OPCHK(part, "sgv_op_sumsq: workspace allocation failed");
+    hipLaunchKernelGGL(sumsq_kernel, dim3((unsigned)blocks), dim3(256), 0, ST(stream), g, n, part);
+    fin_rows(part, (int)blocks, 1L, acc, true, ST(stream));
     return OPLAUNCH_OK();
 }
 int sgv_op_clip_coef(const double* sumsq, float max_norm, float* out2, void* stream) {

@@ -341,6 +341,8 @@ class LatentConditionerImg:
             return x, (lambda d: d)
         if masks is not None:
             mask = masks.pop(0)
+            if tuple(mask.shape) != tuple(x.shape):
+                raise ValueError(f"dropout mask of shape {tuple(mask.shape)} for an activation of shape {tuple(x.shape)}")
         else:
             mask = (torch.rand(x.shape, device=x.device) >= p).float()
         scale = 1.0 / (1.0 - p)
