@@ -254,6 +254,12 @@ int sgv_test_gemm_nt_lib(const void* A, const void* W, void* C, const float* bia
  * 128x128 kernel (fewer than 64 K-steps of 32, or N < 256). */
 int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* bias, const void* addend, int M, int N, int K,
                            int taps, int Tlen, int Cg, double* sums, void* stream);
+/* Test hook: the fused small Conv1d + GroupNorm(G) + GELU (+ residual) forward kernel (csrc/convgn.hip) on caller-owned device
+ * buffers: A [B*T][K] bf16, W [taps][N][K] bf16, y / out / res [B*T][N] bf16, sums [B*G][2] doubles.  Fails for shapes the kernel
+ * does not take (T > 208, channels per group not in {16, 32, 64, 128}, K % 32 != 0). */
+int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const float* scale, const void* res, const float* gamma,
+                         const float* beta, void* y, void* out, double* sums, int B, int T, int N, int K, int taps, int G, float rscale,
+                         void* stream);
 /* Test hook for the 256x256 persistent implicit-GEMM kernel (csrc/gemm256.hip; replaces the hipBLASLt dispatch of round 1 on
  * the reference call sites modules/decoder.py:117-121, modules/common.py:135-141, modules/encoder.py:34).  bf16 operands.
  * mode 0: the kernel itself with the given split-K; mode 1: the engine's kernel choice (gemm_nt_plan: 256x256 kernel, or

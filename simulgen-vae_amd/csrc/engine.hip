@@ -181,6 +181,9 @@ struct sgv_engine {
     hipStream_t lane2 = nullptr; float* partial2 = nullptr; float* colpart2 = nullptr; float* gn_part2 = nullptr;
     hipEvent_t lane_fork = nullptr, lane_join = nullptr;
     int use_lanes = getenv("SGV_LANES") ? atoi(getenv("SGV_LANES")) : 1;
+    // small Conv1d -> GroupNorm -> GELU stages in one launch (convgn.hip); SGV_CONVGN=0 restores GEMM + combine + GroupNorm kernels
+    int use_convgn = getenv("SGV_CONVGN") ? atoi(getenv("SGV_CONVGN")) : 1;
+    long convgn_maxk = getenv("SGV_CONVGN_MAXK") ? atol(getenv("SGV_CONVGN_MAXK")) : 4096;
     float* red = nullptr; size_t red_floats = 0;
     std::vector<FinDot> fin_dots; std::vector<FinAffine> fin_affine;
     int dot_counts[512];
@@ -987,6 +990,23 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
             GNParams p; p.y = x.p; p.ldy = x.ld; p.out = S.pre.p; p.ldout = S.pre.ld; p.B = B; p.T = e->T; p.C = x.C;
             ew_act(e->dt, 0, p, e->stream);
             cin = S.pre;
+        }
+        if (S.gn >= 0 && S.act == 1 && e->use_convgn && e->dt == SGV_DTYPE_BF16 && !S.y.f32 && (long)L.cin * L.k <= e->convgn_maxk) {
+            // one workgroup per (group, sample): convolution, statistics, normalise + GELU (+ residual) in one launch
+            const GNLayer& g = e->gns[S.gn];
+            ConvGN q; memset(&q, 0, sizeof(q));
+            q.A = cin.p; q.lda = cin.ld; q.W = wc_ptr(e, L); q.ldw = L.cin; q.w_tap_stride = (long)L.cout * L.cin;
+            q.bias = e->params + L.b; q.scale = e->sn_sigma + 2 * L.sn + 1;
+            q.y = S.y.p; q.ldy = S.y.ld; q.out = S.a.p; q.ldout = S.a.ld;
+            if (b.residual && s + 1 == b.st.size()) { q.res = in.p; q.ldres = in.ld; q.rscale = 0.1f; } else q.rscale = 1.f;
+            q.gamma = e->params + g.gamma; q.beta = e->params + g.beta; q.sums = e->stats + S.sums;
+            q.B = B; q.T = e->T; q.N = L.cout; q.K = L.cin; q.taps = L.k; q.pad = (L.k - 1) / 2; q.G = g.G; q.Cg = g.C / g.G;
+            if (g.C == L.cout && conv_gn_fused_eligible(e->dt, q)) {
+                ScopedTimer tm(e, "conv_gn", &L, (int)M, L.cout, L.cin, L.k, 1);
+                if (launch_conv_gn_fwd(q, e->stream)) return fail(SGV_ERR_ARG, "conv_gn launch failed for %s", L.prefix.c_str());
+                x = S.a;
+                continue;
+            }
         }
         CHK(conv_fwd(e, L, cin, S.y, M));
         if (S.gn >= 0) {
@@ -2184,6 +2204,19 @@ int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* b
 
 // 256x256 persistent kernel (gemm256.hip), bf16.  mode 0: forced (launch_gemm_nt256, split-K as given), 1: the engine's plan
 // (gemm_nt_plan: kernel choice, split-K, main + tail rows).  sums != null: fused GroupNorm statistics (mode 0, split-K 1).
+int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const float* scale, const void* res, const float* gamma,
+                         const float* beta, void* y, void* out, double* sums, int B, int T, int N, int K, int taps, int G, float rscale,
+                         void* stream) {
+    ConvGN q; memset(&q, 0, sizeof(q));
+    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.w_tap_stride = (long)N * K; q.bias = bias; q.scale = scale;
+    q.y = y; q.ldy = N; q.out = out; q.ldout = N; q.res = res; q.ldres = N; q.rscale = rscale; q.gamma = gamma; q.beta = beta; q.sums = sums;
+    q.B = B; q.T = T; q.N = N; q.K = K; q.taps = taps; q.pad = (taps - 1) / 2; q.G = G; q.Cg = G > 0 ? N / G : 0;
+    if (!conv_gn_fused_eligible(SGV_DTYPE_BF16, q)) return fail(SGV_ERR_ARG, "shape not taken by the fused conv + GroupNorm kernel");
+    const int r = launch_conv_gn_fwd(q, (hipStream_t)stream);
+    const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    if (r || se != hipSuccess) return fail(SGV_ERR_HIP, "conv_gn launch failed (%d, %s)", r, hipGetErrorString(se));
+    return SGV_OK;
+}
 int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
                         int K, int taps, int Tlen, int splitk, int out_f32, int mode, int Cg, double* sums, int* plan_kind, void* stream) {
     GemmNT p; memset(&p, 0, sizeof(p));

@@ -33,6 +33,23 @@ struct GNParams {
 };
 
 constexpr int SGV_GN_MAX_GROUPS = 32;
+// convgn.hip: fused small convolution + GroupNorm + GELU (+ residual) forward, one workgroup per (group, sample)
+struct ConvGN {
+    const void* A; long lda;            // input [B*T][lda] bf16, K columns used
+    const void* W; long ldw;            // weights [taps][N][ldw] bf16 (K contiguous)
+    long w_tap_stride;
+    const float* bias;                  // [N]
+    const float* scale;                 // device scalar 1/sigma, or null
+    void* y; long ldy;                  // pre-norm conv output [B*T][ldy] bf16 (stored)
+    void* out; long ldout;              // result
+    const void* res; long ldres;        // optional residual base
+    float rscale;
+    const float* gamma; const float* beta;
+    double* sums;                       // [B*G][2] sum, sum of squares (stored)
+    int B, T, N, K, taps, pad, G, Cg;
+};
+bool conv_gn_fused_eligible(int dtype, const ConvGN& p);
+int launch_conv_gn_fwd(const ConvGN& p, hipStream_t s);
 // Deterministic reductions: no kernel of the step accumulates floating-point values with atomics.  Block partials go to
 // workspaces and are summed in a fixed order, either by the launcher itself or, for quantities nobody needs before the
 // optimizer (GroupNorm affine / bias gradients, <G, W_eff>), by two table-driven passes the engine runs once per bucket.

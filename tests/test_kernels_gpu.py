@@ -392,3 +392,72 @@ def test_gemm_nt_library_path(case):
         assert d.max() / np.abs(ref).max() < 8e-3 and d.mean() / np.abs(ref).mean() < 1e-4
     # shapes the engine keeps on its own kernels are refused by the hook
     assert lib.sgv_test_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, None, 64, 64, 64, None) != 0
+
+
+CONV_GN_CASES = [
+    # B, T, N, K, taps, G, residual
+    (2, 200, 512, 512, 3, 8, False),       # preset decoder block: Cg = 64, 13 row tiles (the last one with 8 valid rows)
+    (3, 200, 1024, 1024, 3, 8, True),      # widest fused layer: Cg = 128, residual add
+    (2, 200, 128, 256, 1, 8, False),       # Cg = 16, one tap
+    (2, 40, 256, 64, 5, 8, True),          # Cg = 32, five taps, short samples (3 row tiles: one wave idles)
+    (1, 16, 128, 32, 3, 8, False),         # a single row tile, a single K chunk
+    (2, 208, 256, 96, 3, 8, False),        # T at the kernel's maximum, K = 3 chunks
+]
+
+
+@pytest.mark.parametrize("case", CONV_GN_CASES)
+def test_conv_gn_fused_forward(case):
+    """csrc/convgn.hip (one launch: convolution + GroupNorm + GELU [+ residual]) against numpy in fp64 on bf16-exact inputs:
+    stored pre-norm output y (one bf16 rounding of the exact value), group sums of the stored y, the activated output, and a
+    bitwise-equal second launch."""
+    import math
+    import torch
+    lib = E.load_library()
+    B, T, N, K, taps, G, use_res = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31))
+    A = _bf16_round(rng.standard_normal((B * T, K)).astype(np.float32))
+    W = _bf16_round((rng.standard_normal((taps, N, K)) / math.sqrt(K * taps)).astype(np.float32))
+    bias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    gamma = (1.0 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    res = _bf16_round(rng.standard_normal((B * T, N)).astype(np.float32))
+    scale = np.array([0.83], np.float32)
+    y64 = ref_conv_nt(A, W, bias, 0.83, None, taps, T)
+    y_ref = _bf16_round(y64.astype(np.float32)).astype(np.float64)                 # what the kernel stores and normalises
+    Cg = N // G
+    yg = y_ref.reshape(B, T, G, Cg)
+    s1 = yg.sum(axis=(1, 3)); s2 = (yg ** 2).sum(axis=(1, 3))
+    mean = s1 / (T * Cg); var = np.maximum(s2 / (T * Cg) - mean ** 2, 0.0)
+    z = (yg - mean[:, None, :, None]) / np.sqrt(var[:, None, :, None] + 1e-5)
+    z = z.reshape(B * T, N) * gamma[None, :] + beta[None, :]
+    erf = np.vectorize(math.erf)
+    act = 0.5 * z * (1.0 + erf(z / math.sqrt(2.0)))
+    want = res + 0.1 * act if use_res else act
+    dA, dW, dres = _dev(A, 1), _dev(W, 1), _dev(res, 1)
+    dbias, dgamma, dbeta, dscale = (torch.from_numpy(v).cuda() for v in (bias, gamma, beta, scale))
+    outs = []
+    for rep in range(2):
+        y = torch.full((B * T, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        out = torch.full((B * T, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        sums = torch.full((B, G, 2), float("nan"), dtype=torch.float64, device="cuda")
+        rc = lib.sgv_test_conv_gn_fwd(dA.data_ptr(), dW.data_ptr(), dbias.data_ptr(), dscale.data_ptr(), dres.data_ptr() if use_res else None,
+                                      dgamma.data_ptr(), dbeta.data_ptr(), y.data_ptr(), out.data_ptr(), sums.data_ptr(), B, T, N, K, taps, G,
+                                      C.c_float(0.1 if use_res else 1.0), None)
+        assert rc == 0, lib.sgv_last_error()
+        outs.append((y.float().cpu().numpy(), out.float().cpu().numpy(), sums.cpu().numpy()))
+    yk, ok, sk = outs[0]
+    assert np.isfinite(yk).all() and np.isfinite(ok).all() and np.isfinite(sk).all()
+    # y: fp32 accumulation in another order may flip a bf16 rounding: one bf16 ulp (2^-8 relative) on few entries
+    assert np.abs(yk - y_ref).max() <= 2 ** -7 * np.abs(y_ref).max()
+    assert np.mean(np.abs(yk - y_ref)) <= 2e-4 * np.mean(np.abs(y_ref))
+    # sums of the values the kernel itself stored: exact up to fp32 partial sums
+    ykg = yk.astype(np.float64).reshape(B, T, G, Cg)
+    np.testing.assert_allclose(sk[..., 0], ykg.sum(axis=(1, 3)), rtol=0, atol=2e-4 * np.abs(ykg).sum(axis=(1, 3)).max())
+    np.testing.assert_allclose(sk[..., 1], (ykg ** 2).sum(axis=(1, 3)), rtol=2e-5)
+    assert np.abs(ok - want).max() <= 2e-2 * max(1.0, np.abs(want).max())
+    assert np.mean(np.abs(ok - want)) <= 3e-3 * np.mean(np.abs(want))
+    for a, b in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b)                                  # deterministic
+    # shapes the kernel does not take are refused (the engine then uses the GEMM + GroupNorm kernels)
+    assert lib.sgv_test_conv_gn_fwd(dA.data_ptr(), dW.data_ptr(), dbias.data_ptr(), None, None, dgamma.data_ptr(), dbeta.data_ptr(),
+                                    y.data_ptr(), out.data_ptr(), sums.data_ptr(), B, T, N, K, taps, 3, C.c_float(1.0), None) != 0
