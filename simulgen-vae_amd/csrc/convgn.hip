@@ -39,20 +39,23 @@ typedef __attribute__((address_space(3))) void cg_lds_t;
 // One K chunk = 32 channels = 64 bytes per LDS row.  Rows are written by LDS-DMA in blocks of 16 (one wave instruction = 64
 // lanes x 16 bytes = 16 rows x 4 slots); slot p of row r holds source chunk p ^ ((r >> 2) & 3), so the 16 rows a
 // ds_read_b128 fragment touches (same k-group, consecutive rows) fall into 16 different bank groups.
+template <int TAPS, int CT> struct CgGeom {
+    static constexpr int WR = TAPS * CT * 16;                         // weight rows per stage: [tap][column]
+    static constexpr int SB = (CG_AR + WR) * 64;                      // stage bytes
+    static constexpr int NS = (147456 / SB) >= 4 ? 4 : ((147456 / SB) >= 3 ? 3 : 2);      // ring depth
+    static constexpr int LDS = NS * SB;
+};
+struct CgOperands { const void* A; long lda; const void* W; long ldw; long w_tap_stride; int T, K, pad, Cg; };
+// acc[j][c] (+)= the 16 x 16 tile (row tile wave + 8 j, column tile c) of  sum_{tap,k} A[b*T + m + tap - pad][k] * W[tap][g*Cg + n][k]
+// for the workgroup's (group g, sample b); ends with a barrier (the LDS is free again).
 template <int TAPS, int CT>
-__global__ __launch_bounds__(512) void conv_gn_fwd_kernel(const ConvGN p) {
-    constexpr int WR = TAPS * CT * 16;                         // weight rows per stage: [tap][column]
-    constexpr int SB = (CG_AR + WR) * 64;                      // stage bytes
-    constexpr int NS = (147456 / SB) >= 4 ? 4 : ((147456 / SB) >= 3 ? 3 : 2);      // ring depth
+__device__ __forceinline__ void cg_contract(const CgOperands& p, int g, int b, unsigned char* smem, f32x4 (&acc)[2][CT]) {
+    constexpr int SB = CgGeom<TAPS, CT>::SB, NS = CgGeom<TAPS, CT>::NS;
     constexpr int NBLK = CG_AR / 16 + TAPS * CT;               // DMA blocks per stage
     constexpr int NI = (NBLK + 7) / 8;                         // DMA instructions per wave and stage (surplus ones repeat the last block)
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[NS * SB];
-    __shared__ double smd[16];
-
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int lr = lane & 15, q = lane >> 4;
-    const int g = blockIdx.x, b = blockIdx.y;
     const int T = p.T, RT = (T + 15) >> 4;
     const int arows = T + TAPS - 1;                                    // LDS row j <-> time j - pad
     const bf16_t* Ab = reinterpret_cast<const bf16_t*>(p.A) + (long)b * T * p.lda;
@@ -104,11 +107,6 @@ __global__ __launch_bounds__(512) void conv_gn_fwd_kernel(const ConvGN p) {
     // MFMA, but one wave per SIMD): 62 vs 74 us on 3200 x 1024 x (3 x 1024).
     const int rt0 = wave, rt1 = wave + 8 < RT ? wave + 8 : wave;
     const bool has1 = wave + 8 < RT;
-    f32x4 acc[2][CT];
-#pragma unroll
-    for (int j = 0; j < 2; ++j)
-#pragma unroll
-        for (int c = 0; c < CT; ++c) acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 fwA[CT], fwB[CT], faA[2], faB[2];                // fragment sets A / B: one tap is multiplied while the next is read
 #define CG_READ(FW, FA, TAP)                                                                                  \
     {                                                                                                         \
@@ -170,6 +168,26 @@ __global__ __launch_bounds__(512) void conv_gn_fwd_kernel(const ConvGN p) {
 #undef CG_PIN
 #undef CG_ISSUE
     __syncthreads();
+}
+
+template <int TAPS, int CT>
+__global__ __launch_bounds__(512) void conv_gn_fwd_kernel(const ConvGN p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[CgGeom<TAPS, CT>::LDS];
+    __shared__ double smd[16];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int T = p.T, RT = (T + 15) >> 4;
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        CgOperands o = {p.A, p.lda, p.W, p.ldw, p.w_tap_stride, p.T, p.K, p.pad, p.Cg};
+        cg_contract<TAPS, CT>(o, g, b, smem, acc);
+    }
 
     // ---- epilogue: y (bf16, stored), statistics of the stored values, normalise + GELU (+ residual) ----
     const float sc = p.scale ? *p.scale : 1.0f;
@@ -235,6 +253,161 @@ __global__ __launch_bounds__(512) void conv_gn_fwd_kernel(const ConvGN p) {
     }
 }
 
+// Backward mirror (see ConvGNBwd): dA = scale * sum_{tap,k} dY_up[m + tap - pad][k] * WcT[tap][n][k] (rounded to bf16, as the
+// separate input-gradient GEMM stores it), then the GroupNorm + GELU backward of the (group, sample) slab, all sums in a fixed
+// order: dz = dA * rscale * gelu'(z);  s1 = sum gamma dz, s2 = sum gamma dz xhat;  dY = gscale * rstd * (gamma dz - s1/n - xhat s2/n).
+template <int TAPS, int CT>
+__global__ __launch_bounds__(512) void conv_gn_bwd_kernel(const ConvGNBwd p) {
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[CgGeom<TAPS, CT>::LDS];
+    __shared__ float smc[3][8][CT * 16];
+    __shared__ float smw[3][8];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int lr = lane & 15, q = lane >> 4;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int T = p.T, RT = (T + 15) >> 4;
+    f32x4 acc[2][CT];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int c = 0; c < CT; ++c) acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    {
+        CgOperands o = {p.A, p.lda, p.W, p.ldw, p.w_tap_stride, p.T, p.K, p.pad, p.Cg};
+        cg_contract<TAPS, CT>(o, g, b, smem, acc);
+    }
+    typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+    const float sc = p.scale ? *p.scale : 1.0f;
+    const double cnt = (double)p.Cg * (double)T;
+    const double S = p.sums[((long)b * p.G + g) * 2 + 0], SS = p.sums[((long)b * p.G + g) * 2 + 1];
+    const double md = S / cnt;
+    double var = SS / cnt - md * md;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)md, rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const int n_lane = g * p.Cg + q * 4;                                // + c * 16
+    const bf16_t* yb = reinterpret_cast<const bf16_t*>(p.y) + (long)b * T * p.ldy;
+    f32x4 yv[2][CT];                                                    // y of this lane's outputs (kept for the second pass)
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + n_lane + c * 16);
+        const float4 bt = *reinterpret_cast<const float4*>(p.beta + n_lane + c * 16);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w}, btv[4] = {bt.x, bt.y, bt.z, bt.w};
+        float cA[4] = {0.f, 0.f, 0.f, 0.f}, cB[4] = {0.f, 0.f, 0.f, 0.f}, cX[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = (wave + 8 * j) * 16 + lr;
+            yv[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (wave + 8 * j < RT && m < T) {
+                const bf16x4 yy = *reinterpret_cast<const bf16x4*>(yb + (long)m * p.ldy + n_lane + c * 16);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float yf = (float)yy[r];
+                    const float da = (float)(bf16_t)(acc[j][c][r] * sc);
+                    const float xh = (yf - mean) * rstd;
+                    const float qv = da * p.rscale * gelu_grad_f(xh * gmv[r] + btv[r]);
+                    yv[j][c][r] = yf;
+                    acc[j][c][r] = qv;
+                    cA[r] += qv; cB[r] += qv * xh; cX[r] += xh;
+                }
+            } else {
+                acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            }
+        }
+        // column sums over the 16 rows of the wave's tiles (lanes that share q), then to LDS for the sum over the waves
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { cA[r] += __shfl_xor(cA[r], o, 64); cB[r] += __shfl_xor(cB[r], o, 64); cX[r] += __shfl_xor(cX[r], o, 64); }
+        }
+        if (lr == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                smc[0][wave][c * 16 + q * 4 + r] = cA[r];
+                smc[1][wave][c * 16 + q * 4 + r] = cB[r];
+                smc[2][wave][c * 16 + q * 4 + r] = cX[r];
+            }
+        }
+    }
+    __syncthreads();
+    // column owners: thread n < Cg adds the eight waves in order; s1 / s2 over the group's columns
+    float colA = 0.f, colB = 0.f, colX = 0.f, s1 = 0.f, s2 = 0.f, gown = 0.f;
+    const bool owner = tid < p.Cg;
+    if (owner) {
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { colA += smc[0][w][tid]; colB += smc[1][w][tid]; colX += smc[2][w][tid]; }
+        gown = p.gamma[g * p.Cg + tid];
+        s1 = gown * colA; s2 = gown * colB;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
+    if (lane == 0) { smw[0][wave] = s1; smw[1][wave] = s2; }
+    __syncthreads();
+    s1 = (smw[0][0] + smw[0][1]);      // Cg <= 128: the owners sit in waves 0 and 1
+    s2 = (smw[1][0] + smw[1][1]);
+    if (tid == 0) {
+        p.sums2[((long)b * p.G + g) * 2 + 0] = (double)s1;
+        p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
+    }
+    const float m1 = (float)((double)s1 / cnt), m2 = (float)((double)s2 / cnt);
+    if (owner) {
+        const long C = (long)p.G * p.Cg;
+        float* pt = p.ptot + (long)b * 3 * C + g * p.Cg + tid;
+        pt[0] = colA;
+        pt[C] = colB;
+        pt[2 * C] = p.gscale * rstd * (gown * colA - (float)T * m1 - m2 * colX);
+    }
+    // dY and the <G, W_eff> partial
+    bf16_t* dyb = reinterpret_cast<bf16_t*>(p.dy) + (long)b * T * p.lddy;
+    float dotacc = 0.f;
+#pragma unroll
+    for (int c = 0; c < CT; ++c) {
+        const float4 gm = *reinterpret_cast<const float4*>(p.gamma + n_lane + c * 16);
+        const float gmv[4] = {gm.x, gm.y, gm.z, gm.w};
+        float cb[4] = {0.f, 0.f, 0.f, 0.f};
+        if (p.cbias) { const float4 t4 = *reinterpret_cast<const float4*>(p.cbias + n_lane + c * 16); cb[0] = t4.x; cb[1] = t4.y; cb[2] = t4.z; cb[3] = t4.w; }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int m = (wave + 8 * j) * 16 + lr;
+            if (wave + 8 * j < RT && m < T) {
+                bf16x4 o;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float yf = yv[j][c][r];
+                    const float xh = (yf - mean) * rstd;
+                    const float d = rstd * (gmv[r] * acc[j][c][r] - m1 - xh * m2) * p.gscale;
+                    dotacc += d * (yf - cb[r]);
+                    o[r] = (bf16_t)d;
+                }
+                *reinterpret_cast<bf16x4*>(dyb + (long)m * p.lddy + n_lane + c * 16) = o;
+            }
+        }
+    }
+    if (p.cdot_part) {
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) dotacc += __shfl_down(dotacc, o, 64);
+        if (lane == 0) smw[2][wave] = dotacc;
+        __syncthreads();
+        if (tid == 0) {
+            float tot = 0.f;
+#pragma unroll
+            for (int w = 0; w < 8; ++w) tot += smw[2][w];
+            p.cdot_part[(long)b * p.G + g] = tot;
+        }
+    }
+}
+
+template <int TAPS>
+static int launch_taps_bwd(const ConvGNBwd& p, hipStream_t s) {
+    const dim3 grid(p.G, p.B), block(512);
+    switch (p.Cg >> 4) {
+        case 1: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 1>), grid, block, 0, s, p); break;
+        case 2: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 2>), grid, block, 0, s, p); break;
+        case 4: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 4>), grid, block, 0, s, p); break;
+        case 8: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 8>), grid, block, 0, s, p); break;
+        default: return -1;
+    }
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
 template <int TAPS>
 static int launch_taps(const ConvGN& p, hipStream_t s) {
     const dim3 grid(p.G, p.B), block(512);
@@ -269,4 +442,27 @@ int launch_conv_gn_fwd(const ConvGN& p, hipStream_t s) {
     if (p.taps == 1) return launch_taps<1>(p, s);
     if (p.taps == 3) return launch_taps<3>(p, s);
     return launch_taps<5>(p, s);
+}
+
+bool conv_gn_bwd_eligible(int dtype, const ConvGNBwd& p) {
+    if (dtype != 1) return false;
+    if (p.taps != 1 && p.taps != 3 && p.taps != 5) return false;
+    if (p.pad != (p.taps - 1) / 2) return false;
+    if (p.T < 1 || p.T > CG_MAX_T || p.B < 1 || p.G < 1) return false;
+    if (p.Cg != 16 && p.Cg != 32 && p.Cg != 64 && p.Cg != 128) return false;
+    if (p.N != p.G * p.Cg) return false;
+    if (p.K < 32 || p.K % 32) return false;
+    if (p.lda % 8 || p.ldw % 8 || p.w_tap_stride % 8 || p.ldy % 4 || p.lddy % 4) return false;
+    if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return false;
+    if (((uintptr_t)p.y | (uintptr_t)p.dy) & 7) return false;
+    if (((uintptr_t)p.gamma | (uintptr_t)p.beta | (uintptr_t)p.cbias) & 15) return false;
+    if (!p.sums || !p.sums2 || !p.ptot) return false;
+    return true;
+}
+
+int launch_conv_gn_bwd(const ConvGNBwd& p, hipStream_t s) {
+    if (!conv_gn_bwd_eligible(1, p)) return -1;
+    if (p.taps == 1) return launch_taps_bwd<1>(p, s);
+    if (p.taps == 3) return launch_taps_bwd<3>(p, s);
+    return launch_taps_bwd<5>(p, s);
 }

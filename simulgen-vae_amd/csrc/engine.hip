@@ -1033,6 +1033,7 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
     const long M = (long)B * e->T;
     Tensor dA = dOut;
     float sc = b.residual ? 0.1f : 1.0f;
+    bool dy_ready = false;          // the stage's dY was produced by the fused kernel launched from the stage above
     for (int s = (int)b.st.size() - 1; s >= 0; --s) {
         Stage& S = b.st[s];
         const Layer& L = e->layers[S.layer];
@@ -1042,7 +1043,10 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
         // <G,W_eff> and the GroupNorm affine / bias gradients leave these kernels as block / per-sample partials in e->red; the
         // fixed-order sums run once per bucket (flush_fin in backward_impl)
         int* cnt = &e->dot_counts[e->fin_dots.size() % 512];
-        if (S.gn >= 0) {
+        if (dy_ready) {
+            dY = S.dy;
+            dy_ready = false;
+        } else if (S.gn >= 0) {
             const GNLayer& g = e->gns[S.gn];
             GNParams p = gn_base(e, g, B);
             p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.sums2 = e->stats + S.sums2;
@@ -1077,6 +1081,33 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
         if (s == 0 && before_first_dw) (*before_first_dw)();
         CHK(conv_bwd_dw(e, L, dY, x_conv, M));
         const bool need = (s > 0) || (dIn != nullptr);
+        if (need && s > 0 && !S.pre_gelu && e->use_convgn && e->dt == SGV_DTYPE_BF16 && L.need_wct && (long)L.cout * L.k <= e->convgn_maxk) {
+            // input gradient of this convolution + GroupNorm / GELU backward of the stage below in one launch (convgn.hip): the
+            // gradient wrt that stage's activated output is never stored
+            Stage& P = b.st[s - 1];
+            const Layer& LP = e->layers[P.layer];
+            if (P.gn >= 0 && P.act == 1 && !P.y.f32) {
+                const GNLayer& g = e->gns[P.gn];
+                ConvGNBwd q; memset(&q, 0, sizeof(q));
+                q.A = dY.p; q.lda = dY.ld; q.W = wct_ptr(e, L); q.ldw = L.cout; q.w_tap_stride = (long)L.cin * L.cout;
+                q.scale = e->sn_sigma + 2 * L.sn + 1;
+                q.y = P.y.p; q.ldy = P.y.ld; q.sums = e->stats + P.sums; q.gamma = e->params + g.gamma; q.beta = e->params + g.beta;
+                q.cbias = e->params + LP.b; q.dy = P.dy.p; q.lddy = P.dy.ld; q.sums2 = e->stats + P.sums2; q.ptot = e->red + g.ptot;
+                q.cdot_part = e->red + LP.dot_part; q.rscale = 1.f; q.gscale = 1.f;
+                q.B = B; q.T = e->T; q.N = L.cin; q.K = L.cout; q.taps = L.k; q.pad = (L.k - 1) / 2; q.G = g.G; q.Cg = g.C / g.G;
+                if (g.C == L.cin && LP.cout == L.cin && conv_gn_bwd_eligible(e->dt, q)) {
+                    ScopedTimer tm(e, "conv_gn_bwd", &L, (int)M, L.cin, L.cout, L.k, 1);
+                    if (launch_conv_gn_bwd(q, e->stream)) return fail(SGV_ERR_ARG, "conv_gn_bwd launch failed for %s", L.prefix.c_str());
+                    int* cntp = &e->dot_counts[e->fin_dots.size() % 512];
+                    *cntp = g.G * B;
+                    e->fin_dots.push_back({q.cdot_part, e->grads + LP.gdot, *cntp, 0});
+                    e->fin_affine.push_back({q.ptot, e->grads + g.gbeta, e->grads + g.ggamma, e->grads + LP.gb, g.C, B, 0, 0});
+                    dy_ready = true;
+                    dA = P.da;
+                    continue;
+                }
+            }
+        }
         if (need) {
             const Tensor target = (s > 0) ? b.st[s - 1].da : *dIn;
             if (S.pre_gelu) {
@@ -2215,6 +2246,20 @@ int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const 
     const int r = launch_conv_gn_fwd(q, (hipStream_t)stream);
     const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
     if (r || se != hipSuccess) return fail(SGV_ERR_HIP, "conv_gn launch failed (%d, %s)", r, hipGetErrorString(se));
+    return SGV_OK;
+}
+int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* y, const double* sums, const float* gamma,
+                         const float* beta, const float* cbias, void* dy, double* sums2, float* ptot, float* cdot_part, int B, int T,
+                         int N, int K, int taps, int G, void* stream) {
+    ConvGNBwd q; memset(&q, 0, sizeof(q));
+    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.w_tap_stride = (long)N * K; q.scale = scale;
+    q.y = y; q.ldy = N; q.sums = sums; q.gamma = gamma; q.beta = beta; q.cbias = cbias; q.dy = dy; q.lddy = N;
+    q.sums2 = sums2; q.ptot = ptot; q.cdot_part = cdot_part; q.rscale = 1.f; q.gscale = 1.f;
+    q.B = B; q.T = T; q.N = N; q.K = K; q.taps = taps; q.pad = (taps - 1) / 2; q.G = G; q.Cg = G > 0 ? N / G : 0;
+    if (!conv_gn_bwd_eligible(SGV_DTYPE_BF16, q)) return fail(SGV_ERR_ARG, "shape not taken by the fused input-gradient + GroupNorm backward kernel");
+    const int r = launch_conv_gn_bwd(q, (hipStream_t)stream);
+    const hipError_t se = hipStreamSynchronize((hipStream_t)stream);
+    if (r || se != hipSuccess) return fail(SGV_ERR_HIP, "conv_gn_bwd launch failed (%d, %s)", r, hipGetErrorString(se));
     return SGV_OK;
 }
 int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,

@@ -48,6 +48,26 @@ struct ConvGN {
     double* sums;                       // [B*G][2] sum, sum of squares (stored)
     int B, T, N, K, taps, pad, G, Cg;
 };
+// backward mirror: input gradient of the UPPER convolution + GroupNorm / GELU backward of the stage below it in one launch
+// (the gradient wrt the lower stage's activated output is never stored)
+struct ConvGNBwd {
+    const void* A; long lda;            // dY of the upper stage [B*T][lda] bf16, K = its output channels
+    const void* W; long ldw;            // its transposed, tap-flipped weight copy [taps][N][ldw] bf16
+    long w_tap_stride;
+    const float* scale;                 // 1/sigma of the upper convolution, or null
+    const void* y; long ldy;            // pre-norm output of the lower stage [B*T][ldy] bf16
+    const double* sums;                 // its forward statistics [B*G][2]
+    const float* gamma; const float* beta;
+    const float* cbias;                 // bias of the lower convolution (for <G, W_eff>), or null
+    void* dy; long lddy;                // out: gradient wrt y [B*T][lddy] bf16
+    double* sums2;                      // out [B*G][2]
+    float* ptot;                        // out [B][3][C]: per-sample column totals (sum dz, sum dz*xhat, bias-gradient term)
+    float* cdot_part;                   // out [B*G]: partials of <G, W_eff> = sum dY * (y - cbias), or null
+    float rscale, gscale;
+    int B, T, N, K, taps, pad, G, Cg;
+};
+bool conv_gn_bwd_eligible(int dtype, const ConvGNBwd& p);
+int launch_conv_gn_bwd(const ConvGNBwd& p, hipStream_t s);
 bool conv_gn_fused_eligible(int dtype, const ConvGN& p);
 int launch_conv_gn_fwd(const ConvGN& p, hipStream_t s);
 // Deterministic reductions: no kernel of the step accumulates floating-point values with atomics.  Block partials go to

@@ -461,3 +461,70 @@ def test_conv_gn_fused_forward(case):
     # shapes the kernel does not take are refused (the engine then uses the GEMM + GroupNorm kernels)
     assert lib.sgv_test_conv_gn_fwd(dA.data_ptr(), dW.data_ptr(), dbias.data_ptr(), None, None, dgamma.data_ptr(), dbeta.data_ptr(),
                                     y.data_ptr(), out.data_ptr(), sums.data_ptr(), B, T, N, K, taps, 3, C.c_float(1.0), None) != 0
+
+
+@pytest.mark.parametrize("case", CONV_GN_CASES)
+def test_conv_gn_fused_backward(case):
+    """csrc/convgn.hip backward mirror (input gradient of the upper convolution + GroupNorm / GELU backward of the stage below in
+    one launch) against numpy in fp64: dY, the group sums (s1, s2), the per-sample column totals and the <G, W_eff> partials;
+    a second launch is bitwise equal."""
+    import math
+    import torch
+    lib = E.load_library()
+    B, T, N, K, taps, G, _ = case
+    rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
+    dYup = _bf16_round((0.5 * rng.standard_normal((B * T, K))).astype(np.float32))
+    W = _bf16_round((rng.standard_normal((taps, N, K)) / math.sqrt(K * taps)).astype(np.float32))
+    y = _bf16_round(rng.standard_normal((B * T, N)).astype(np.float32))
+    gamma = (1.0 + 0.2 * rng.standard_normal(N)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    cbias = (0.1 * rng.standard_normal(N)).astype(np.float32)
+    scale = np.array([0.83], np.float32)
+    Cg = N // G
+    cnt = T * Cg
+    dA = _bf16_round(ref_conv_nt(dYup, W, None, 0.83, None, taps, T).astype(np.float32)).astype(np.float64)
+    yg = y.astype(np.float64).reshape(B, T, G, Cg)
+    S = yg.sum(axis=(1, 3)); SS = (yg ** 2).sum(axis=(1, 3))
+    mean = S / cnt; var = np.maximum(SS / cnt - mean ** 2, 0.0); rstd = 1.0 / np.sqrt(var + 1e-5)
+    xh = (yg - mean[:, None, :, None]) * rstd[:, None, :, None]
+    gm = gamma.astype(np.float64).reshape(G, Cg)[None, None]; bt = beta.astype(np.float64).reshape(G, Cg)[None, None]
+    z = xh * gm + bt
+    erf = np.vectorize(math.erf)
+    gprime = 0.5 * (1.0 + erf(z / math.sqrt(2.0))) + z * np.exp(-0.5 * z * z) / math.sqrt(2.0 * math.pi)
+    dz = dA.reshape(B, T, G, Cg) * gprime
+    s1 = (gm * dz).sum(axis=(1, 3)); s2 = (gm * dz * xh).sum(axis=(1, 3))
+    dy_ref = rstd[:, None, :, None] * (gm * dz - s1[:, None, :, None] / cnt - xh * s2[:, None, :, None] / cnt)
+    colA = dz.sum(axis=1); colB = (dz * xh).sum(axis=1); colX = xh.sum(axis=1)                      # [B][G][Cg]
+    colD = rstd[:, :, None] * (gm[0] * colA - T * s1[:, :, None] / cnt - s2[:, :, None] / cnt * colX)
+    dot_ref = (dy_ref * (yg - cbias.astype(np.float64).reshape(G, Cg)[None, None])).sum(axis=(1, 3))
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    dA_dev, dW, dy_in = _dev(dYup, 1), _dev(W, 1), _dev(y, 1)
+    sums = d(np.stack([S, SS], axis=-1))
+    dg, db, dcb, dsc = d(gamma), d(beta), d(cbias), d(scale)
+    outs = []
+    for rep in range(2):
+        dy = torch.full((B * T, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        sums2 = torch.full((B, G, 2), float("nan"), dtype=torch.float64, device="cuda")
+        ptot = torch.full((B, 3, N), float("nan"), dtype=torch.float32, device="cuda")
+        cdot = torch.full((B, G), float("nan"), dtype=torch.float32, device="cuda")
+        rc = lib.sgv_test_conv_gn_bwd(dA_dev.data_ptr(), dW.data_ptr(), dsc.data_ptr(), dy_in.data_ptr(), sums.data_ptr(), dg.data_ptr(),
+                                      db.data_ptr(), dcb.data_ptr(), dy.data_ptr(), sums2.data_ptr(), ptot.data_ptr(), cdot.data_ptr(),
+                                      B, T, N, K, taps, G, None)
+        assert rc == 0, lib.sgv_last_error()
+        outs.append((dy.float().cpu().numpy(), sums2.cpu().numpy(), ptot.cpu().numpy(), cdot.cpu().numpy()))
+    dyk, s2k, ptk, cdk = outs[0]
+    for a in outs[0]:
+        assert np.isfinite(a).all()
+    dyr = dy_ref.reshape(B * T, N)
+    assert np.abs(dyk - dyr).max() <= 2e-2 * np.abs(dyr).max()
+    assert np.mean(np.abs(dyk - dyr)) <= 4e-3 * np.mean(np.abs(dyr))
+    scale12 = np.abs(gm * dz).sum(axis=(1, 3))                      # s1 / s2 are sums with cancellation: scale by the sum of magnitudes
+    assert np.abs(s2k[..., 0] - s1).max() <= 3e-3 * scale12.max()
+    assert np.abs(s2k[..., 1] - s2).max() <= 3e-3 * np.abs(gm * dz * xh).sum(axis=(1, 3)).max()
+    pt = ptk.reshape(B, 3, G, Cg)
+    assert np.abs(pt[:, 0] - colA).max() <= 3e-3 * np.abs(dz).sum(axis=1).max()
+    assert np.abs(pt[:, 1] - colB).max() <= 3e-3 * np.abs(dz * xh).sum(axis=1).max()
+    assert np.abs(pt[:, 2] - colD).max() <= 5e-3 * (np.abs(colD).max() + np.abs(rstd[:, :, None] * gm[0] * np.abs(dz).sum(axis=1)).max())
+    assert np.abs(cdk - dot_ref).max() <= 5e-3 * np.abs(dy_ref * (yg - cbias.reshape(G, Cg)[None, None])).sum(axis=(1, 3)).max()
+    for a, b2 in zip(outs[0], outs[1]):
+        assert np.array_equal(a, b2)
