@@ -256,7 +256,7 @@ int sgv_test_gemm_nt_stats(const void* A, const void* W, void* C, const float* b
                            int taps, int Tlen, int Cg, double* sums, void* stream);
 /* Test hook: the fused small Conv1d + GroupNorm(G) + GELU (+ residual) forward kernel (csrc/convgn.hip) on caller-owned device
  * buffers: A [B*T][K] bf16, W [taps][N][K] bf16, y / out / res [B*T][N] bf16, sums [B*G][2] doubles.  Fails for shapes the kernel
- * does not take (T > 208, channels per group not in {16, 32, 64, 128}, K % 32 != 0). */
+ * does not take (T > 208, channels per group not in {16, 32, 64, 80, 128, 160}, K % 32 != 0). */
 int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const float* scale, const void* res, const float* gamma,
                          const float* beta, void* y, void* out, double* sums, int B, int T, int N, int K, int taps, int G, float rscale,
                          void* stream);

@@ -9,7 +9,7 @@
 //
 // Why: for these layers the step spent three launches -- an implicit-GEMM kernel with split-K (few 128-row tiles exist), its
 // combine pass and the fused GroupNorm kernel -- of 15 + 6 + 9 us, each latency-bound.  One workgroup per (group, sample) owns
-// the whole T x Cg output slab of its normalisation group (T <= 208 rows, Cg <= 128 columns), so the contraction needs no
+// the whole T x Cg output slab of its normalisation group (T <= 208 rows, Cg <= 160 columns), so the contraction needs no
 // split, the statistics are complete inside the workgroup, and y never has to be re-read: one launch, deterministic (fixed
 // summation order), 128 workgroups of 4 waves.
 //
@@ -341,8 +341,8 @@ __global__ __launch_bounds__(512) void conv_gn_bwd_kernel(const ConvGNBwd p) {
     for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_down(s1, o, 64); s2 += __shfl_down(s2, o, 64); }
     if (lane == 0) { smw[0][wave] = s1; smw[1][wave] = s2; }
     __syncthreads();
-    s1 = (smw[0][0] + smw[0][1]);      // Cg <= 128: the owners sit in waves 0 and 1
-    s2 = (smw[1][0] + smw[1][1]);
+    s1 = (smw[0][0] + smw[0][1]) + smw[0][2];      // Cg <= 160: the owners sit in waves 0-2 (the others wrote zeros)
+    s2 = (smw[1][0] + smw[1][1]) + smw[1][2];
     if (tid == 0) {
         p.sums2[((long)b * p.G + g) * 2 + 0] = (double)s1;
         p.sums2[((long)b * p.G + g) * 2 + 1] = (double)s2;
@@ -402,7 +402,9 @@ static int launch_taps_bwd(const ConvGNBwd& p, hipStream_t s) {
         case 1: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 1>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 2>), grid, block, 0, s, p); break;
         case 4: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 4>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 5>), grid, block, 0, s, p); break;
         case 8: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 8>), grid, block, 0, s, p); break;
+        case 10: hipLaunchKernelGGL((conv_gn_bwd_kernel<TAPS, 10>), grid, block, 0, s, p); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -415,7 +417,9 @@ static int launch_taps(const ConvGN& p, hipStream_t s) {
         case 1: hipLaunchKernelGGL((conv_gn_fwd_kernel<TAPS, 1>), grid, block, 0, s, p); break;
         case 2: hipLaunchKernelGGL((conv_gn_fwd_kernel<TAPS, 2>), grid, block, 0, s, p); break;
         case 4: hipLaunchKernelGGL((conv_gn_fwd_kernel<TAPS, 4>), grid, block, 0, s, p); break;
+        case 5: hipLaunchKernelGGL((conv_gn_fwd_kernel<TAPS, 5>), grid, block, 0, s, p); break;
         case 8: hipLaunchKernelGGL((conv_gn_fwd_kernel<TAPS, 8>), grid, block, 0, s, p); break;
+        case 10: hipLaunchKernelGGL((conv_gn_fwd_kernel<TAPS, 10>), grid, block, 0, s, p); break;
         default: return -1;
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
@@ -427,7 +431,7 @@ bool conv_gn_fused_eligible(int dtype, const ConvGN& p) {
     if (p.taps != 1 && p.taps != 3 && p.taps != 5) return false;
     if (p.pad != (p.taps - 1) / 2) return false;
     if (p.T < 1 || p.T > CG_MAX_T || p.B < 1 || p.G < 1) return false;
-    if (p.Cg != 16 && p.Cg != 32 && p.Cg != 64 && p.Cg != 128) return false;
+    if (p.Cg != 16 && p.Cg != 32 && p.Cg != 64 && p.Cg != 80 && p.Cg != 128 && p.Cg != 160) return false;
     if (p.N != p.G * p.Cg) return false;
     if (p.K < 32 || p.K % 32) return false;
     if (p.lda % 8 || p.ldw % 8 || p.w_tap_stride % 8 || p.ldy % 4 || p.ldout % 4 || (p.res && p.ldres % 4)) return false;
@@ -449,7 +453,7 @@ bool conv_gn_bwd_eligible(int dtype, const ConvGNBwd& p) {
     if (p.taps != 1 && p.taps != 3 && p.taps != 5) return false;
     if (p.pad != (p.taps - 1) / 2) return false;
     if (p.T < 1 || p.T > CG_MAX_T || p.B < 1 || p.G < 1) return false;
-    if (p.Cg != 16 && p.Cg != 32 && p.Cg != 64 && p.Cg != 128) return false;
+    if (p.Cg != 16 && p.Cg != 32 && p.Cg != 64 && p.Cg != 80 && p.Cg != 128 && p.Cg != 160) return false;
     if (p.N != p.G * p.Cg) return false;
     if (p.K < 32 || p.K % 32) return false;
     if (p.lda % 8 || p.ldw % 8 || p.w_tap_stride % 8 || p.ldy % 4 || p.lddy % 4) return false;

@@ -402,6 +402,8 @@ CONV_GN_CASES = [
     (2, 40, 256, 64, 5, 8, True),          # Cg = 32, five taps, short samples (3 row tiles: one wave idles)
     (1, 16, 128, 32, 3, 8, False),         # a single row tile, a single K chunk
     (2, 208, 256, 96, 3, 8, False),        # T at the kernel's maximum, K = 3 chunks
+    (2, 200, 640, 128, 1, 8, False),       # Cg = 80 (five column tiles): the 5C-channel decoder residual layers
+    (2, 200, 1280, 256, 1, 8, True),       # Cg = 160 (ten column tiles; the column owners of the backward kernel span three waves)
 ]
 
 
