@@ -283,8 +283,7 @@ def main():
         eng.augment_collate(data, idx, seeds, scale, mix, lam)
         eng.forward(train=True, sync=False)
         if ddp:
-            eng.backward(ALPHA, epochs_beta)
-            allreduce.step(eng, LR)
+            allreduce.backward_step(eng, ALPHA, epochs_beta, LR)      # one rank: the fused single-GPU step, no collective
         else:
             eng.backward_step(ALPHA, epochs_beta, LR)     # backward + AdamW, optimizer overlapped under backward
 

@@ -105,7 +105,17 @@ class GradAllReduce:
             engine.set_grad_payload("bf16")
             lp_ptr, lp_n = engine.grad_payload_buffer()
             self.flat_lp = torch.as_tensor(_DevArray(lp_ptr, lp_n, "<i2"), device="cuda").view(torch.bfloat16)
-        engine.set_bucket_callback(self._on_bucket)
+        if not self.single:
+            engine.set_bucket_callback(self._on_bucket)        # one rank: nothing to exchange, the engine keeps its single-GPU schedule
+
+    def backward_step(self, engine, alpha, beta, lr):
+        """backward + gradient exchange + AdamW.  One rank: the engine's fused step (optimizer overlapped under backward), exactly
+        the single-GPU path; several ranks: backward with bucket callbacks, then the bucket-ordered optimizer."""
+        if self.single:
+            engine.backward_step(alpha, beta, lr)
+        else:
+            engine.backward(alpha, beta)
+            self.step(engine, lr)
 
     def _on_bucket(self, b, off, cnt):
         seg = self.flat[off:off + cnt] if self.flat_lp is None or b == self.nb - 1 else self.flat_lp[off:off + cnt]
@@ -168,10 +178,19 @@ class NativeAllReduce:
         if lib.sgv_rccl_comm_init(C.byref(comm), world, ident, rank) != 0:
             raise RuntimeError(lib.sgv_last_error().decode())
         self.comm = comm.value
+        self.single = world == 1
         if world > 1 and grad_payload_dtype(engine) == "bf16":
             engine.set_grad_payload("bf16")      # the engine packs, all-reduces the bf16 copy and unpacks by itself
         self.stream = torch.cuda.Stream()
-        engine.set_rccl(self.comm, self.stream.cuda_stream)
+        if not self.single:
+            engine.set_rccl(self.comm, self.stream.cuda_stream)      # one rank: nothing to exchange, single-GPU schedule
+
+    def backward_step(self, engine, alpha, beta, lr):
+        if self.single:
+            engine.backward_step(alpha, beta, lr)
+        else:
+            engine.backward(alpha, beta)
+            self.step(engine, lr)
 
     def step(self, engine, lr):
         engine.adamw_step(lr)           # waits for the buckets in the overlapped order (sgv_adamw_step with a communicator)
@@ -181,7 +200,8 @@ class NativeAllReduce:
 
     def close(self):
         if self.comm:
-            self.engine.set_rccl(None, None)
+            if not self.single:
+                self.engine.set_rccl(None, None)
             self.engine.lib.sgv_rccl_comm_destroy(self.comm)
             self.comm = None
 
@@ -260,8 +280,7 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
                 eng.set_input(model._prep(item))
             eng.forward(train=True, sync=False)          # nothing in the step waits for the host: the step's scalars and its
             if allreduce is not None:                   # gradient norm (train.py:156-161,171-174) are added up on the device
-                eng.backward(alpha, beta)
-                allreduce.step(eng, lr)
+                allreduce.backward_step(eng, alpha, beta, lr)
             else:
                 eng.backward_step(alpha, beta, lr)
             eng.accumulate_scalars()

@@ -271,6 +271,11 @@ def test_native_rccl_path_equals_plain_step():
             eng.load_state(state)
             eng.seed(99)
             ar = NativeAllReduce(eng) if mode != "plain" else None
+            if ar is not None:
+                # a one-rank NativeAllReduce leaves the engine on its single-GPU schedule (nothing to exchange); register the
+                # communicator by hand so that the engine's own bucket / event / wait plumbing is what runs here
+                assert ar.single
+                eng.set_rccl(ar.comm, ar.stream.cuda_stream)
             norms = []
             for step in range(3):
                 eng.set_input(x)
@@ -295,6 +300,7 @@ def test_native_rccl_path_equals_plain_step():
                 np.testing.assert_array_equal(eng.grad("decoder.decoder_residual_blocks.1.seq.3.weight_orig"), g0)
             outs.append((eng.state_dict(), norms))
             if ar is not None:
+                eng.set_rccl(None, None)
                 ar.close()
             eng.close()
         (sa, na) = outs[0]
