@@ -71,6 +71,7 @@ struct Layer {
     int sn = -1;
     int splitk_tn = 1;
     size_t dot_part = NPOS;                         // per-block <G,W_eff> partials of the layer's dY kernel (e->red arena)
+    size_t col_part = NPOS;                         // per-block column sums of dY (bias gradient of a conv without GroupNorm), same arena
     long nw() const { return (long)cout * cin * k; }
 };
 struct GNLayer {
@@ -1065,7 +1066,9 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
             p.out = S.dy.p; p.ldout = S.dy.ld; p.dbias = e->grads + L.gb; p.part = e->colpart; p.B = B; p.T = e->T; p.C = L.cout;
             p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b;
             p.cdot_part = e->red + L.dot_part; p.cdot_blocks = cnt;
+            if (L.col_part != NPOS) { p.part = e->red + L.col_part; p.defer_colsum = 1; }     // bias gradient: summed with the small bucket's other sums
             ew_act(e->dt, 1, p, e->stream);
+            if (L.col_part != NPOS) e->fin_affine.push_back({p.part, p.dbias, nullptr, nullptr, L.cout, ew_act_part_rows(B, e->T, L.cout), 0, 1});
             e->fin_dots.push_back({p.cdot_part, p.cdot, *cnt, 0});
             dY = S.dy;
         } else {
@@ -1073,7 +1076,9 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
             if (!S.y.f32) return fail(SGV_ERR_STATE, "conv without norm/activation must have an fp32 output (%s)", L.prefix.c_str());
             p.cdot = e->grads + L.gdot; p.cbias = e->params + L.b; p.yf32 = (const float*)S.y.p; p.ldyf = S.y.ld;
             p.cdot_part = e->red + L.dot_part; p.cdot_blocks = cnt;
+            if (L.col_part != NPOS) { p.part = e->red + L.col_part; p.defer_colsum = 1; }
             ew_act(e->dt, 2, p, e->stream);
+            if (L.col_part != NPOS) e->fin_affine.push_back({p.part, p.dbias, nullptr, nullptr, L.cout, ew_act_part_rows(B, e->T, L.cout), 0, 1});
             e->fin_dots.push_back({p.cdot_part, p.cdot, *cnt, 0});
             dY = dA;
         }
@@ -1213,6 +1218,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
         size_t nr = 0;
         for (auto& g : e->gns) { g.ptot = nr; nr += align_up((size_t)e->maxB * 3 * g.C, 4); }
         for (auto& l : e->layers) if (l.op != OP_LINEAR) { l.dot_part = nr; nr += align_up((size_t)ew_gn_max_blocks(e->maxB, e->T, l.cout), 4); }
+        for (auto& l : e->layers) if (l.op != OP_LINEAR && l.used && l.cout <= 8192) { l.col_part = nr; nr += align_up((size_t)ew_act_part_rows(e->maxB, e->T, l.cout) * l.cout, 4); }
         e->red_floats = nr;
     }
     ALLOC(e->red, e->red_floats * 4);

@@ -567,9 +567,13 @@ __global__ __launch_bounds__(256) void fin_affine_kernel(const FinAffineArgs a) 
     const int c = ((int)blockIdx.x - a.chunk0[i]) * 256 + threadIdx.x;
     if (c >= it.C) return;
     float A = 0.f, Bv = 0.f, D = 0.f;
-    for (int b = 0; b < it.B; ++b) {
-        const float* pt = it.ptot + (long)b * 3 * it.C + c;
-        A += pt[0]; Bv += pt[it.C]; D += pt[2L * it.C];
+    if (it.arrays == 1) {                 // [B][C] column-sum partials (bias gradient of a convolution without GroupNorm)
+        for (int b = 0; b < it.B; ++b) A += it.ptot[(long)b * it.C + c];
+    } else {
+        for (int b = 0; b < it.B; ++b) {
+            const float* pt = it.ptot + (long)b * 3 * it.C + c;
+            A += pt[0]; Bv += pt[it.C]; D += pt[2L * it.C];
+        }
     }
     if (it.dbeta) it.dbeta[c] = (it.accum ? it.dbeta[c] : 0.f) + A;
     if (it.dgamma) it.dgamma[c] = (it.accum ? it.dgamma[c] : 0.f) + Bv;
@@ -960,6 +964,7 @@ static GNWork gn_work(int B, int T, int C) {
     return w;
 }
 size_t ew_gn_part_floats(int B, int T, int C) { return gn_work(B, T, C).total; }
+int ew_act_part_rows(int B, int T, int C) { return B * gn_geom(B, T, C, GN_REDUCE_TARGET).rowsplit; }
 int ew_gn_max_blocks(int B, int T, int C) { return gn_work(B, T, C).nblk; }
 // deferred mode (p.ptot / p.cdot_part given): only report the partial count; else sum the partials here
 static void gn_fin_immediate(const GNParams& p, bool own_ptot, bool own_dots, int nblk, hipStream_t s) {
@@ -1145,7 +1150,7 @@ int ew_act(int dtype, int mode, GNParams p, hipStream_t s) {
         else { if (mode == 1) GN_LAUNCH_R((act_kernel<float, 1>), p, s); else GN_LAUNCH_R((act_kernel<float, 2>), p, s); }
         // combine the per-block column sums into the bias gradient
         GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-        hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 16)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
+        if (!p.defer_colsum) hipLaunchKernelGGL(colsum_finalize_kernel, dim3(cdiv_i(p.C, 16)), dim3(256), 0, s, p.part, p.B * g_.rowsplit, p.C, p.dbias);
         gn_fin_immediate(p, false, own_dots, grid_total(g_.grid), s);
         return 0;
     }

@@ -25,6 +25,7 @@ struct GNParams {
     double* sums2 = nullptr;                       // [B*G][2] backward group sums
     double* loss_sums = nullptr;                   // [2]
     int accum_affine = 0;                          // immediate mode: dbeta / dgamma / dbias += instead of =
+    int defer_colsum = 0;                          // ew_act modes 1 / 2: leave the per-block column sums in `part` ([ew_act_part_rows][C]); the caller sums them later (ew_fin_affine, arrays = 1)
     float* lpart = nullptr;                        // recon loss: per-block (selected, squared) partial sums (workspace)
     int B = 0, T = 0, C = 0, G = 1, Cg = 1, CV = 1;
     float rscale = 1.f;                            // residual / incoming-gradient scale
@@ -74,7 +75,7 @@ int launch_conv_gn_fwd(const ConvGN& p, hipStream_t s);
 // workspaces and are summed in a fixed order, either by the launcher itself or, for quantities nobody needs before the
 // optimizer (GroupNorm affine / bias gradients, <G, W_eff>), by two table-driven passes the engine runs once per bucket.
 struct FinDot { const float* src; float* dst; int count; int pad; };                      // dst[0] = sum src[0..count)
-struct FinAffine { const float* ptot; float* dbeta; float* dgamma; float* dbias; int C; int B; int accum; int pad; };   // d*[c] (+)= sum_b ptot[b][k][c]
+struct FinAffine { const float* ptot; float* dbeta; float* dgamma; float* dbias; int C; int B; int accum; int arrays; };   // d*[c] (+)= sum_b ptot[b][k][c]; arrays = k range (0 -> 3; 1: ptot is [B][C], dbeta only)
 int ew_fin_dots(const FinDot* items_host, int n, hipStream_t s);
 int ew_fin_affine(const FinAffine* items_host, int n, hipStream_t s);
 // out[b*n + j] = scale * sum_{r<R} part[(b*R + r)*n + j] in a fixed order (out_f or out_d, the other null)
@@ -88,7 +89,8 @@ int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // ac
 int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
 size_t ew_gn_part_floats(int B, int T, int C);
-int ew_gn_max_blocks(int B, int T, int C);          // upper bound of the per-block <G,W_eff> partials one launch writes
+int ew_gn_max_blocks(int B, int T, int C);
+int ew_act_part_rows(int B, int T, int C);         // rows of per-block column sums an ew_act launch with dbias writes          // upper bound of the per-block <G,W_eff> partials one launch writes
 int ew_recon_loss(int dtype, int train, GNParams p, hipStream_t s);
 int ew_recon_bwd_apply(int dtype, GNParams p, hipStream_t s);
 int ew_act(int dtype, int mode, GNParams p, hipStream_t s);
