@@ -104,8 +104,11 @@ int sgv_set_eps(sgv_engine* e, int site, const float* eps_dev, int batch);
 int sgv_seed(sgv_engine* e, uint64_t seed);
 /* Engine switches: "write_xhat" (materialise the reconstruction in training forwards; default 1),
  * "use_tr" (weight-gradient GEMM reads LDS with ds_read_b64_tr_b16; default 1), "dw_side_stream" (small weight-gradient
- * GEMMs on a second stream; default 1), "vendor_gemm" (plain one-tap bf16 GEMMs the library wins go to hipBLASLt when
- * libhipblaslt.so.1 can be loaded; default 1, 0 keeps every GEMM on the hand-written kernels). */
+ * GEMMs on a second stream; default 1), "vendor_gemm" (A/B comparator: plain one-tap bf16 GEMMs go to hipBLASLt when
+ * libhipblaslt.so.1 can be loaded; default 0: every GEMM runs on the hand-written kernels), "deterministic" (default 1: no
+ * floating-point atomics anywhere in the step), "lanes" (second compute lane for the posterior branch of a decoder stage and
+ * the xs heads; schedule only, results are bitwise the same; default 1), "fused_stages" (small Conv1d -> GroupNorm -> GELU
+ * stages in one launch, csrc/convgn.hip; default 1, 0: GEMM + split-K combine + GroupNorm kernels). */
 int sgv_set_option(sgv_engine* e, const char* key, int value);
 
 /* VAE.forward (VAE_network.py:79-121) on the current input.  train != 0: spectral-norm power

@@ -1464,6 +1464,8 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     else if (!strcmp(key, "dw_side_stream")) e->use_side = value != 0 && e->side != nullptr;
     else if (!strcmp(key, "vendor_gemm")) e->vendor_gemm = value != 0;
     else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
+    else if (!strcmp(key, "lanes")) e->use_lanes = value != 0 && e->lane2 != nullptr;          // second compute lane (schedule only: results are bitwise the same)
+    else if (!strcmp(key, "fused_stages")) e->use_convgn = value != 0;                          // csrc/convgn.hip kernels for the small Conv -> GroupNorm -> GELU stages
     else return fail(SGV_ERR_ARG, "unknown option '%s'", key);
     return SGV_OK;
 }

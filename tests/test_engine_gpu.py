@@ -226,3 +226,41 @@ def test_api_error_behaviour():
     eng.backward(1.0, 1.0)
     assert eng.grad("encoder.xs_linear.0.weight_orig") is None       # dead parameter: grad=None as in the reference
     eng.close()
+
+
+def test_schedule_and_fused_stage_options_agree():
+    """Two engine switches on a net whose stages the fused kernels take (G2: 256-32 channels, T = 40), bf16:
+    "lanes" changes the schedule only -> loss and every gradient BITWISE equal with the lane on and off;
+    "fused_stages" swaps GEMM + combine + GroupNorm kernels for csrc/convgn.hip -> same step up to bf16 rounding order
+    (stated: ELBO 2e-4, gradient tensors 2e-2 rel-L2)."""
+    import torch
+    cfg = make_cfg(G2, True)
+    state = init_state(cfg, 7)
+    B = 2
+    x = synthetic_samples(20251003, range(B), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(1234, 0, cfg, B)
+    names = [k for k in state if k.endswith("weight_orig")][:24]
+    out = {}
+    for tag, opts in (("base", {}), ("nolanes", {"lanes": 0}), ("unfused", {"fused_stages": 0})):
+        eng = E.Engine(cfg, max_batch=B, compute_dtype="bf16")
+        for k, v in opts.items():
+            eng.set_option(k, v)
+        eng.load_state(state)
+        eng.set_input(torch.from_numpy(x).cuda())
+        eng.set_eps([torch.from_numpy(e).cuda() for e in eps])
+        sc = eng.forward(train=True)
+        eng.backward(1e6, 1e-4)
+        out[tag] = (sc, {k: eng.grad(k) for k in names if eng.grad(k) is not None}, eng.grad_norm())
+        eng.close()
+    sb, gb, nb = out["base"]
+    sl, gl, nl = out["nolanes"]
+    assert sb["recon"] == sl["recon"] and list(sb["kls"]) == list(sl["kls"]) and nb == nl
+    for k in gb:
+        assert np.array_equal(gb[k], gl[k]), k
+    su, gu, nu = out["unfused"]
+    eb = 1e6 * sb["recon"] + 1e-4 * sum(sb["kls"])
+    eu = 1e6 * su["recon"] + 1e-4 * sum(su["kls"])
+    assert abs(eb - eu) <= 2e-4 * abs(eu), (eb, eu)
+    assert abs(nb - nu) <= 1e-2 * nu
+    for k in gb:
+        assert rel_l2(gb[k], gu[k]) < 2e-2, (k, rel_l2(gb[k], gu[k]))
