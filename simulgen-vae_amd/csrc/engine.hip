@@ -1029,12 +1029,43 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
 // dOut: gradient wrt the block output; dIn (nullable): gradient wrt the block input (overwritten).
 // before_first_dw (optional) runs after the last dY of the block exists, right before the weight-gradient GEMM of
 // the block's first conv (sgv_backward uses it to release the small-gradient bucket early).
+// Input gradient of convolution L (its dY given) + GroupNorm / GELU backward of stage P below it in one launch (convgn.hip);
+// `addend` (residual path) is added to the input gradient before it is rounded.  Returns 1 when the fused kernel ran (P.dy,
+// the group sums, the per-sample column totals and the <G, W_eff> partials of P's layer are written and their fixed-order sums
+// queued), 0 when the shapes are not taken, < 0 on error.
+static int fused_dx_gn_bwd(sgv_engine* e, const Layer& L, const Tensor& dY, const Tensor* addend, Stage& P, int B, long M) {
+    if (!e->use_convgn || e->dt != SGV_DTYPE_BF16 || !L.need_wct || (long)L.cout * L.k > e->convgn_maxk) return 0;
+    if (P.gn < 0 || P.act != 1 || P.y.f32) return 0;
+    const Layer& LP = e->layers[P.layer];
+    const GNLayer& g = e->gns[P.gn];
+    ConvGNBwd q; memset(&q, 0, sizeof(q));
+    q.A = dY.p; q.lda = dY.ld; q.W = wct_ptr(e, L); q.ldw = L.cout; q.w_tap_stride = (long)L.cin * L.cout;
+    q.scale = e->sn_sigma + 2 * L.sn + 1;
+    if (addend) { q.addend = addend->p; q.ldadd = addend->ld; }
+    q.y = P.y.p; q.ldy = P.y.ld; q.sums = e->stats + P.sums; q.gamma = e->params + g.gamma; q.beta = e->params + g.beta;
+    q.cbias = e->params + LP.b; q.dy = P.dy.p; q.lddy = P.dy.ld; q.sums2 = e->stats + P.sums2; q.ptot = e->red + g.ptot;
+    q.cdot_part = e->red + LP.dot_part; q.rscale = 1.f; q.gscale = 1.f;
+    q.B = B; q.T = e->T; q.N = L.cin; q.K = L.cout; q.taps = L.k; q.pad = (L.k - 1) / 2; q.G = g.G; q.Cg = g.C / g.G;
+    if (g.C != L.cin || LP.cout != L.cin || !conv_gn_bwd_eligible(e->dt, q)) return 0;
+    ScopedTimer tm(e, "conv_gn_bwd", &L, (int)M, L.cin, L.cout, L.k, 1);
+    if (launch_conv_gn_bwd(q, e->stream)) return fail(SGV_ERR_ARG, "conv_gn_bwd launch failed for %s", L.prefix.c_str());
+    int* cntp = &e->dot_counts[e->fin_dots.size() % 512];
+    *cntp = g.G * B;
+    e->fin_dots.push_back({q.cdot_part, e->grads + LP.gdot, *cntp, 0});
+    e->fin_affine.push_back({q.ptot, e->grads + g.gbeta, e->grads + g.ggamma, e->grads + LP.gb, g.C, B, 0, 0});
+    return 1;
+}
+
+// below / below_done (optional): the last stage of the block that consumes dIn as its incoming gradient and nothing else does;
+// when the fused kernel can take (this block's first convolution, that stage) together, dIn is not written, *below_done is
+// set and the caller passes last_dy_ready = true to that block's block_bwd.
 static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dOut, const Tensor* dIn, int B,
-                     const std::function<void()>* before_first_dw = nullptr) {
+                     const std::function<void()>* before_first_dw = nullptr, Stage* below = nullptr, bool* below_done = nullptr,
+                     bool last_dy_ready = false) {
     const long M = (long)B * e->T;
     Tensor dA = dOut;
     float sc = b.residual ? 0.1f : 1.0f;
-    bool dy_ready = false;          // the stage's dY was produced by the fused kernel launched from the stage above
+    bool dy_ready = last_dy_ready;  // the stage's dY was produced by the fused kernel launched from the stage above
     for (int s = (int)b.st.size() - 1; s >= 0; --s) {
         Stage& S = b.st[s];
         const Layer& L = e->layers[S.layer];
@@ -1086,31 +1117,15 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
         if (s == 0 && before_first_dw) (*before_first_dw)();
         CHK(conv_bwd_dw(e, L, dY, x_conv, M));
         const bool need = (s > 0) || (dIn != nullptr);
-        if (need && s > 0 && !S.pre_gelu && e->use_convgn && e->dt == SGV_DTYPE_BF16 && L.need_wct && (long)L.cout * L.k <= e->convgn_maxk) {
-            // input gradient of this convolution + GroupNorm / GELU backward of the stage below in one launch (convgn.hip): the
-            // gradient wrt that stage's activated output is never stored
-            Stage& P = b.st[s - 1];
-            const Layer& LP = e->layers[P.layer];
-            if (P.gn >= 0 && P.act == 1 && !P.y.f32) {
-                const GNLayer& g = e->gns[P.gn];
-                ConvGNBwd q; memset(&q, 0, sizeof(q));
-                q.A = dY.p; q.lda = dY.ld; q.W = wct_ptr(e, L); q.ldw = L.cout; q.w_tap_stride = (long)L.cin * L.cout;
-                q.scale = e->sn_sigma + 2 * L.sn + 1;
-                q.y = P.y.p; q.ldy = P.y.ld; q.sums = e->stats + P.sums; q.gamma = e->params + g.gamma; q.beta = e->params + g.beta;
-                q.cbias = e->params + LP.b; q.dy = P.dy.p; q.lddy = P.dy.ld; q.sums2 = e->stats + P.sums2; q.ptot = e->red + g.ptot;
-                q.cdot_part = e->red + LP.dot_part; q.rscale = 1.f; q.gscale = 1.f;
-                q.B = B; q.T = e->T; q.N = L.cin; q.K = L.cout; q.taps = L.k; q.pad = (L.k - 1) / 2; q.G = g.G; q.Cg = g.C / g.G;
-                if (g.C == L.cin && LP.cout == L.cin && conv_gn_bwd_eligible(e->dt, q)) {
-                    ScopedTimer tm(e, "conv_gn_bwd", &L, (int)M, L.cin, L.cout, L.k, 1);
-                    if (launch_conv_gn_bwd(q, e->stream)) return fail(SGV_ERR_ARG, "conv_gn_bwd launch failed for %s", L.prefix.c_str());
-                    int* cntp = &e->dot_counts[e->fin_dots.size() % 512];
-                    *cntp = g.G * B;
-                    e->fin_dots.push_back({q.cdot_part, e->grads + LP.gdot, *cntp, 0});
-                    e->fin_affine.push_back({q.ptot, e->grads + g.gbeta, e->grads + g.ggamma, e->grads + LP.gb, g.C, B, 0, 0});
-                    dy_ready = true;
-                    dA = P.da;
-                    continue;
-                }
+        if (need && !S.pre_gelu && (s > 0 || (below && below_done))) {
+            Stage& P = s > 0 ? b.st[s - 1] : *below;
+            const Tensor* add = (s == 0 && b.residual) ? &dOut : nullptr;
+            const int fr = fused_dx_gn_bwd(e, L, dY, add, P, B, M);
+            if (fr < 0) return fr;
+            if (fr > 0) {
+                if (s > 0) { dy_ready = true; dA = P.da; }
+                else *below_done = true;
+                continue;
             }
         }
         if (need) {
@@ -1910,7 +1925,8 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             ew_linear_head_bwd(e->dt, e->d_xs_raw[i], e->enc_h[i].p, e->params + xl.w, e->sn_sigma + 2 * xl.sn + 1, e->d_h[i].p, e->d_h[i].p,
                                e->grads + xl.gw, e->grads + xl.gb, B, xl.cin, xl.cout, e->stream);
         }
-        CHK(block_bwd(e, e->encR[i], e->encA[i].st.back().a, e->d_h[i], &e->enc_a_dummy[i], B));
+        bool a_ready = false;       // the residual block's input gradient went straight into the GroupNorm backward of encA[i]'s last stage
+        CHK(block_bwd(e, e->encR[i], e->encA[i].st.back().a, e->d_h[i], &e->enc_a_dummy[i], B, nullptr, &e->encA[i].st.back(), &a_ready));
         const Tensor x_prev = i == 0 ? e->x_in : e->enc_h[i - 1];
         if (i == 0) {
             fire();   // everything but the first block's weight gradients is now enqueued
@@ -1921,9 +1937,9 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             // release it BEFORE the first-layer weight-gradient GEMM so that its all-reduce (and, with it, the AdamW
             // of every other layer) does not queue behind the 390 MB first-layer bucket
             const std::function<void()> early = [&]() { flush_fin(true); fire_at(small_bucket); };
-            CHK(block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early));
+            CHK(block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early, nullptr, nullptr, a_ready));
         } else {
-            CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], &e->d_h[i - 1], B));
+            CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], &e->d_h[i - 1], B, nullptr, nullptr, nullptr, a_ready));
         }
     }
     fire();   // first encoder block's weights
@@ -2256,11 +2272,11 @@ int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const 
     if (r || se != hipSuccess) return fail(SGV_ERR_HIP, "conv_gn launch failed (%d, %s)", r, hipGetErrorString(se));
     return SGV_OK;
 }
-int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* y, const double* sums, const float* gamma,
+int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* addend, const void* y, const double* sums, const float* gamma,
                          const float* beta, const float* cbias, void* dy, double* sums2, float* ptot, float* cdot_part, int B, int T,
                          int N, int K, int taps, int G, void* stream) {
     ConvGNBwd q; memset(&q, 0, sizeof(q));
-    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.w_tap_stride = (long)N * K; q.scale = scale;
+    q.A = A; q.lda = K; q.W = W; q.ldw = K; q.w_tap_stride = (long)N * K; q.scale = scale; q.addend = addend; q.ldadd = N;
     q.y = y; q.ldy = N; q.sums = sums; q.gamma = gamma; q.beta = beta; q.cbias = cbias; q.dy = dy; q.lddy = N;
     q.sums2 = sums2; q.ptot = ptot; q.cdot_part = cdot_part; q.rscale = 1.f; q.gscale = 1.f;
     q.B = B; q.T = T; q.N = N; q.K = K; q.taps = taps; q.pad = (taps - 1) / 2; q.G = G; q.Cg = G > 0 ? N / G : 0;

@@ -56,6 +56,7 @@ struct ConvGNBwd {
     const void* W; long ldw;            // its transposed, tap-flipped weight copy [taps][N][ldw] bf16
     long w_tap_stride;
     const float* scale;                 // 1/sigma of the upper convolution, or null
+    const void* addend; long ldadd;     // optional [B*T][ldadd] bf16 added to the input gradient before it is rounded (residual path)
     const void* y; long ldy;            // pre-norm output of the lower stage [B*T][ldy] bf16
     const double* sums;                 // its forward statistics [B*G][2]
     const float* gamma; const float* beta;

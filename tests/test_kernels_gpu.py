@@ -467,13 +467,13 @@ def test_conv_gn_fused_forward(case):
 
 @pytest.mark.parametrize("case", CONV_GN_CASES)
 def test_conv_gn_fused_backward(case):
-    """csrc/convgn.hip backward mirror (input gradient of the upper convolution + GroupNorm / GELU backward of the stage below in
-    one launch) against numpy in fp64: dY, the group sums (s1, s2), the per-sample column totals and the <G, W_eff> partials;
+    """csrc/convgn.hip backward mirror (input gradient of the upper convolution [+ the residual path's addend] + GroupNorm / GELU
+    backward of the stage below in one launch) against numpy in fp64: dY, the group sums (s1, s2), the per-sample column totals and the <G, W_eff> partials;
     a second launch is bitwise equal."""
     import math
     import torch
     lib = E.load_library()
-    B, T, N, K, taps, G, _ = case
+    B, T, N, K, taps, G, use_res = case
     rng = np.random.default_rng(abs(hash(case)) % (2 ** 31) + 1)
     dYup = _bf16_round((0.5 * rng.standard_normal((B * T, K))).astype(np.float32))
     W = _bf16_round((rng.standard_normal((taps, N, K)) / math.sqrt(K * taps)).astype(np.float32))
@@ -484,7 +484,8 @@ def test_conv_gn_fused_backward(case):
     scale = np.array([0.83], np.float32)
     Cg = N // G
     cnt = T * Cg
-    dA = _bf16_round(ref_conv_nt(dYup, W, None, 0.83, None, taps, T).astype(np.float32)).astype(np.float64)
+    add = _bf16_round((0.3 * rng.standard_normal((B * T, N))).astype(np.float32)) if use_res else None     # residual path of the block above
+    dA = _bf16_round(ref_conv_nt(dYup, W, None, 0.83, add, taps, T).astype(np.float32)).astype(np.float64)
     yg = y.astype(np.float64).reshape(B, T, G, Cg)
     S = yg.sum(axis=(1, 3)); SS = (yg ** 2).sum(axis=(1, 3))
     mean = S / cnt; var = np.maximum(SS / cnt - mean ** 2, 0.0); rstd = 1.0 / np.sqrt(var + 1e-5)
@@ -501,6 +502,7 @@ def test_conv_gn_fused_backward(case):
     dot_ref = (dy_ref * (yg - cbias.astype(np.float64).reshape(G, Cg)[None, None])).sum(axis=(1, 3))
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     dA_dev, dW, dy_in = _dev(dYup, 1), _dev(W, 1), _dev(y, 1)
+    dadd = _dev(add, 1) if use_res else None
     sums = d(np.stack([S, SS], axis=-1))
     dg, db, dcb, dsc = d(gamma), d(beta), d(cbias), d(scale)
     outs = []
@@ -509,7 +511,7 @@ def test_conv_gn_fused_backward(case):
         sums2 = torch.full((B, G, 2), float("nan"), dtype=torch.float64, device="cuda")
         ptot = torch.full((B, 3, N), float("nan"), dtype=torch.float32, device="cuda")
         cdot = torch.full((B, G), float("nan"), dtype=torch.float32, device="cuda")
-        rc = lib.sgv_test_conv_gn_bwd(dA_dev.data_ptr(), dW.data_ptr(), dsc.data_ptr(), dy_in.data_ptr(), sums.data_ptr(), dg.data_ptr(),
+        rc = lib.sgv_test_conv_gn_bwd(dA_dev.data_ptr(), dW.data_ptr(), dsc.data_ptr(), dadd.data_ptr() if use_res else None, dy_in.data_ptr(), sums.data_ptr(), dg.data_ptr(),
                                       db.data_ptr(), dcb.data_ptr(), dy.data_ptr(), sums2.data_ptr(), ptot.data_ptr(), cdot.data_ptr(),
                                       B, T, N, K, taps, G, None)
         assert rc == 0, lib.sgv_last_error()
