@@ -264,10 +264,12 @@ int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const 
                          const float* beta, void* y, void* out, double* sums, int B, int T, int N, int K, int taps, int G, float rscale,
                          void* stream);
 /* Test hook: its backward mirror -- input gradient of the upper convolution (A = its dY [B*T][K], W = its transposed tap-flipped
- * weight copy [taps][N][K], optional addend [B*T][N] bf16 added before rounding: the residual path) + GroupNorm / GELU backward
+ * weight copy [taps][N][K], optional addend [B*T][N] bf16 added before rounding: the residual path; optional premul x [B*T][N]: the
+ * gradient is multiplied by gelu'(x) and rounded again; optional da [B*T][N]: the input gradient itself is stored too) + GroupNorm / GELU backward
  * of the stage below (y, forward sums, gamma, beta, conv bias) in one
  * launch: dy [B*T][N] bf16, sums2 [B*G][2], ptot [B][3][N] (per-sample column totals), cdot_part [B*G]. */
-int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* addend, const void* y, const double* sums, const float* gamma,
+int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* addend, const void* premul, void* da, const void* y,
+                         const double* sums, const float* gamma,
                          const float* beta, const float* cbias, void* dy, double* sums2, float* ptot, float* cdot_part, int B, int T,
                          int N, int K, int taps, int G, void* stream);
 /* Test hook for the 256x256 persistent implicit-GEMM kernel (csrc/gemm256.hip; replaces the hipBLASLt dispatch of round 1 on

@@ -300,16 +300,22 @@ __global__ __launch_bounds__(512) void conv_gn_bwd_kernel(const ConvGNBwd p) {
                 const bf16x4 yy = *reinterpret_cast<const bf16x4*>(yb + (long)m * p.ldy + n_lane + c * 16);
                 bf16x4 ad = {0, 0, 0, 0};
                 if (p.addend) ad = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.addend) + ((long)b * T + m) * p.ldadd + n_lane + c * 16);
+                bf16x4 dav = {0, 0, 0, 0};
+                bf16x4 pm = {0, 0, 0, 0};
+                if (p.premul) pm = *reinterpret_cast<const bf16x4*>(reinterpret_cast<const bf16_t*>(p.premul) + ((long)b * T + m) * p.ldpre + n_lane + c * 16);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float yf = (float)yy[r];
-                    const float da = (float)(bf16_t)(acc[j][c][r] * sc + (float)ad[r]);
+                    float da = (float)(bf16_t)(acc[j][c][r] * sc + (float)ad[r]);
+                    if (p.premul) da = (float)(bf16_t)(da * gelu_grad_f((float)pm[r]));
+                    dav[r] = (bf16_t)da;
                     const float xh = (yf - mean) * rstd;
                     const float qv = da * p.rscale * gelu_grad_f(xh * gmv[r] + btv[r]);
                     yv[j][c][r] = yf;
                     acc[j][c][r] = qv;
                     cA[r] += qv; cB[r] += qv * xh; cX[r] += xh;
                 }
+                if (p.da) *reinterpret_cast<bf16x4*>(reinterpret_cast<bf16_t*>(p.da) + ((long)b * T + m) * p.ldda + n_lane + c * 16) = dav;
             } else {
                 acc[j][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
             }
@@ -460,8 +466,8 @@ bool conv_gn_bwd_eligible(int dtype, const ConvGNBwd& p) {
     if (p.K < 32 || p.K % 32) return false;
     if (p.lda % 8 || p.ldw % 8 || p.w_tap_stride % 8 || p.ldy % 4 || p.lddy % 4) return false;
     if (((uintptr_t)p.A | (uintptr_t)p.W) & 15) return false;
-    if (((uintptr_t)p.y | (uintptr_t)p.dy | (uintptr_t)p.addend) & 7) return false;
-    if (p.addend && p.ldadd % 4) return false;
+    if (((uintptr_t)p.y | (uintptr_t)p.dy | (uintptr_t)p.addend | (uintptr_t)p.premul | (uintptr_t)p.da) & 7) return false;
+    if ((p.addend && p.ldadd % 4) || (p.premul && p.ldpre % 4) || (p.da && p.ldda % 4)) return false;
     if (((uintptr_t)p.gamma | (uintptr_t)p.beta | (uintptr_t)p.cbias) & 15) return false;
     if (!p.sums || !p.sums2 || !p.ptot) return false;
     return true;

@@ -1030,10 +1030,12 @@ static int block_fwd(sgv_engine* e, Block& b, const Tensor& in, int B) {
 // before_first_dw (optional) runs after the last dY of the block exists, right before the weight-gradient GEMM of
 // the block's first conv (sgv_backward uses it to release the small-gradient bucket early).
 // Input gradient of convolution L (its dY given) + GroupNorm / GELU backward of stage P below it in one launch (convgn.hip);
-// `addend` (residual path) is added to the input gradient before it is rounded.  Returns 1 when the fused kernel ran (P.dy,
+// `addend` (residual path) is added to the input gradient before it is rounded; `premul` = x when L reads GELU(x) (the gradient
+// is multiplied by gelu'(x)); rscale = the residual scale of P's block when P is its last stage.  Returns 1 when the fused kernel ran (P.dy,
 // the group sums, the per-sample column totals and the <G, W_eff> partials of P's layer are written and their fixed-order sums
 // queued), 0 when the shapes are not taken, < 0 on error.
-static int fused_dx_gn_bwd(sgv_engine* e, const Layer& L, const Tensor& dY, const Tensor* addend, Stage& P, int B, long M) {
+static int fused_dx_gn_bwd(sgv_engine* e, const Layer& L, const Tensor& dY, const Tensor* addend, Stage& P, int B, long M,
+                           const Tensor* premul = nullptr, float rscale = 1.f, const Tensor* da_out = nullptr) {
     if (!e->use_convgn || e->dt != SGV_DTYPE_BF16 || !L.need_wct || (long)L.cout * L.k > e->convgn_maxk) return 0;
     if (P.gn < 0 || P.act != 1 || P.y.f32) return 0;
     const Layer& LP = e->layers[P.layer];
@@ -1042,9 +1044,11 @@ static int fused_dx_gn_bwd(sgv_engine* e, const Layer& L, const Tensor& dY, cons
     q.A = dY.p; q.lda = dY.ld; q.W = wct_ptr(e, L); q.ldw = L.cout; q.w_tap_stride = (long)L.cin * L.cout;
     q.scale = e->sn_sigma + 2 * L.sn + 1;
     if (addend) { q.addend = addend->p; q.ldadd = addend->ld; }
+    if (premul) { q.premul = premul->p; q.ldpre = premul->ld; }
+    if (da_out) { q.da = da_out->p; q.ldda = da_out->ld; }
     q.y = P.y.p; q.ldy = P.y.ld; q.sums = e->stats + P.sums; q.gamma = e->params + g.gamma; q.beta = e->params + g.beta;
     q.cbias = e->params + LP.b; q.dy = P.dy.p; q.lddy = P.dy.ld; q.sums2 = e->stats + P.sums2; q.ptot = e->red + g.ptot;
-    q.cdot_part = e->red + LP.dot_part; q.rscale = 1.f; q.gscale = 1.f;
+    q.cdot_part = e->red + LP.dot_part; q.rscale = rscale; q.gscale = 1.f;
     q.B = B; q.T = e->T; q.N = L.cin; q.K = L.cout; q.taps = L.k; q.pad = (L.k - 1) / 2; q.G = g.G; q.Cg = g.C / g.G;
     if (g.C != L.cin || LP.cout != L.cin || !conv_gn_bwd_eligible(e->dt, q)) return 0;
     ScopedTimer tm(e, "conv_gn_bwd", &L, (int)M, L.cin, L.cout, L.k, 1);
@@ -1056,12 +1060,12 @@ static int fused_dx_gn_bwd(sgv_engine* e, const Layer& L, const Tensor& dY, cons
     return 1;
 }
 
-// below / below_done (optional): the last stage of the block that consumes dIn as its incoming gradient and nothing else does;
-// when the fused kernel can take (this block's first convolution, that stage) together, dIn is not written, *below_done is
-// set and the caller passes last_dy_ready = true to that block's block_bwd.
+// below / below_done (optional): the last stage of the block that consumes dIn as its incoming gradient; when the fused kernel
+// can take (this block's first convolution, that stage) together, it writes dIn AND that stage's dY, *below_done is set and the
+// caller passes last_dy_ready = true to that block's block_bwd (below_rscale: that block's residual scale).
 static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dOut, const Tensor* dIn, int B,
                      const std::function<void()>* before_first_dw = nullptr, Stage* below = nullptr, bool* below_done = nullptr,
-                     bool last_dy_ready = false) {
+                     bool last_dy_ready = false, float below_rscale = 1.f) {
     const long M = (long)B * e->T;
     Tensor dA = dOut;
     float sc = b.residual ? 0.1f : 1.0f;
@@ -1117,10 +1121,11 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
         if (s == 0 && before_first_dw) (*before_first_dw)();
         CHK(conv_bwd_dw(e, L, dY, x_conv, M));
         const bool need = (s > 0) || (dIn != nullptr);
-        if (need && !S.pre_gelu && (s > 0 || (below && below_done))) {
+        if (need && (s > 0 ? !S.pre_gelu : (below && below_done))) {
             Stage& P = s > 0 ? b.st[s - 1] : *below;
             const Tensor* add = (s == 0 && b.residual) ? &dOut : nullptr;
-            const int fr = fused_dx_gn_bwd(e, L, dY, add, P, B, M);
+            // across blocks the input gradient itself is stored too (dIn): a residual block below adds it to its own input gradient
+            const int fr = fused_dx_gn_bwd(e, L, dY, add, P, B, M, S.pre_gelu ? &x_raw : nullptr, s > 0 ? 1.f : below_rscale, s > 0 ? nullptr : dIn);
             if (fr < 0) return fr;
             if (fr > 0) {
                 if (s > 0) { dy_ready = true; dA = P.da; }
@@ -1889,16 +1894,18 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             Tensor d_oq = e->dcat[i]; d_oq.C = C; d_oq.p = (char*)d_oq.p + (size_t)C * e->esz;
             {   // posterior branch on the second lane, beside the prior branch below (they meet in the add3 after the join)
                 Lane2 lane(e);
-                CHK(block_bwd(e, e->decQ2[i], e->decQ1[i].st.back().a, e->gq[i], &e->d_qres[i], B));
-                CHK(block_bwd(e, e->decQ1[i], e->cat[i], e->d_qres[i], &e->dcat[i], B));
+                bool q_ready = false;      // condition_xz: the output convolution's input gradient went straight into the residual block's GroupNorm backward
+                CHK(block_bwd(e, e->decQ2[i], e->decQ1[i].st.back().a, e->gq[i], &e->d_qres[i], B, nullptr, &e->decQ1[i].st.back(), &q_ready, false, 0.1f));
+                CHK(block_bwd(e, e->decQ1[i], e->cat[i], e->d_qres[i], &e->dcat[i], B, nullptr, nullptr, nullptr, q_ready));
                 CHK(block_bwd(e, e->decX[i], e->xl[i], d_xs, &e->d_xl[i], B));
                 const Layer& l = e->layers[e->xs_exp[i]];
                 const int lvl = n - 2 - i;
                 ew_linear_expand_bwd(e->dt, e->d_xl[i].p, e->xs_raw[lvl], e->params + l.w, e->sn_sigma + 2 * l.sn + 1, e->d_xs_raw[lvl],
                                      e->grads + l.gw, e->grads + l.gb, B, l.cin, l.cout, e->stream);
             }
-            CHK(block_bwd(e, e->decP2[i], e->decP1[i].st.back().a, e->gp[i], &e->d_pres[i], B));
-            CHK(block_bwd(e, e->decP1[i], e->dec_out[i], e->d_pres[i], &e->d_outp[i], B));
+            bool p_ready = false;
+            CHK(block_bwd(e, e->decP2[i], e->decP1[i].st.back().a, e->gp[i], &e->d_pres[i], B, nullptr, &e->decP1[i].st.back(), &p_ready, false, 0.1f));
+            CHK(block_bwd(e, e->decP1[i], e->dec_out[i], e->d_pres[i], &e->d_outp[i], B, nullptr, nullptr, nullptr, p_ready));
             lane2_join(e);
             ew_add3(e->dt, e->d_outp[i].p, e->d_outp[i].ld, e->dzs[i + 1].p, e->dzs[i + 1].ld, d_oq.p, d_oq.ld, e->d_out[i].p, e->d_out[i].ld, (int)M, C, e->stream);
         }
@@ -2272,11 +2279,13 @@ int sgv_test_conv_gn_fwd(const void* A, const void* W, const float* bias, const 
     if (r || se != hipSuccess) return fail(SGV_ERR_HIP, "conv_gn launch failed (%d, %s)", r, hipGetErrorString(se));
     return SGV_OK;
 }
-int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* addend, const void* y, const double* sums, const float* gamma,
+int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const void* addend, const void* premul, void* da, const void* y,
+                         const double* sums, const float* gamma,
                          const float* beta, const float* cbias, void* dy, double* sums2, float* ptot, float* cdot_part, int B, int T,
                          int N, int K, int taps, int G, void* stream) {
     ConvGNBwd q; memset(&q, 0, sizeof(q));
     q.A = A; q.lda = K; q.W = W; q.ldw = K; q.w_tap_stride = (long)N * K; q.scale = scale; q.addend = addend; q.ldadd = N;
+    q.premul = premul; q.ldpre = N; q.da = da; q.ldda = N;
     q.y = y; q.ldy = N; q.sums = sums; q.gamma = gamma; q.beta = beta; q.cbias = cbias; q.dy = dy; q.lddy = N;
     q.sums2 = sums2; q.ptot = ptot; q.cdot_part = cdot_part; q.rscale = 1.f; q.gscale = 1.f;
     q.B = B; q.T = T; q.N = N; q.K = K; q.taps = taps; q.pad = (taps - 1) / 2; q.G = G; q.Cg = G > 0 ? N / G : 0;

@@ -57,11 +57,14 @@ struct ConvGNBwd {
     long w_tap_stride;
     const float* scale;                 // 1/sigma of the upper convolution, or null
     const void* addend; long ldadd;     // optional [B*T][ldadd] bf16 added to the input gradient before it is rounded (residual path)
+    const void* premul; long ldpre;     // optional [B*T][ldpre] bf16 x: the (rounded) input gradient is multiplied by gelu'(x) and rounded
+                                        //   again (the upper convolution reads GELU(x): modules/decoder.py condition blocks)
     const void* y; long ldy;            // pre-norm output of the lower stage [B*T][ldy] bf16
     const double* sums;                 // its forward statistics [B*G][2]
     const float* gamma; const float* beta;
     const float* cbias;                 // bias of the lower convolution (for <G, W_eff>), or null
     void* dy; long lddy;                // out: gradient wrt y [B*T][lddy] bf16
+    void* da; long ldda;                // optional out: the input gradient itself [B*T][ldda] bf16 (a residual block below needs it again)
     double* sums2;                      // out [B*G][2]
     float* ptot;                        // out [B][3][C]: per-sample column totals (sum dz, sum dz*xhat, bias-gradient term)
     float* cdot_part;                   // out [B*G]: partials of <G, W_eff> = sum dY * (y - cbias), or null

@@ -116,7 +116,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_test_gemm_nt256.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.sgv_test_gemm_tn.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sgv_test_conv_gn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]
-    lib.sgv_test_conv_gn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
+    lib.sgv_test_conv_gn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]
     _lib = lib
     return lib
 

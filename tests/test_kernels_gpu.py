@@ -486,6 +486,12 @@ def test_conv_gn_fused_backward(case):
     cnt = T * Cg
     add = _bf16_round((0.3 * rng.standard_normal((B * T, N))).astype(np.float32)) if use_res else None     # residual path of the block above
     dA = _bf16_round(ref_conv_nt(dYup, W, None, 0.83, add, taps, T).astype(np.float32)).astype(np.float64)
+    use_pre = taps == 3                     # the upper convolution reads GELU(x): gradient times gelu'(x), rounded again
+    xpre = _bf16_round(rng.standard_normal((B * T, N)).astype(np.float32)) if use_pre else None
+    if use_pre:
+        xp = xpre.astype(np.float64)
+        gp_ = 0.5 * (1.0 + np.vectorize(math.erf)(xp / math.sqrt(2.0))) + xp * np.exp(-0.5 * xp * xp) / math.sqrt(2.0 * math.pi)
+        dA = _bf16_round((dA * gp_).astype(np.float32)).astype(np.float64)
     yg = y.astype(np.float64).reshape(B, T, G, Cg)
     S = yg.sum(axis=(1, 3)); SS = (yg ** 2).sum(axis=(1, 3))
     mean = S / cnt; var = np.maximum(SS / cnt - mean ** 2, 0.0); rstd = 1.0 / np.sqrt(var + 1e-5)
@@ -503,6 +509,7 @@ def test_conv_gn_fused_backward(case):
     d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
     dA_dev, dW, dy_in = _dev(dYup, 1), _dev(W, 1), _dev(y, 1)
     dadd = _dev(add, 1) if use_res else None
+    dpre = _dev(xpre, 1) if use_pre else None
     sums = d(np.stack([S, SS], axis=-1))
     dg, db, dcb, dsc = d(gamma), d(beta), d(cbias), d(scale)
     outs = []
@@ -511,12 +518,16 @@ def test_conv_gn_fused_backward(case):
         sums2 = torch.full((B, G, 2), float("nan"), dtype=torch.float64, device="cuda")
         ptot = torch.full((B, 3, N), float("nan"), dtype=torch.float32, device="cuda")
         cdot = torch.full((B, G), float("nan"), dtype=torch.float32, device="cuda")
-        rc = lib.sgv_test_conv_gn_bwd(dA_dev.data_ptr(), dW.data_ptr(), dsc.data_ptr(), dadd.data_ptr() if use_res else None, dy_in.data_ptr(), sums.data_ptr(), dg.data_ptr(),
+        da_out = torch.full((B * T, N), float("nan"), dtype=torch.bfloat16, device="cuda")
+        rc = lib.sgv_test_conv_gn_bwd(dA_dev.data_ptr(), dW.data_ptr(), dsc.data_ptr(), dadd.data_ptr() if use_res else None,
+                                      dpre.data_ptr() if use_pre else None, da_out.data_ptr(), dy_in.data_ptr(), sums.data_ptr(), dg.data_ptr(),
                                       db.data_ptr(), dcb.data_ptr(), dy.data_ptr(), sums2.data_ptr(), ptot.data_ptr(), cdot.data_ptr(),
                                       B, T, N, K, taps, G, None)
         assert rc == 0, lib.sgv_last_error()
-        outs.append((dy.float().cpu().numpy(), sums2.cpu().numpy(), ptot.cpu().numpy(), cdot.cpu().numpy()))
-    dyk, s2k, ptk, cdk = outs[0]
+        outs.append((dy.float().cpu().numpy(), sums2.cpu().numpy(), ptot.cpu().numpy(), cdot.cpu().numpy(), da_out.float().cpu().numpy()))
+    dyk, s2k, ptk, cdk, dak = outs[0]
+    # the stored input gradient: one or two bf16 roundings of the exact value
+    assert np.abs(dak - dA).max() <= 2 ** -6 * np.abs(dA).max() and np.mean(np.abs(dak - dA)) <= 1e-3 * np.mean(np.abs(dA))
     for a in outs[0]:
         assert np.isfinite(a).all()
     dyr = dy_ref.reshape(B * T, N)
