@@ -1,17 +1,19 @@
-// Fused small convolution + GroupNorm + GELU (+ residual) forward for gfx950, bf16.
+// Fused small convolution + GroupNorm + GELU (+ residual) stages for gfx950, bf16: the forward kernel described here and its
+// backward mirror (conv_gn_bwd_kernel below: input gradient of the upper convolution + GroupNorm / GELU backward of the stage
+// below it, with the residual addend, the gelu' pre-multiply and the stored input gradient the block graph needs).
 //
 //   y[m][n]   = bf16( scale * sum_{tap,k} x[m + tap - pad][k] * W[tap][n][k] + bias[n] )          (stored: backward reads it)
 //   out[m][n] = [res[m][n] + rscale *] gelu( gamma[n] * (y - mean_bg) * rstd_bg + beta[n] )
 //   sums[b][g] = (sum y, sum y^2) over the T x Cg slab of sample b, group g                        (stored: backward reads it)
 //
 // Reference call sites: every Conv1d -> GroupNorm(8, C) -> GELU of modules/common.py:78-162 (encoder / decoder blocks and
-// residual blocks) and modules/decoder.py:59-117 (condition_z / condition_xz) whose channel count is at most 1024.
+// residual blocks) and modules/decoder.py:59-117 (condition_z / condition_xz) whose channel count is at most 1280.
 //
 // Why: for these layers the step spent three launches -- an implicit-GEMM kernel with split-K (few 128-row tiles exist), its
 // combine pass and the fused GroupNorm kernel -- of 15 + 6 + 9 us, each latency-bound.  One workgroup per (group, sample) owns
 // the whole T x Cg output slab of its normalisation group (T <= 208 rows, Cg <= 160 columns), so the contraction needs no
 // split, the statistics are complete inside the workgroup, and y never has to be re-read: one launch, deterministic (fixed
-// summation order), 128 workgroups of 4 waves.
+// summation order), 128 workgroups of 8 waves.
 //
 // Structure: K in chunks of 32; a chunk of the sample's rows (with `pad` halo rows of zeros above and below: the workgroup is
 // exactly one sample, so the tap window test is a zero row) and of the group's weight rows for every tap goes HBM/L2 -> LDS by
@@ -19,7 +21,7 @@
 // ds_read_b128 fragments); a tap is a row offset into the SAME LDS chunk, so the activations are fetched once for all taps.
 // Eight waves, two per SIMD: wave w owns row tiles w and w + 8 (16 rows each) times all Cg/16 column tiles of
 // v_mfma_f32_16x16x32_bf16; the fragments of tap t + 1 are read while tap t is multiplied (two register sets, counted lgkmcnt);
-// the MFMA takes with the weight fragment as the first operand (a lane ends with four consecutive channels of one row).
+// the MFMA takes the weight fragment as its first operand (a lane ends with four consecutive channels of one row).
 #include "sgv_common.h"
 #include "sgv_ew.h"
 
