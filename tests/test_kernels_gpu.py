@@ -307,6 +307,8 @@ TN_W2_CASES = [
     (990, 128, 256, 5, 33, 2),        # Tlen = 33: the boundary walks through every row of the stage
     (1360, 200, 512, 3, 34, 1),
     (288, 64, 256, 5, 48, 1),         # 9 stages
+    (400, 128, 95008, 1, 200, 1),     # the first encoder layer's width on the input side (95008 = 371 * 256 + 32)
+    (400, 95008, 256, 1, 200, 1),     # the recon head's width on the output side (95008 = 742 * 128 + 32)
 ]
 
 
