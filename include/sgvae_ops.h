@@ -26,6 +26,15 @@ int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, in
  * (K, N multiples of 8; scale/bias/addend may be NULL; out_f32 = 1 writes fp32 instead of the compute dtype). */
 int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend,
                    int M, int N, int K, int out_f32, void* stream);
+/* The same convolution as an implicit GEMM (no im2col matrix; bf16 or fp32, Cin and N multiples of 8, KH*KW <= 31):
+ *   y[b][oh][ow][n] = scale[0] * sum_{kh,kw,c} x[b][oh*stride - pad + kh][ow*stride - pad + kw][c] * Wt(kh*KW + kw)[n][c]
+ * with x [B][H][W][Cin] and y [B][Ho][Wo][N] channels-last, Ho = (H + 2 pad - KH)/stride + 1 (pixels outside the image are
+ * zero), and tap t's [N][Cin] weight matrix at W + t*w_tap_stride with row pitch ldw (elements; flip = 1: at
+ * W + (KH*KW-1-t)*w_tap_stride).  Forward on the packed [Cout][KH][KW][Cin] weights: ldw = KH*KW*Cin, w_tap_stride = Cin.
+ * Input gradient of a stride-1 convolution (model_cnn.py conv2 of the stride-1 blocks): x = dY, N = Cin, the transposed
+ * weights [(kh,kw,ci)][Cout] with ldw = Cout, w_tap_stride = Cin*Cout, flip = 1, pad = KH-1-pad. */
+int sgv_op_conv2d_nt(int dtype, const void* x, const void* W, void* y, const float* scale, int B, int H, int Wd, int Cin, int N,
+                     int KH, int KW, int stride, int pad, long ldw, long w_tap_stride, int flip, void* stream);
 /* dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]  (N1, N2 multiples of 8).  The reduction runs over M = B*H*W rows:
  * sgv_op_gemm_tn_splitk() returns the number of row slices to use, the caller passes that many N1*N2 fp32 slabs
  * (slabs may be NULL when splitk == 1). */

@@ -1056,6 +1056,27 @@ int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float
     if (r) return sgv_set_error(-1, "sgv_op_gemm_nt: launch rejected (%d) for M=%d N=%d K=%d", r, M, N, K);
     return 0;
 }
+// Implicit-GEMM 2-D convolution on a channels-last batch (no im2col matrix): see include/sgvae_ops.h.
+int sgv_op_conv2d_nt(int dtype, const void* x, const void* W, void* y, const float* scale, int B, int H, int Wd, int Cin, int N,
+                     int KH, int KW, int stride, int pad, long ldw, long w_tap_stride, int flip, void* stream) {
+    OPCHK(x && W && y && B > 0 && H > 0 && Wd > 0 && Cin > 0 && N > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+          "sgv_op_conv2d_nt: bad argument");
+    OPCHK(Cin % 8 == 0 && N % 8 == 0 && ldw % 8 == 0 && w_tap_stride % 8 == 0,
+          "sgv_op_conv2d_nt: channels, ldw and the tap stride must be multiples of 8 (got Cin=%d N=%d ldw=%ld tap stride=%ld)", Cin, N, ldw, w_tap_stride);
+    OPCHK(KH * KW <= 31, "sgv_op_conv2d_nt: at most 31 taps (got %dx%d)", KH, KW);
+    OPCHK(H + 2 * pad >= KH && Wd + 2 * pad >= KW, "sgv_op_conv2d_nt: window larger than the padded image");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    OPCHK((long)B * Ho * Wo < 0x7FFFFFFFL, "sgv_op_conv2d_nt: too many output pixels");
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = x; p.lda = Cin; p.W = W; p.ldw = ldw; p.w_tap_stride = w_tap_stride; p.C = y; p.ldc = N; p.scale = scale;
+    p.M = B * Ho * Wo; p.N = N; p.K = Cin; p.taps = KH * KW; p.pad = 0; p.Tlen = p.M; p.splitk = 1;
+    p.a_rows = (long)B * H * Wd;
+    p.cv_kw = KW; p.cv_H = H; p.cv_W = Wd; p.cv_S = stride; p.cv_P = pad; p.cv_Ho = Ho; p.cv_Wo = Wo; p.cv_flip = flip ? 1 : 0;
+    const GemmPlan pl = gemm_nt_plan(dtype, p, 0, 0);
+    const int r = launch_gemm_nt_planned(dtype, p, pl, ST(stream));
+    if (r) return sgv_set_error(-1, "sgv_op_conv2d_nt: launch rejected (%d) for B=%d H=%d W=%d Cin=%d N=%d %dx%d/%d", r, B, H, Wd, Cin, N, KH, KW, stride);
+    return 0;
+}
 // dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]; N1, N2 multiples of 8.  The reduction runs over the M = B*H*W rows, up to
 // a million of them for a handful of output tiles: sgv_op_gemm_tn_splitk() says how many row slices to use and the caller
 // provides splitk * N1 * N2 floats of slab workspace (deterministic: plain stores + one sum pass).

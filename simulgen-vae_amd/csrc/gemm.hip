@@ -57,7 +57,8 @@ __device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t off)
 // =========================================================================================
 // NT
 // =========================================================================================
-template <typename T, int KCH>
+// C2D: 2-D taps (GemmNT::cv_*): rows are output pixels of a channels-last image batch, a tap is a (kh, kw) window offset
+template <typename T, int KCH, bool C2D = false>
 __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = KCH * EPC;
@@ -95,9 +96,34 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     const int wn0 = n0 + r0, wn1 = n0 + r0 + RSTEP;
     const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
     const bool wok0 = wn0 < p.N, wok1 = wn1 < p.N;
-    const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
     constexpr int ESZ = (int)sizeof(T);
-    const uint32_t abase0 = (uint32_t)(((long)am0 * p.lda + kq * EPC) * ESZ), abase1 = (uint32_t)(((long)am1 * p.lda + kq * EPC) * ESZ);
+    // per-tap validity of this thread's two activation rows as bit masks (taps <= 31)
+    uint32_t am0_mask = 0u, am1_mask = 0u;
+    uint32_t abase0, abase1;
+    if constexpr (C2D) {
+        // row -> (b, oh, ow); the base is the window's top-left input pixel (it may lie outside the image: the offset then
+        // wraps modulo 2^32 and only the taps whose pixel is inside -- where the sum is the true offset -- are loaded)
+        const int hw = p.cv_Ho * p.cv_Wo;
+        const int b0_ = am0 / hw, q0_ = am0 - b0_ * hw, b1_ = am1 / hw, q1_ = am1 - b1_ * hw;
+        const int oh0 = q0_ / p.cv_Wo, oh1 = q1_ / p.cv_Wo;
+        const int ih0 = oh0 * p.cv_S - p.cv_P, iw0 = (q0_ - oh0 * p.cv_Wo) * p.cv_S - p.cv_P;
+        const int ih1 = oh1 * p.cv_S - p.cv_P, iw1 = (q1_ - oh1 * p.cv_Wo) * p.cv_S - p.cv_P;
+        abase0 = (uint32_t)(((((long)b0_ * p.cv_H + ih0) * p.cv_W + iw0) * p.lda + kq * EPC) * ESZ);
+        abase1 = (uint32_t)(((((long)b1_ * p.cv_H + ih1) * p.cv_W + iw1) * p.lda + kq * EPC) * ESZ);
+        for (int j = 0, kh = 0, kw = 0; j < p.taps; ++j) {
+            if (aok0 && (unsigned)(ih0 + kh) < (unsigned)p.cv_H && (unsigned)(iw0 + kw) < (unsigned)p.cv_W) am0_mask |= 1u << j;
+            if (aok1 && (unsigned)(ih1 + kh) < (unsigned)p.cv_H && (unsigned)(iw1 + kw) < (unsigned)p.cv_W) am1_mask |= 1u << j;
+            if (++kw == p.cv_kw) { kw = 0; ++kh; }
+        }
+    } else {
+        const int at0 = am0 % p.Tlen, at1 = am1 % p.Tlen;
+        abase0 = (uint32_t)(((long)am0 * p.lda + kq * EPC) * ESZ);
+        abase1 = (uint32_t)(((long)am1 * p.lda + kq * EPC) * ESZ);
+        for (int j = 0; j < p.taps; ++j) {
+            if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
+            if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
+        }
+    }
     const uint32_t wbase0 = wok0 ? (uint32_t)(((long)wn0 * p.ldw + kq * EPC) * ESZ) : OOB_OFF;
     const uint32_t wbase1 = wok1 ? (uint32_t)(((long)wn1 * p.ldw + kq * EPC) * ESZ) : OOB_OFF;
     // two register sets (A, B): loads for tile s+2 are issued while tile s is multiplied and tile s+1 is
@@ -109,20 +135,27 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     // arithmetic alone cost ~40 % of the kernel time.
     const int lda_b = (int)(p.lda * ESZ), wts_b = (int)(p.w_tap_stride * ESZ);
     int ld_j = 0, ld_kcb = 0, ld_aoff = 0, ld_woff = 0;     // state of the NEXT tile to load
+    int ld_jw = 0;                                           // C2D: kw of tap ld_j
+    // C2D: a tap step moves one pixel right, a kernel-row wrap moves to the next image row; the weights advance by
+    // +- one tap (cv_flip walks them backwards from the last tap)
+    const int a0_b = C2D ? 0 : -p.pad * lda_b;
+    const int rowskip_b = C2D ? (p.cv_W - p.cv_kw) * lda_b : 0;
+    const int wstep_b = (C2D && p.cv_flip) ? -wts_b : wts_b;
+    const int w0_b = (C2D && p.cv_flip) ? (p.taps - 1) * wts_b : 0;
     {
         const int kci0 = s_begin / p.taps;
         ld_j = s_begin - kci0 * p.taps;
         ld_kcb = kci0 * BK * ESZ;
-        ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
-        ld_woff = ld_j * wts_b + ld_kcb;
+        if constexpr (C2D) {
+            const int kh0 = ld_j / p.cv_kw;
+            ld_jw = ld_j - kh0 * p.cv_kw;
+            ld_aoff = (kh0 * p.cv_W + ld_jw) * lda_b + ld_kcb;
+        } else {
+            ld_aoff = (ld_j - p.pad) * lda_b + ld_kcb;
+        }
+        ld_woff = w0_b + ld_j * wstep_b + ld_kcb;
     }
     const int klim_b = (p.K - kq * EPC) * ESZ;               // chunk valid iff ld_kcb < klim_b
-    // per-tap validity of this thread's two activation rows as bit masks (taps <= 31)
-    uint32_t am0_mask = 0u, am1_mask = 0u;
-    for (int j = 0; j < p.taps; ++j) {
-        if (aok0 && (unsigned)(at0 + j - p.pad) < (unsigned)p.Tlen) am0_mask |= 1u << j;
-        if (aok1 && (unsigned)(at1 + j - p.pad) < (unsigned)p.Tlen) am1_mask |= 1u << j;
-    }
 #define SGV_NT_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
         const bool kok_ = ld_kcb < klim_b;                                                                    \
@@ -132,8 +165,9 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
         ra1##X = bload16(rsA, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF);                                    \
         rw0##X = bload16(rsW, kok_ ? wbase0 + (uint32_t)ld_woff : OOB_OFF);                                   \
         rw1##X = bload16(rsW, kok_ ? wbase1 + (uint32_t)ld_woff : OOB_OFF);                                   \
-        ++ld_j; ld_aoff += lda_b; ld_woff += wts_b;                                                           \
-        if (ld_j == p.taps) { ld_j = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb - p.pad * lda_b; ld_woff = ld_kcb; } \
+        ++ld_j; ld_aoff += lda_b; ld_woff += wstep_b;                                                         \
+        if constexpr (C2D) { if (++ld_jw == p.cv_kw) { ld_jw = 0; ld_aoff += rowskip_b; } }                   \
+        if (ld_j == p.taps) { ld_j = 0; ld_jw = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb + a0_b; ld_woff = ld_kcb + w0_b; } \
     }
 #define SGV_NT_ST1(PTR, V)                                                                                    \
     if constexpr (IS_BF16) { *reinterpret_cast<uint4*>(PTR) = (V); }                                          \
@@ -1208,7 +1242,15 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;   // 32-bit buffer offsets
     if (p.row0 < 0 || p.row0 >= p.M || (p.row0 && p.gn_sums)) return -1;
     const int Mr = p.M - p.row0;                                           // rows this launch computes
-    if (p.vendor && !p.row0 && gemm_nt_vendor_eligible(dtype, p)) {
+    const bool c2d = p.cv_kw > 0;
+    if (c2d) {
+        if (p.taps > 31 || p.taps % p.cv_kw || p.cv_S < 1 || p.cv_P < 0 || p.cv_H < 1 || p.cv_W < 1 || p.cv_Ho < 1 || p.cv_Wo < 1) return -1;
+        if (p.M % (p.cv_Ho * p.cv_Wo) || p.a_rows != (long)(p.M / (p.cv_Ho * p.cv_Wo)) * p.cv_H * p.cv_W) return -1;
+        // every output pixel's window may start outside the image but must not reach past it by more than the padding
+        if ((p.cv_Ho - 1) * p.cv_S - p.cv_P >= p.cv_H || (p.cv_Wo - 1) * p.cv_S - p.cv_P >= p.cv_W) return -1;
+        if (p.gn_sums || p.row0) return -1;
+    }
+    if (!c2d && p.vendor && !p.row0 && gemm_nt_vendor_eligible(dtype, p)) {
         const int vr = launch_gemm_nt_vendor(p, s);
         if (vr <= 0) {
             if (main_done) hipEventRecord(main_done, s);
@@ -1219,7 +1261,11 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (p.gn_sums && (dtype != 1 || gemm_nt_is_wide(dtype, p.N, total_steps) || p.splitk != 1 || p.out_f32 || p.Tlen < 128 ||
                       p.gn_Cg < 128 || p.gn_G < 1))
         return -1;                                   // only the bf16 128x128 epilogue accumulates statistics
-    if (gemm_nt_is_wide(dtype, p.N, total_steps)) {
+    if (c2d) {
+        dim3 grid(cdiv(Mr, 128) * cdiv(p.N, 128) * p.splitk);
+        if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4, true>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_kernel<float, 4, true>), grid, dim3(256), 0, s, q);
+    } else if (gemm_nt_is_wide(dtype, p.N, total_steps)) {
         dim3 grid(cdiv(Mr, 128) * cdiv(p.N, 256) * p.splitk);
         hipLaunchKernelGGL(gemm_nt_wide64p_kernel, grid, dim3(256), 0, s, q);
     } else {

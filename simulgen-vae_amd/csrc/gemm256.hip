@@ -70,7 +70,8 @@ __device__ __forceinline__ float t256_hi(uint32_t v) { return __builtin_bit_cast
 
 // OUT: 0 = bf16 output (scale, bias, addend, optional statistics), 1 = fp32 (split-K slab: raw sums; or final fp32 output)
 // MT:  the layer has more than one tap (per-row tap windows are tested when a DMA is issued)
-template <int OUT, bool MT>
+// C2D: 2-D taps (GemmNT::cv_*, needs MT): rows are output pixels of a channels-last image batch, tap = (kh, kw)
+template <int OUT, bool MT, bool C2D = false>
 __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     constexpr int ESZ = 2;
     constexpr int NST = (OUT == 0 ? 16 : 32) + 1;     // buffer stores per wave and epilogue + the next item's bias load
@@ -99,8 +100,12 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // the A descriptor starts `pad` rows BEFORE the buffer: per-lane offsets (row * lda) stay non-negative and the uniform part
     // (tap * lda + k) goes to the instruction's scalar offset.  Lanes whose tap leaves the sample window get an offset beyond
     // the extent (hardware zero-fill), so nothing in front of the buffer is ever read.
+    // (C2D: the shift is cv_P image rows + cv_P pixels, a lane's row is the pixel (b, oh*S, ow*S), the uniform part (kh, kw).)
+    const long a_shift = C2D ? ((long)p.cv_P * p.cv_W + p.cv_P) * lda_b : (long)p.pad * lda_b;
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<char*>(reinterpret_cast<const char*>(p.A)) - (long)p.pad * lda_b, 0, (int)(p.a_bytes + (long)p.pad * lda_b), 0x00020000);
+        const_cast<char*>(reinterpret_cast<const char*>(p.A)) - a_shift, 0, (int)(p.a_bytes + a_shift), 0x00020000);
+    const int wstep_b = (C2D && p.cv_flip) ? -wts_b : wts_b;            // cv_flip: tap j multiplies W[taps - 1 - j]
+    const int w0_b = (C2D && p.cv_flip) ? (p.taps - 1) * wts_b : 0;
     const __amdgpu_buffer_rsrc_t rsW = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.W), 0, (int)p.w_bytes, 0x00020000);
     const float sc = p.scale ? *p.scale : 1.0f;
 
@@ -125,6 +130,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     int li = it_lo + jb;                   // item being loaded
     int l_kt = 0, l_kt_end = 0;            // K-tile of item li the cursor points at / end of its slice
     int ld_j = 0, ld_kcb = 0;              // its tap and channel-chunk byte offset
+    int ld_jh = 0, ld_jw = 0;              // C2D: (kh, kw) of tap ld_j
     int sA = 0, sW = 0;                    // scalar offsets: tap * lda + k / tap * tap_stride + k (bytes)
     bool l_active = true;
 
@@ -137,6 +143,21 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
             if ((unsigned)(at_ + j_ - p.pad) >= (unsigned)p.Tlen) mk_ |= 1u << j_;                            \
         DST = mk_;                                                                                            \
     }
+    // C2D: offset of the row's pixel (b, oh*S, ow*S) and the taps whose pixel leaves the image (all of them for rows >= M)
+#define T256_ROW2D(V, IM, AM, DC)                                                                             \
+    {                                                                                                         \
+        const int hw_ = p.cv_Ho * p.cv_Wo;                                                                    \
+        const int b_ = (AM) / hw_, q_ = (AM) - b_ * hw_;                                                      \
+        const int oh_ = q_ / p.cv_Wo, ow_ = q_ - oh_ * p.cv_Wo;                                               \
+        const int ih_ = oh_ * p.cv_S - p.cv_P, iw_ = ow_ * p.cv_S - p.cv_P;                                   \
+        V = (uint32_t)((((long)b_ * p.cv_H + oh_ * p.cv_S) * p.cv_W + ow_ * p.cv_S) * lda_b + (DC) * 16);     \
+        uint32_t mk_ = 0u;                                                                                    \
+        for (int j_ = 0, kh_ = 0, kw_ = 0; j_ < p.taps; ++j_) {                                               \
+            if ((AM) >= p.M || (unsigned)(ih_ + kh_) >= (unsigned)p.cv_H || (unsigned)(iw_ + kw_) >= (unsigned)p.cv_W) mk_ |= 1u << j_; \
+            if (++kw_ == p.cv_kw) { kw_ = 0; ++kh_; }                                                         \
+        }                                                                                                     \
+        IM = mk_;                                                                                             \
+    }
 #define T256_SETUP_ITEM()                                                                                     \
     {                                                                                                         \
         const int z_ = T256_UNI(li / ntile);                                                                  \
@@ -148,13 +169,20 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
         const int kci_ = T256_UNI(l_kt / p.taps);                                                             \
         ld_j = l_kt - kci_ * p.taps;                                                                          \
         ld_kcb = kci_ * 128;                                                                                  \
-        sA = ld_j * lda_b + ld_kcb; sW = ld_j * wts_b + ld_kcb;                                               \
         const int ar_ = m0_ + a_row0 + rl;                                                                    \
-        vA0 = (uint32_t)((long)ar_ * lda_b + dc0 * 16);                                                       \
-        vA1 = (uint32_t)((long)(ar_ + 8) * lda_b + dc1 * 16);                                                 \
-        vA2 = (uint32_t)((long)(ar_ + 64) * lda_b + dc0 * 16);                                                \
-        vA3 = (uint32_t)((long)(ar_ + 72) * lda_b + dc1 * 16);                                                \
-        if (MT) { T256_ROWMASK(imA0, ar_) T256_ROWMASK(imA1, ar_ + 8) T256_ROWMASK(imA2, ar_ + 64) T256_ROWMASK(imA3, ar_ + 72) } \
+        if constexpr (C2D) {                                                                                  \
+            ld_jh = T256_UNI(ld_j / p.cv_kw); ld_jw = ld_j - ld_jh * p.cv_kw;                                 \
+            sA = (ld_jh * p.cv_W + ld_jw) * lda_b + ld_kcb; sW = w0_b + ld_j * wstep_b + ld_kcb;              \
+            T256_ROW2D(vA0, imA0, ar_, dc0) T256_ROW2D(vA1, imA1, ar_ + 8, dc1)                               \
+            T256_ROW2D(vA2, imA2, ar_ + 64, dc0) T256_ROW2D(vA3, imA3, ar_ + 72, dc1)                         \
+        } else {                                                                                              \
+            sA = ld_j * lda_b + ld_kcb; sW = ld_j * wts_b + ld_kcb;                                           \
+            vA0 = (uint32_t)((long)ar_ * lda_b + dc0 * 16);                                                   \
+            vA1 = (uint32_t)((long)(ar_ + 8) * lda_b + dc1 * 16);                                             \
+            vA2 = (uint32_t)((long)(ar_ + 64) * lda_b + dc0 * 16);                                            \
+            vA3 = (uint32_t)((long)(ar_ + 72) * lda_b + dc1 * 16);                                            \
+            if (MT) { T256_ROWMASK(imA0, ar_) T256_ROWMASK(imA1, ar_ + 8) T256_ROWMASK(imA2, ar_ + 64) T256_ROWMASK(imA3, ar_ + 72) } \
+        }                                                                                                     \
         const int wr_ = n0_ + w_row0 + rl;                                                                    \
         vW0 = wr_ < p.N ? (uint32_t)((long)wr_ * ldw_b + dc0 * 16) : 0x80000000u;                             \
         vW1 = wr_ + 8 < p.N ? (uint32_t)((long)(wr_ + 8) * ldw_b + dc1 * 16) : 0x80000000u;                   \
@@ -198,8 +226,14 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
         ++l_kt;                                                                                               \
         if ((F) || l_kt < l_kt_end) {                                                                         \
             ++ld_j;                                                                                           \
-            if (ld_j == p.taps) { ld_j = 0; ld_kcb += 128; }                                                  \
-            sA = ld_j * lda_b + ld_kcb; sW = ld_j * wts_b + ld_kcb;                                           \
+            if constexpr (C2D) {                                                                              \
+                if (++ld_jw == p.cv_kw) { ld_jw = 0; ++ld_jh; }                                               \
+                if (ld_j == p.taps) { ld_j = 0; ld_jh = 0; ld_jw = 0; ld_kcb += 128; }                        \
+                sA = (ld_jh * p.cv_W + ld_jw) * lda_b + ld_kcb; sW = w0_b + ld_j * wstep_b + ld_kcb;          \
+            } else {                                                                                          \
+                if (ld_j == p.taps) { ld_j = 0; ld_kcb += 128; }                                              \
+                sA = ld_j * lda_b + ld_kcb; sW = ld_j * wts_b + ld_kcb;                                       \
+            }                                                                                                 \
         } else {                                                                                              \
             li += nbx;                                                                                        \
             if (li < it_hi) T256_SETUP_ITEM() else l_active = false;                                          \
@@ -681,7 +715,13 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
     int grid = ((nitems + 7) / 8) * 8;
     if (grid > 256) grid = 256;
     const bool f32 = p.splitk > 1 || p.out_f32;
-    if (p.taps > 1) {
+    if (p.cv_kw > 0) {
+        if (p.taps % p.cv_kw || p.cv_S < 1 || p.cv_P < 0 || p.cv_H < 1 || p.cv_W < 1 || p.cv_Ho < 1 || p.cv_Wo < 1) return -1;
+        if (p.M % (p.cv_Ho * p.cv_Wo) || p.a_rows != (long)(p.M / (p.cv_Ho * p.cv_Wo)) * p.cv_H * p.cv_W) return -1;
+        if (p.gn_part || p.row0) return -1;
+        if (f32) hipLaunchKernelGGL((gemm_nt_t256_kernel<1, true, true>), dim3(grid), dim3(512), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_t256_kernel<0, true, true>), dim3(grid), dim3(512), 0, s, q);
+    } else if (p.taps > 1) {
         if (f32) hipLaunchKernelGGL((gemm_nt_t256_kernel<1, true>), dim3(grid), dim3(512), 0, s, q);
         else hipLaunchKernelGGL((gemm_nt_t256_kernel<0, true>), dim3(grid), dim3(512), 0, s, q);
     } else {
@@ -739,7 +779,7 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
     if (stats_ok) { pl.kind = 1; pl.sk_main = 1; pl.fuse_stats = 1; return pl; }
     const int rem = p.M & 255;
     int sk_main = 1, sk_tail = 1;
-    if (rem > 0 && rem <= 128 && p.M - rem >= 256) {
+    if (rem > 0 && rem <= 128 && p.M - rem >= 256 && !p.cv_kw) {
         sk_main = t256_best_sk(p.M - rem, p.N, total_kt, partial_floats, &c_main);
         sk_tail = gemm_nt_pick_splitk(rem, p.N, p.K, p.taps, dtype);
         if ((size_t)sk_tail * rem * p.N > partial_floats) sk_tail = 1;

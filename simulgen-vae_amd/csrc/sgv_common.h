@@ -151,6 +151,12 @@ struct GemmNT {
     long a_rows;                    // rows of the A buffer that may be read (>= M; 0: M) -- lets a launch cover rows [0, M) of a
                                     // longer batch whose taps reach into the rows after M (launch_gemm_nt256 main + tail split)
     int row0;                       // first row this launch computes (128x128 / 128x256 kernels; tiles start at row0)
+    // 2-D taps (cv_kw > 0; the latent conditioner's convolutions as implicit GEMMs): A is a channels-last image batch
+    // [B][cv_H][cv_W][lda], row m = (b, oh, ow) of a [B][cv_Ho][cv_Wo] output, tap j = (kh, kw) = (j / cv_kw, j % cv_kw) reads
+    // A[b][oh*cv_S - cv_P + kh][ow*cv_S - cv_P + kw][k] (zero outside the image); taps = KH * cv_kw; pad / Tlen are not used
+    // and a_rows must be B*cv_H*cv_W.  cv_flip: tap j multiplies W[taps-1-j] (the input gradient of a stride-1 convolution
+    // is the convolution of dY with the taps reversed).  128x128 bf16/fp32 kernel and the 256x256 kernel only.
+    int cv_kw, cv_H, cv_W, cv_S, cv_P, cv_Ho, cv_Wo, cv_flip;
 };
 // gemm256.hip
 bool gemm_nt256_eligible(int dtype, const GemmNT& p);

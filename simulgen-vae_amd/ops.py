@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -37,6 +37,7 @@ def lib():
             "sgv_op_im2col": [i, vp, vp] + [i] * 8 + [vp],
             "sgv_op_col2im": [i, vp, vp] + [i] * 8 + [vp],
             "sgv_op_gemm_nt": [i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_conv2d_nt": [i, vp, vp, vp, vp] + [i] * 9 + [C.c_long, C.c_long, i, vp],
             "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp, i, vp],
             "sgv_op_gemm_tn_splitk": [i, i, i, i],
             "sgv_op_matvec_t": [vp, vp, vp, i, i, vp],
@@ -159,6 +160,18 @@ def gemm_nt(A, W, bias=None, scale=None, addend=None, out_f32=False):
     out = torch.empty((M, N), dtype=torch.float32 if out_f32 else A.dtype, device=A.device)
     _timed("gemm_nt", 2.0 * M * N * K, lambda: _ck(lib().sgv_op_gemm_nt(_d(A), _p(A), _p(W), _p(out), _p(bias), _p(scale), _p(addend), M, N, K,
                                                                          int(out_f32), _stream()), "sgv_op_gemm_nt"))
+    return out
+
+
+def conv2d_nt(x, W, N, KH, KW, stride, pad, ldw, w_tap_stride, flip=False, scale=None):
+    """Implicit-GEMM convolution of a channels-last batch x [B, H, W, Cin] (include/sgvae_ops.h: sgv_op_conv2d_nt): tap t's
+    [N, Cin] weight matrix lies at W + t*w_tap_stride (elements) with row pitch ldw.  -> [B, Ho, Wo, N]."""
+    B, H, Wd, Cin = x.shape
+    Ho, Wo = (H + 2 * pad - KH) // stride + 1, (Wd + 2 * pad - KW) // stride + 1
+    out = torch.empty((B, Ho, Wo, N), dtype=x.dtype, device=x.device)
+    _timed("gemm_nt", 2.0 * B * Ho * Wo * N * Cin * KH * KW,
+           lambda: _ck(lib().sgv_op_conv2d_nt(_d(x), _p(x), _p(W), _p(out), _p(scale), B, H, Wd, Cin, N, KH, KW, stride, pad, ldw, w_tap_stride,
+                                              int(bool(flip)), _stream()), "sgv_op_conv2d_nt"))
     return out
 
 

@@ -64,6 +64,40 @@ def test_conv2d_via_im2col(dt, cfg):
     assert rel(nchw(dx), x.grad) < TOL[dt]
 
 
+# (B, Cin, Cout, H, W, k, stride, pad): small-channel 128x128-tile cases, ragged images, stride 2, a 1x1 stride-2 gather, a 5x5
+# window, and two shapes the planner hands to the 256x256 persistent kernel (one with ragged rows and a K tail)
+IMPLICIT_CASES = [(2, 16, 16, 20, 24, 3, 1, 1), (3, 64, 64, 16, 16, 3, 1, 1), (2, 32, 48, 17, 22, 3, 2, 1), (3, 24, 40, 9, 11, 1, 2, 0),
+                  (2, 8, 16, 13, 10, 5, 1, 2), (1, 128, 136, 33, 31, 3, 1, 1), (4, 256, 1024, 64, 64, 3, 1, 1), (3, 200, 1024, 50, 70, 3, 1, 1),
+                  (8, 256, 1024, 64, 64, 3, 2, 1)]
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", IMPLICIT_CASES)
+def test_conv2d_implicit_gemm(dt, cfg):
+    """sgv_op_conv2d_nt: forward on the packed weights (any stride) and, for stride 1, the input gradient as the convolution
+    of dY with the reversed taps of the transposed weights -- against F.conv2d and its autograd in fp32 on the CPU."""
+    B, Ci, Co, H, W, k, s, p = cfg
+    if dt == torch.float32 and Co >= 1024:
+        pytest.skip("the large shapes exercise the bf16 256x256 kernel")
+    g = torch.Generator().manual_seed(7)
+    x = q(torch.randn(B, Ci, H, W, generator=g), dt).requires_grad_()
+    w = q(torch.randn(Co, Ci, k, k, generator=g) * 0.1, dt).requires_grad_()
+    y = F.conv2d(x, w, None, s, p)
+    dy = q(torch.randn(y.shape, generator=g), dt)
+    y.backward(dy)
+    xd = nhwc(x.detach(), dt)
+    wp = w.detach().permute(0, 2, 3, 1).reshape(Co, -1).contiguous().to(device="cuda", dtype=dt)      # [Cout][(kh,kw,ci)]
+    scale = torch.tensor([0.5], device="cuda")
+    out = ops.conv2d_nt(xd, wp, Co, k, k, s, p, k * k * Ci, Ci, scale=scale)
+    assert tuple(out.shape) == (B, y.shape[2], y.shape[3], Co)
+    assert rel(nchw(out), 0.5 * y) < TOL[dt]
+    if s == 1:
+        wt = wp.t().contiguous()                                                                       # [(kh,kw,ci)][Cout]
+        dx = ops.conv2d_nt(nhwc(dy, dt), wt, Ci, k, k, 1, k - 1 - p, Co, Ci * Co, flip=True)
+        assert tuple(dx.shape) == tuple(xd.shape)
+        assert rel(nchw(dx), x.grad) < TOL[dt]
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(2, 32, 32, 36, 3), (3, 64, 32, 25, 0), (2, 256, 32, 16, 3), (2, 48, 16, 300, 0)])
 def test_groupnorm_relu(dt, cfg):
