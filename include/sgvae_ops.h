@@ -39,6 +39,12 @@ int sgv_op_conv2d_nt(int dtype, const void* x, const void* W, void* y, const flo
  * sgv_op_gemm_tn_splitk() returns the number of row slices to use, the caller passes that many N1*N2 fp32 slabs
  * (slabs may be NULL when splitk == 1). */
 int sgv_op_gemm_tn_splitk(int dtype, int M, int N1, int N2);
+/* Weight gradient of the convolution without the im2col matrix (the X operand of the TN GEMM is addressed through the
+ * window geometry): dW[n1][(kh*KW + kw)*Cin + c] (fp32) = sum_{b,oh,ow} dy[b][oh][ow][n1] * x[b][oh*stride - pad + kh][ow*stride - pad + kw][c];
+ * dy [B][Ho][Wo][N1], x [B][H][W][Cin] channels-last, Cin and N1 multiples of 8; splitk / slabs as for sgv_op_gemm_tn with
+ * M = B*Ho*Wo, N2 = KH*KW*Cin. */
+int sgv_op_conv2d_tn(int dtype, const void* dy, const void* x, float* dW, int B, int H, int Wd, int Cin, int N1, int KH, int KW,
+                     int stride, int pad, float* slabs, int splitk, void* stream);
 int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, float* slabs, int splitk, void* stream);
 
 /* nn.GroupNorm + optional ReLU (model_cnn.py:94,98,104,187-188; act: 0 none, 3 relu) on [B][P][C], C % 8 == 0,

@@ -1119,6 +1119,29 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
         hipLaunchKernelGGL(op_sum_slabs_kernel, grid1((long)N1 * N2 * 4), dim3(256), 0, ST(stream), dW, slabs, p.splitk, (long)N1 * N2);
     return OPLAUNCH_OK();
 }
+// Weight gradient of a 2-D convolution without the im2col matrix: see include/sgvae_ops.h.
+int sgv_op_conv2d_tn(int dtype, const void* dy, const void* x, float* dW, int B, int H, int Wd, int Cin, int N1, int KH, int KW,
+                     int stride, int pad, float* slabs, int splitk, void* stream) {
+    OPCHK(dy && x && dW && B > 0 && H > 0 && Wd > 0 && Cin > 0 && N1 > 0 && KH > 0 && KW > 0 && stride > 0 && pad >= 0,
+          "sgv_op_conv2d_tn: bad argument");
+    OPCHK(Cin % 8 == 0 && N1 % 8 == 0, "sgv_op_conv2d_tn: channels must be multiples of 8 (got Cin=%d Cout=%d)", Cin, N1);
+    OPCHK(H + 2 * pad >= KH && Wd + 2 * pad >= KW, "sgv_op_conv2d_tn: window larger than the padded image");
+    OPCHK(splitk <= 1 || slabs, "sgv_op_conv2d_tn: split-K needs a slab workspace");
+    const int Ho = (H + 2 * pad - KH) / stride + 1, Wo = (Wd + 2 * pad - KW) / stride + 1;
+    OPCHK((long)B * Ho * Wo < 0x7FFFFFFFL, "sgv_op_conv2d_tn: too many output pixels");
+    const int N2 = KH * KW * Cin;
+    GemmTN p; memset(&p, 0, sizeof(p));
+    p.A = dy; p.lda = N1; p.B = x; p.ldb = Cin; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
+    p.M = B * Ho * Wo; p.N1 = N1; p.N2 = N2; p.taps = 1; p.pad = 0; p.Tlen = p.M; p.use_tr = 1;
+    p.splitk = splitk < 1 ? 1 : splitk;
+    p.out = p.splitk > 1 ? slabs : dW; p.out_slab_stride = (long)N1 * N2;
+    p.cv_kw = KW; p.cv_H = H; p.cv_W = Wd; p.cv_S = stride; p.cv_P = pad; p.cv_Ho = Ho; p.cv_Wo = Wo; p.cv_C = Cin;
+    const int r = launch_gemm_tn(dtype, p, ST(stream));
+    if (r) return sgv_set_error(-1, "sgv_op_conv2d_tn: launch rejected (%d) for B=%d H=%d W=%d Cin=%d Cout=%d %dx%d/%d", r, B, H, Wd, Cin, N1, KH, KW, stride);
+    if (p.splitk > 1)
+        hipLaunchKernelGGL(op_sum_slabs_kernel, grid1((long)N1 * N2 * 4), dim3(256), 0, ST(stream), dW, slabs, p.splitk, (long)N1 * N2);
+    return OPLAUNCH_OK();
+}
 // dst_k[0..count_k) = src_k[0..count_k) for every row k of a device table {src, dst, count} (fp32 tensors): the host model
 // files ~110 freshly computed gradients into its flat arena with one launch instead of one copy each
 struct CopyRow { const float* src; float* dst; long count; };

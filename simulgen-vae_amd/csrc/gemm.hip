@@ -731,7 +731,9 @@ __global__ __launch_bounds__(256) void gemm_nt_reduce_kernel(const GemmNT p) {
 // =========================================================================================
 // TN
 // =========================================================================================
-template <typename T, bool USE_TR>
+// C2D: the X operand is a virtual im2col matrix (GemmTN::cv_*): a thread's 16-byte column chunk belongs to one window
+// offset (kh, kw), its rows are output pixels whose (oh, ow) is carried from stage to stage
+template <typename T, bool USE_TR, bool C2D = false>
 __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const GemmTN p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr bool IS_BF16 = sizeof(T) == 2;
@@ -757,7 +759,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
     grouped_raster(tile, tiles_1, tiles_2, t1, t2);
     const int i0 = t1 << 7, j0 = t2 << 7;
     const int tap = tz / p.splitk, z = tz - tap * p.splitk;
-    const int dt = tap - p.pad;
+    const int dt = C2D ? 0 : tap - p.pad;
     const int ksteps = (p.M + KR - 1) / KR;
     const int s_begin = (int)((long)ksteps * z / p.splitk);
     const int s_end = (int)((long)ksteps * (z + 1) / p.splitk);
@@ -771,8 +773,15 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
     const bool a_cok = (i0 + cq * EPC) < p.N1;
     const bool b_cok = (j0 + cq * EPC) < p.N2;
     const uint32_t acol = a_cok ? (uint32_t)((i0 + cq * EPC) * ESZ) : OOB_OFF;
-    const uint32_t bcol = b_cok ? (uint32_t)((j0 + cq * EPC) * ESZ) : OOB_OFF;
     const uint32_t lda_b = (uint32_t)(p.lda * ESZ), ldb_b = (uint32_t)(p.ldb * ESZ);
+    uint32_t bcol = b_cok ? (uint32_t)((j0 + cq * EPC) * ESZ) : OOB_OFF;
+    int dh = 0, dw = 0;                        // C2D: this thread's window offset minus the padding
+    if constexpr (C2D) {
+        const int vc = j0 + cq * EPC;
+        const int tp = vc / p.cv_C, kh = tp / p.cv_kw;
+        dh = kh - p.cv_P; dw = tp - kh * p.cv_kw - p.cv_P;
+        if (b_cok) bcol = (uint32_t)((vc - tp * p.cv_C) * ESZ);
+    }
     uint4 ra0A, ra1A, rb0A, rb1A, ra0B, ra1B, rb0B, rb1B;
 
     // rows past M and taps that leave the sample window point out of range -> hardware returns zeros
@@ -782,19 +791,45 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
     uint32_t ld_a0 = (uint32_t)ld_m0 * lda_b + acol, ld_a1 = (uint32_t)ld_m1 * lda_b + acol;
     uint32_t ld_b0 = (uint32_t)(ld_m0 + dt) * ldb_b + bcol, ld_b1 = (uint32_t)(ld_m1 + dt) * ldb_b + bcol;
     const int kr_t = KR % p.Tlen;
+    // C2D: (image byte offset, oh, ow) of the two rows
+    uint32_t im0 = 0u, im1 = 0u;
+    int oh0 = 0, ow0 = 0, oh1 = 0, ow1 = 0;
+    const uint32_t img_b = C2D ? (uint32_t)p.cv_H * (uint32_t)p.cv_W * ldb_b : 0u;
+    if constexpr (C2D) {
+        const int hw = p.cv_Ho * p.cv_Wo;
+        const int b0_ = ld_m0 / hw, q0_ = ld_m0 - b0_ * hw, b1_ = ld_m1 / hw, q1_ = ld_m1 - b1_ * hw;
+        oh0 = q0_ / p.cv_Wo; ow0 = q0_ - oh0 * p.cv_Wo; im0 = (uint32_t)b0_ * img_b;
+        oh1 = q1_ / p.cv_Wo; ow1 = q1_ - oh1 * p.cv_Wo; im1 = (uint32_t)b1_ * img_b;
+    }
+#define SGV_TN_ROW2D(PB, LB, PA, IM, OH, OW)                                                                  \
+    {                                                                                                         \
+        const int ih_ = OH * p.cv_S + dh, iw_ = OW * p.cv_S + dw;                                             \
+        PB = PA && (unsigned)ih_ < (unsigned)p.cv_H && (unsigned)iw_ < (unsigned)p.cv_W;                      \
+        LB = IM + (uint32_t)(ih_ * p.cv_W + iw_) * ldb_b + bcol;                                              \
+        OW += KR;                                                                                             \
+        while (OW >= p.cv_Wo) { OW -= p.cv_Wo; if (++OH == p.cv_Ho) { OH = 0; IM += img_b; } }                \
+    }
 #define SGV_TN_GLOAD(S, X)                                                                                    \
     {                                                                                                         \
         const bool pa0 = (ld_m0 < p.M), pa1 = (ld_m1 < p.M);                                                  \
-        const bool pb0 = pa0 && ((unsigned)(ld_t0 + dt) < (unsigned)p.Tlen);                                  \
-        const bool pb1 = pa1 && ((unsigned)(ld_t1 + dt) < (unsigned)p.Tlen);                                  \
+        bool pb0, pb1;                                                                                        \
+        if constexpr (C2D) {                                                                                  \
+            SGV_TN_ROW2D(pb0, ld_b0, pa0, im0, oh0, ow0) SGV_TN_ROW2D(pb1, ld_b1, pa1, im1, oh1, ow1)         \
+        } else {                                                                                              \
+            pb0 = pa0 && ((unsigned)(ld_t0 + dt) < (unsigned)p.Tlen);                                         \
+            pb1 = pa1 && ((unsigned)(ld_t1 + dt) < (unsigned)p.Tlen);                                         \
+        }                                                                                                     \
         ra0##X = bload16(rsA, pa0 ? ld_a0 : OOB_OFF);                                                         \
         ra1##X = bload16(rsA, pa1 ? ld_a1 : OOB_OFF);                                                         \
         rb0##X = bload16(rsB, pb0 ? ld_b0 : OOB_OFF);                                                         \
         rb1##X = bload16(rsB, pb1 ? ld_b1 : OOB_OFF);                                                         \
         ld_m0 += KR; ld_m1 += KR;                                                                             \
-        ld_t0 += kr_t; if (ld_t0 >= p.Tlen) ld_t0 -= p.Tlen;                                                  \
-        ld_t1 += kr_t; if (ld_t1 >= p.Tlen) ld_t1 -= p.Tlen;                                                  \
-        ld_a0 += KR * lda_b; ld_a1 += KR * lda_b; ld_b0 += KR * ldb_b; ld_b1 += KR * ldb_b;                   \
+        if constexpr (!C2D) {                                                                                 \
+            ld_t0 += kr_t; if (ld_t0 >= p.Tlen) ld_t0 -= p.Tlen;                                              \
+            ld_t1 += kr_t; if (ld_t1 >= p.Tlen) ld_t1 -= p.Tlen;                                              \
+            ld_b0 += KR * ldb_b; ld_b1 += KR * ldb_b;                                                         \
+        }                                                                                                     \
+        ld_a0 += KR * lda_b; ld_a1 += KR * lda_b;                                                             \
     }
 #define SGV_TN_SSTORE(BUF, X)                                                                                 \
     {                                                                                                         \
@@ -912,6 +947,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
         }
     }
 #undef SGV_TN_STEP
+#undef SGV_TN_ROW2D
 #undef SGV_TN_GLOAD
 #undef SGV_TN_SSTORE
 #undef SGV_TN_COMPUTE
@@ -948,6 +984,9 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_tn_kernel(const 
 // The transposed reads and the boundary stores are inline asm with hand-tracked lgkmcnt: the builtin / plain C++ LDS
 // accesses make the compiler put s_waitcnt vmcnt(0) in front of them while LDS-DMA is in flight.
 // =========================================================================================
+// C2D: X is the virtual im2col operand of GemmTN::cv_* -- a lane's chunk column fixes its window offset (kh, kw), the rows'
+// (image, oh, ow) are carried from stage to stage and every DMA is predicated on its pixel lying inside the image.
+template <bool C2D>
 __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     constexpr int ESZ = 2, KR = 32;
     constexpr int ROWA = 256, ROWX = 512;
@@ -967,7 +1006,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     grouped_raster(tile, tiles_1, tiles_2, t1, t2);
     const int i0 = t1 << 7, j0 = t2 << 8;
     const int tap = tz / p.splitk, z = tz - tap * p.splitk;
-    const int dt = tap - p.pad;
+    const int dt = C2D ? 0 : tap - p.pad;
     const int ksteps = (p.M + KR - 1) / KR;
     const int s_begin = (int)((long)ksteps * z / p.splitk);
     const int s_end = (int)((long)ksteps * (z + 1) / p.splitk);
@@ -987,8 +1026,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     const int lx_row = lane >> 5;
     const int lx_chunk0 = (lane & 31) ^ (lx_row << 2);
     const int lx_chunk1 = (lane & 31) ^ ((2 + lx_row) << 2);
-    const uint32_t x_col0 = (j0 + lx_chunk0 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk0 * 8) * ESZ) : OOB_OFF;
-    const uint32_t x_col1 = (j0 + lx_chunk1 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk1 * 8) * ESZ) : OOB_OFF;
+    uint32_t x_col0 = (j0 + lx_chunk0 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk0 * 8) * ESZ) : OOB_OFF;
+    uint32_t x_col1 = (j0 + lx_chunk1 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk1 * 8) * ESZ) : OOB_OFF;
+    // C2D: window offsets (minus the padding) of the lane's two chunk columns; state of the lane's first row of the next stage
+    int dh0 = 0, dw0 = 0, dh1 = 0, dw1 = 0;
+    uint32_t x_im = 0u;
+    int x_oh = 0, x_ow = 0;
+    const uint32_t img_b = C2D ? (uint32_t)p.cv_H * (uint32_t)p.cv_W * (uint32_t)ldx_b : 0u;
+    if constexpr (C2D) {
+        const int vc0 = j0 + lx_chunk0 * 8, vc1 = j0 + lx_chunk1 * 8;
+        const int t0_ = vc0 / p.cv_C, t1_ = vc1 / p.cv_C;
+        const int kh0_ = t0_ / p.cv_kw, kh1_ = t1_ / p.cv_kw;
+        dh0 = kh0_ - p.cv_P; dw0 = t0_ - kh0_ * p.cv_kw - p.cv_P;
+        dh1 = kh1_ - p.cv_P; dw1 = t1_ - kh1_ * p.cv_kw - p.cv_P;
+        if (vc0 < p.N2) x_col0 = (uint32_t)((vc0 - t0_ * p.cv_C) * ESZ);
+        if (vc1 < p.N2) x_col1 = (uint32_t)((vc1 - t1_ * p.cv_C) * ESZ);
+        const int m_ = s_begin * KR + wave * 8 + lx_row;
+        const int hw_ = p.cv_Ho * p.cv_Wo;
+        const int b_ = m_ / hw_, q_ = m_ - b_ * hw_;
+        x_oh = q_ / p.cv_Wo; x_ow = q_ - x_oh * p.cv_Wo; x_im = (uint32_t)b_ * img_b;
+    }
     uint32_t aoffs[2], xoffs[4];
 #pragma unroll
     for (int q = 0; q < 2; ++q) aoffs[q] = (uint32_t)(wave * 8 + q * 4 + la_row) * (uint32_t)lda_b + a_col;
@@ -1009,10 +1066,27 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
 #define SGV_T2_X(Q, STAGE)                                                                                    \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(dmaX + (STAGE) + (Q) * 1024), 16,      \
                                              xoffs[Q] + ld_x, 0, 0, 0);
+    // C2D op Q: row (lane's first row + 2Q) of the stage; offset of its pixel or out of range
+#define SGV_T2_X2D(Q, STAGE)                                                                                  \
+    {                                                                                                         \
+        const int ih_ = oh_ * p.cv_S + (((Q) & 1) ? dh1 : dh0), iw_ = ow_ * p.cv_S + (((Q) & 1) ? dw1 : dw0);  \
+        const bool ok_ = (unsigned)ih_ < (unsigned)p.cv_H && (unsigned)iw_ < (unsigned)p.cv_W;                \
+        const uint32_t vo_ = ok_ ? im_ + (uint32_t)(ih_ * p.cv_W + iw_) * (uint32_t)ldx_b + (((Q) & 1) ? x_col1 : x_col0) : OOB_OFF; \
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsX, (lds_void*)(dmaX + (STAGE) + (Q) * 1024), 16, vo_, 0, 0, 0); \
+        ow_ += 2;                                                                                             \
+        while (ow_ >= p.cv_Wo) { ow_ -= p.cv_Wo; if (++oh_ == p.cv_Ho) { oh_ = 0; im_ += img_b; } }           \
+    }
 #define SGV_T2_ISSUE(STAGE)                                                                                   \
     {                                                                                                         \
         SGV_T2_A(0, STAGE) SGV_T2_A(1, STAGE)                                                                 \
-        SGV_T2_X(0, STAGE) SGV_T2_X(1, STAGE) SGV_T2_X(2, STAGE) SGV_T2_X(3, STAGE)                           \
+        if constexpr (C2D) {                                                                                  \
+            int oh_ = x_oh, ow_ = x_ow; uint32_t im_ = x_im;                                                  \
+            SGV_T2_X2D(0, STAGE) SGV_T2_X2D(1, STAGE) SGV_T2_X2D(2, STAGE) SGV_T2_X2D(3, STAGE)               \
+            x_ow += KR;                                                                                       \
+            while (x_ow >= p.cv_Wo) { x_ow -= p.cv_Wo; if (++x_oh == p.cv_Ho) { x_oh = 0; x_im += img_b; } }  \
+        } else {                                                                                              \
+            SGV_T2_X(0, STAGE) SGV_T2_X(1, STAGE) SGV_T2_X(2, STAGE) SGV_T2_X(3, STAGE)                       \
+        }                                                                                                     \
         ld_a += (uint32_t)(KR * lda_b); ld_x += (uint32_t)(KR * ldx_b);                                       \
     }
     // X rows of stage STAGE (just landed, barrier passed) whose tap leaves the sample window are zeroed in LDS.  Bad rows
@@ -1021,7 +1095,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     // 8 x 32 threads tests one candidate row and clears one 16-byte chunk of it.  Skipped (no extra barrier) when no
     // boundary is near the window.
 #define SGV_T2_FIX(STAGE)                                                                                     \
-    {                                                                                                         \
+    if constexpr (!C2D) {                                                                                     \
         const bool near_ = dt != 0 && (rd_t < 2 || rd_t + KR + 2 > p.Tlen);                                   \
         if (near_) {                                                                                          \
             const int rb_ = rd_t == 0 ? 0 : p.Tlen - rd_t;                                                    \
@@ -1131,6 +1205,7 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     }
 #undef SGV_T2_A
 #undef SGV_T2_X
+#undef SGV_T2_X2D
 #undef SGV_T2_ISSUE
 #undef SGV_T2_FIX
 #undef SGV_T2_TR
@@ -1301,10 +1376,27 @@ int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
     GemmTN q = p;
     q.a_bytes = ((long)(p.M - 1) * p.lda + p.N1) * esz;
     q.b_bytes = ((long)(p.M - 1) * p.ldb + p.N2) * esz;
+    const bool c2d = p.cv_kw > 0;
+    if (c2d) {
+        if (p.taps != 1 || p.cv_C < epc || p.cv_C % epc || p.N2 % p.cv_C || (p.N2 / p.cv_C) % p.cv_kw) return -1;
+        if (p.cv_S < 1 || p.cv_P < 0 || p.cv_H < 1 || p.cv_W < 1 || p.cv_Ho < 1 || p.cv_Wo < 1 || p.M % (p.cv_Ho * p.cv_Wo)) return -1;
+        q.b_bytes = (((long)(p.M / (p.cv_Ho * p.cv_Wo)) * p.cv_H * p.cv_W - 1) * p.ldb + p.cv_C) * esz;
+    }
     if (q.a_bytes >= 0x7FFFFFF0L || q.b_bytes >= 0x7FFFFFF0L) return -1;
+    if (c2d && p.use_tr && (gemm_tn_uses_w2(dtype, p.M, p.N1, p.N2, p.M) || (p.force_w2 && gemm_tn_w2_eligible(dtype, p.M, p.N1, p.N2, p.M)))) {
+        dim3 gridw(cdiv(p.N1, 128) * cdiv(p.N2, 256) * p.splitk);
+        hipLaunchKernelGGL(gemm_tn_w2_kernel<true>, gridw, dim3(256), 0, s, q);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (c2d) {
+        dim3 grid(cdiv(p.N1, 128) * cdiv(p.N2, 128) * p.splitk);
+        if (dtype == 1) hipLaunchKernelGGL((gemm_tn_kernel<bf16_t, true, true>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_tn_kernel<float, false, true>), grid, dim3(256), 0, s, q);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     if (p.use_tr && (gemm_tn_uses_w2(dtype, p.M, p.N1, p.N2, p.Tlen) || (p.force_w2 && gemm_tn_w2_eligible(dtype, p.M, p.N1, p.N2, p.Tlen)))) {
         dim3 gridw(cdiv(p.N1, 128) * cdiv(p.N2, 256) * p.taps * p.splitk);
-        hipLaunchKernelGGL(gemm_tn_w2_kernel, gridw, dim3(256), 0, s, q);
+        hipLaunchKernelGGL(gemm_tn_w2_kernel<false>, gridw, dim3(256), 0, s, q);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     dim3 grid(cdiv(p.N1, 128) * cdiv(p.N2, 128) * p.taps * p.splitk);

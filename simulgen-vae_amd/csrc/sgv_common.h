@@ -184,6 +184,11 @@ struct GemmTN {
     int M, N1, N2, taps, pad, Tlen, splitk, use_tr;
     int force_w2;                   // tests: take gemm_tn_w2_kernel whenever the shape is eligible (ignores SGV_TN_W2)
     long a_bytes, b_bytes;          // filled by launch_gemm_tn
+    // virtual im2col operand (cv_kw > 0; weight gradient of a 2-D convolution without the im2col matrix): B is a channels-
+    // last image batch [nb][cv_H][cv_W][ldb] with cv_C channels, reduction row m = output pixel (b, oh, ow) of a
+    // [nb][cv_Ho][cv_Wo] grid, column n2 = (kh*cv_kw + kw)*cv_C + c reads B[b][oh*cv_S - cv_P + kh][ow*cv_S - cv_P + kw][c]
+    // (zero outside the image); N2 = KH*cv_kw*cv_C, taps = 1, pad / Tlen are not used.
+    int cv_kw, cv_H, cv_W, cv_S, cv_P, cv_Ho, cv_Wo, cv_C;
 };
 
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s);

@@ -17,6 +17,7 @@ forward, the loss 10*MSE(y1) + MSE(y2) and the backward and leaves `m.grads`; `m
 from __future__ import annotations
 
 import math
+import os
 
 import numpy as np
 import torch
@@ -47,6 +48,9 @@ class LatentConditionerImg:
         # fused_params: spectral-norm power iteration, clipping and AdamW run as multi-tensor passes over fixed gradient
         # buffers (ops.ParamSet); otherwise one operator call per tensor (the mode the gradient parity tests read)
         self.fused_params = bool(fused_params)
+        # implicit_conv: 3x3 / strided convolutions as implicit GEMMs (sgv_op_conv2d_nt); SGV_LC_IMPLICIT=0 keeps the
+        # im2col + GEMM lowering (A/B runs, and the comparator of tests/test_ops_gpu.py)
+        self.implicit_conv = os.environ.get("SGV_LC_IMPLICIT", "1") != "0"
         self.pset = None
         if any(c % 16 for c in self.filters):
             raise SgvError("latent_conditioner_filter entries must be multiples of 16 (bottleneck channels feed 8-wide GEMM tiles)")
@@ -279,16 +283,26 @@ class LatentConditionerImg:
         Wp = ops.conv_weight_pack(W, self.dt)
         B, H, Wd, _ = x4.shape
         direct = (k == 1 and stride == 1 and ci % 8 == 0)
+        # implicit GEMM (no im2col matrix): every convolution whose input channels fill 16-byte chunks, i.e. all but the stem
+        implicit = self.implicit_conv and not direct and ci % 8 == 0 and k * k <= 24
+        col = None
         if direct:
             col, Ho, Wo = x4.view(-1, ci), H, Wd
+        if implicit:
+            y = ops.conv2d_nt(x4, Wp, co, k, k, stride, pad, k * k * ci, ci, scale=inv_sigma)
+            Ho, Wo = y.shape[1], y.shape[2]
         else:
-            col, Ho, Wo = ops.im2col(x4, k, k, stride, pad)
-        y = ops.gemm_nt(col, Wp, scale=inv_sigma).view(B, Ho, Wo, co)
+            if col is None:
+                col, Ho, Wo = ops.im2col(x4, k, k, stride, pad)
+            y = ops.gemm_nt(col, Wp, scale=inv_sigma).view(B, Ho, Wo, co)
         u, v = self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"]
 
         def bwd(dy4):
             dy = dy4.reshape(-1, co)
-            G = ops.conv_weight_unpack(ops.gemm_tn(dy, col), W.shape)           # gradient wrt W / sigma
+            if implicit:
+                G = ops.conv_weight_unpack(ops.conv2d_tn(dy4.reshape(B, Ho, Wo, co), x4, k, k, stride, pad), W.shape)
+            else:
+                G = ops.conv_weight_unpack(ops.gemm_tn(dy, col), W.shape)       # gradient wrt W / sigma
             if sig2 is None:
                 self._acc(prefix + ".weight_orig", G)                            # chain rule applied by the fused step
             else:
@@ -296,6 +310,9 @@ class LatentConditionerImg:
             if not need_dx:
                 return None
             Wt = ops.transpose(Wp.view(1, co, -1), self.dt, 1, co, Wp.shape[1]).view(Wp.shape[1], co)
+            if implicit and stride == 1 and co % 8 == 0:
+                # dX of a stride-1 convolution = convolution of dY with the reversed taps of the transposed weights
+                return ops.conv2d_nt(dy4.reshape(B, Ho, Wo, co), Wt, ci, k, k, 1, k - 1 - pad, co, ci * co, flip=True, scale=inv_sigma)
             dcol = ops.gemm_nt(dy, Wt, scale=inv_sigma)
             return dcol.view(x4.shape) if direct else ops.col2im(dcol, x4.shape, k, k, stride, pad)
         return y, bwd

@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -39,6 +39,7 @@ def lib():
             "sgv_op_gemm_nt": [i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_conv2d_nt": [i, vp, vp, vp, vp] + [i] * 9 + [C.c_long, C.c_long, i, vp],
             "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp, i, vp],
+            "sgv_op_conv2d_tn": [i, vp, vp, vp] + [i] * 9 + [vp, i, vp],
             "sgv_op_gemm_tn_splitk": [i, i, i, i],
             "sgv_op_matvec_t": [vp, vp, vp, i, i, vp],
             "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp, vp],
@@ -184,6 +185,20 @@ def gemm_tn(A, Bm):
     slabs = torch.empty((sk, N1, N2), dtype=torch.float32, device=A.device) if sk > 1 else None
     _timed("gemm_tn", 2.0 * M * N1 * N2, lambda: _ck(lib().sgv_op_gemm_tn(_d(A), _p(A), _p(Bm), _p(out), M, N1, N2, _p(slabs), sk, _stream()),
                                                      "sgv_op_gemm_tn"))
+    return out
+
+
+def conv2d_tn(dy, x, KH, KW, stride, pad):
+    """Weight gradient of the convolution x [B, H, W, Cin] -> dy [B, Ho, Wo, N1] without the im2col matrix
+    (sgv_op_conv2d_tn) -> fp32 [N1, KH*KW*Cin] in the packed weight layout."""
+    B, H, Wd, Cin = x.shape
+    N1 = dy.shape[-1]
+    M, N2 = dy.numel() // N1, KH * KW * Cin
+    out = torch.empty((N1, N2), dtype=torch.float32, device=x.device)
+    sk = int(lib().sgv_op_gemm_tn_splitk(_d(x), M, N1, N2))
+    slabs = torch.empty((sk, N1, N2), dtype=torch.float32, device=x.device) if sk > 1 else None
+    _timed("gemm_tn", 2.0 * M * N1 * N2, lambda: _ck(lib().sgv_op_conv2d_tn(_d(x), _p(dy), _p(x), _p(out), B, H, Wd, Cin, N1, KH, KW, stride, pad,
+                                                                          _p(slabs), sk, _stream()), "sgv_op_conv2d_tn"))
     return out
 
 

@@ -74,8 +74,9 @@ IMPLICIT_CASES = [(2, 16, 16, 20, 24, 3, 1, 1), (3, 64, 64, 16, 16, 3, 1, 1), (2
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", IMPLICIT_CASES)
 def test_conv2d_implicit_gemm(dt, cfg):
-    """sgv_op_conv2d_nt: forward on the packed weights (any stride) and, for stride 1, the input gradient as the convolution
-    of dY with the reversed taps of the transposed weights -- against F.conv2d and its autograd in fp32 on the CPU."""
+    """sgv_op_conv2d_nt / sgv_op_conv2d_tn: forward on the packed weights (any stride), the weight gradient through the
+    virtual im2col operand and, for stride 1, the input gradient as the convolution of dY with the reversed taps of the
+    transposed weights -- against F.conv2d and its autograd in fp32 on the CPU."""
     B, Ci, Co, H, W, k, s, p = cfg
     if dt == torch.float32 and Co >= 1024:
         pytest.skip("the large shapes exercise the bf16 256x256 kernel")
@@ -91,6 +92,8 @@ def test_conv2d_implicit_gemm(dt, cfg):
     out = ops.conv2d_nt(xd, wp, Co, k, k, s, p, k * k * Ci, Ci, scale=scale)
     assert tuple(out.shape) == (B, y.shape[2], y.shape[3], Co)
     assert rel(nchw(out), 0.5 * y) < TOL[dt]
+    dW = ops.conv2d_tn(nhwc(dy, dt), xd, k, k, s, p)                                                   # [Cout][(kh,kw,ci)]
+    assert rel(dW, w.grad.permute(0, 2, 3, 1).reshape(Co, -1)) < TOL[dt]
     if s == 1:
         wt = wp.t().contiguous()                                                                       # [(kh,kw,ci)][Cout]
         dx = ops.conv2d_nt(nhwc(dy, dt), wt, Ci, k, k, 1, k - 1 - p, Co, Ci * Co, flip=True)
