@@ -1081,9 +1081,10 @@ int sgv_op_conv2d_nt(int dtype, const void* x, const void* W, void* y, const flo
 // a million of them for a handful of output tiles: sgv_op_gemm_tn_splitk() says how many row slices to use and the caller
 // provides splitk * N1 * N2 floats of slab workspace (deterministic: plain stores + one sum pass).
 int sgv_op_gemm_tn_splitk(int dtype, int M, int N1, int N2) {
-    const long tiles = (long)cdivi(N1, 128) * cdivi(N2, 128);
     const long steps = cdivi(M, dtype == 1 ? 32 : 16);
-    long sk = 768 / tiles;                       // three 128x128 blocks per CU
+    long tiles = (long)cdivi(N1, 128) * cdivi(N2, 128), slots = 768;      // three 128x128 blocks per CU
+    if (gemm_tn_uses_w2(dtype, M, N1, N2, M)) { tiles = (long)cdivi(N1, 128) * cdivi(N2, 256); slots = 512; }   // two 128x256 blocks per CU
+    long sk = slots / tiles;                     // one full round of blocks
     if (sk > steps / 8) sk = steps / 8;          // keep >= 8 K-steps per slice
     if (sk > 256) sk = 256;
     return sk < 1 ? 1 : (int)sk;
