@@ -147,6 +147,11 @@ def bench_latent_conditioner(args):
         step()
     torch.cuda.synchronize()
     cls = {}
+    if os.environ.get("SGV_LC_CALLS"):        # per-call listing of the second timed step (tools/run_lc_calls.sh)
+        calls_ = _ops.GEMM_TIMING[len(_ops.GEMM_TIMING) // 2:]
+        for c, fl, e0, e1 in calls_:
+            ms_ = e0.elapsed_time(e1)
+            print(f"[lc call] {c} {fl / 1e9:9.2f} GFLOP {ms_ * 1e3:8.1f} us {fl / ms_ / 1e9:7.0f} TFLOP/s", file=sys.stderr)
     for c, fl, e0, e1 in _ops.GEMM_TIMING:
         st = cls.setdefault(c, [0.0, 0.0, 0])
         st[0] += fl; st[1] += e0.elapsed_time(e1); st[2] += 1

@@ -53,6 +53,14 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
  * no atomics, results are bitwise reproducible); dgamma/dbeta are ACCUMULATED into (+=). */
 int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
                   double* sums, float* part, void* stream);
+/* Tail of ResidualBlock.forward (model_cnn.py:108-124) in one streaming pass after the statistics:
+ *   out = relu(A + gn(y; gamma, beta))   with  A = gn(y2; gamma2, beta2)   (cscale == NULL: blocks without squeeze-excite)
+ *                                          or  A = y2 * cscale[b][c]       (y2 = the normalised main branch, cscale [B][C])
+ * y = skip-projection output, y2 as above, all [B][P][C]; sums (and sums2 when cscale == NULL) are WRITTEN (B*G*2 doubles each,
+ * read later by sgv_op_gn_bwd).  Every term is rounded to the compute dtype before the sum, i.e. the result equals
+ * sgv_op_gn_fwd (x2) / sgv_op_chan_scale_fwd followed by sgv_op_add_relu_fwd bit for bit. */
+int sgv_op_gn_tail(int dtype, const void* y, const float* gamma, const float* beta, double* sums, const void* y2, const float* gamma2,
+                   const float* beta2, double* sums2, const float* cscale, void* out, int B, int P, int C, int G, float* part, void* stream);
 size_t sgv_op_gn_workspace_floats(int B, int P, int C);
 int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
                   const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream);

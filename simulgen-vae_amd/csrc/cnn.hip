@@ -896,6 +896,27 @@ int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, in
     return OPLAUNCH_OK();
 }
 size_t sgv_op_gn_workspace_floats(int B, int P, int C) { return ew_gn_part_floats(B, P, C); }
+// residual-block tail in one pass: see include/sgvae_ops.h
+int sgv_op_gn_tail(int dtype, const void* y, const float* gamma, const float* beta, double* sums, const void* y2, const float* gamma2,
+                   const float* beta2, double* sums2, const float* cscale, void* out, int B, int P, int C, int G, float* part, void* stream) {
+    OPCHK(y && gamma && beta && sums && y2 && out && part, "sgv_op_gn_tail: null argument");
+    OPCHK(cscale || (gamma2 && beta2 && sums2), "sgv_op_gn_tail: the second operand needs either cscale or gamma2 / beta2 / sums2");
+    OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_tail: C %% 8 == 0, 1 <= G <= %d, C %% G == 0 required", SGV_GN_MAX_GROUPS);
+    GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
+    p.part = part;
+    if (ew_gn_stats(dtype, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_tail: statistics launch failed");
+    GNTail t;
+    t.y2 = y2; t.ldy2 = C; t.cscale = cscale;
+    if (!cscale) {
+        GNParams q = gn_params(y2, B, P, C, G, gamma2, beta2, sums2);
+        q.part = part;                  // same stream: the first statistics pass has consumed its partials
+        if (ew_gn_stats(dtype, q, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_tail: statistics launch failed");
+        t.gamma2 = gamma2; t.beta2 = beta2; t.sums2 = sums2;
+    }
+    p.out = out; p.ldout = C;
+    if (ew_gn_tail(dtype, p, t, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_tail: launch failed");
+    return OPLAUNCH_OK();
+}
 // backward of out = act(gn(y)): dy (same dtype) and dgamma/dbeta (+= , fp32); sums from the forward; sums2: B*G*2 doubles
 // scratch; part: sgv_op_gn_workspace_floats floats scratch
 int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,

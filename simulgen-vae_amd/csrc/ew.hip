@@ -280,6 +280,71 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GNParams p) {
     }
 }
 
+// Tail of a residual block of the latent conditioner in one pass (modules/latent_conditioner_model_cnn.py:ResidualBlock.forward):
+//   out = relu(A + gn(y))   with A = gn2(y2) (its own statistics and affine; SE = false)
+//                                or y2 * cscale[b][c] (y2 already normalised, squeeze-excite scaling; SE = true)
+// instead of two normalise passes (or a scale pass) and an add + relu pass over the same rows.
+template <typename T, bool SE>
+__global__ __launch_bounds__(256) void gn_tail_kernel(const GNParams p, const GNTail t) {
+    const GNCtx c = gn_ctx(p);
+    float mean[8], rstd[8], ka[8], kb[8], ka2[8], kb2[8];
+    gn_consts(p, c, mean, rstd);
+    if (c.col_ok) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float g = p.gamma[c.c0 + e];
+            ka[e] = rstd[e] * g;
+            kb[e] = p.beta[c.c0 + e] - mean[e] * rstd[e] * g;
+        }
+    }
+    if constexpr (SE) {
+        if (c.col_ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ka2[e] = t.cscale[(long)c.b * p.C + c.c0 + e]; kb2[e] = 0.f; }
+        }
+    } else {
+        __syncthreads();                      // gn_consts broadcasts through one LDS table: everyone has read the first set
+        GNParams q = p;
+        q.sums = t.sums2;
+        gn_consts(q, c, mean, rstd);
+        if (c.col_ok) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float g = t.gamma2[c.c0 + e];
+                ka2[e] = rstd[e] * g;
+                kb2[e] = t.beta2[c.c0 + e] - mean[e] * rstd[e] * g;
+            }
+        }
+    }
+    if (!c.col_ok) return;
+    const T* y = reinterpret_cast<const T*>(p.y);
+    const T* y2 = reinterpret_cast<const T*>(t.y2);
+    T* out = reinterpret_cast<T*>(p.out);
+    for (int r = c.t_lo + c.ty; r < c.t_hi; r += 2 * c.RL) {      // two rows per round, loads first
+        const bool two = r + c.RL < c.t_hi;
+        const long m0 = (long)c.b * p.T + r, m1 = two ? m0 + c.RL : m0;
+        Raw8<T> ry0, ry1, rz0, rz1;
+        raw_load(y + m0 * p.ldy + c.c0, ry0);
+        raw_load(y + m1 * p.ldy + c.c0, ry1);
+        raw_load(y2 + m0 * t.ldy2 + c.c0, rz0);
+        raw_load(y2 + m1 * t.ldy2 + c.c0, rz1);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && !two) break;
+            float v[8], z[8];
+            raw_unpack(u ? ry1 : ry0, v);
+            raw_unpack(u ? rz1 : rz0, z);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                // each term is rounded to the compute dtype first: the same values as the separate normalise / scale passes
+                const float a = to_f32(from_f32<T>(z[e] * ka2[e] + kb2[e])), b = to_f32(from_f32<T>(v[e] * ka[e] + kb[e]));
+                v[e] = fmaxf(a + b, 0.f);
+            }
+            store8(out + (u ? m1 : m0) * p.ldout + c.c0, v);
+        }
+    }
+}
+
 // d(loss)/d(xhat) for the selected reconstruction loss, unit weight (mean reduction folded by caller)
 __device__ __forceinline__ float loss_grad(int lt, float d) {
     if (lt == 0) return 2.f * d;
@@ -932,11 +997,11 @@ __global__ __launch_bounds__(256) void act_kernel(const GNParams p) {
     }
 }
 
-#define GN_LAUNCH(KERN, P, S)                                              \
+#define GN_LAUNCH(KERN, P, S, ...)                                         \
     do {                                                                   \
         GNGeom g_ = gn_geom((P).B, (P).T, (P).C);                          \
         (P).CV = g_.CV;                                                    \
-        hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P);             \
+        hipLaunchKernelGGL(KERN, g_.grid, dim3(256), 0, S, P, ##__VA_ARGS__); \
     } while (0)
 // reduce-type kernels write per-block column sums: coarser row split keeps that workspace traffic small
 constexpr int GN_REDUCE_TARGET = 768;
@@ -995,6 +1060,17 @@ int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s) {
         else if (act == 2) GN_LAUNCH((gn_apply_kernel<float, 2>), p, s);
         else if (act == 3) GN_LAUNCH((gn_apply_kernel<float, 3>), p, s);
         else GN_LAUNCH((gn_apply_kernel<float, 0>), p, s);
+    }
+    return 0;
+}
+int ew_gn_tail(int dtype, GNParams p, GNTail t, hipStream_t s) {
+    if (!p.y || !p.out || !t.y2 || !p.sums || (t.cscale ? 0 : (!t.sums2 || !t.gamma2 || !t.beta2))) return -1;
+    if (dtype == 1) {
+        if (t.cscale) GN_LAUNCH((gn_tail_kernel<bf16_t, true>), p, s, t);
+        else GN_LAUNCH((gn_tail_kernel<bf16_t, false>), p, s, t);
+    } else {
+        if (t.cscale) GN_LAUNCH((gn_tail_kernel<float, true>), p, s, t);
+        else GN_LAUNCH((gn_tail_kernel<float, false>), p, s, t);
     }
     return 0;
 }

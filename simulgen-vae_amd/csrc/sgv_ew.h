@@ -33,6 +33,15 @@ struct GNParams {
     int loss_type = 0;
 };
 
+// second operand of ew_gn_tail: out = relu(A + gn(y)), A = gn2(y2) (gamma2 / beta2 / sums2) or y2 * cscale[b][c] (cscale != null)
+struct GNTail {
+    const void* y2 = nullptr; long ldy2 = 0;
+    const float* gamma2 = nullptr;
+    const float* beta2 = nullptr;
+    double* sums2 = nullptr;            // [B*G][2] statistics of y2 (same groups as y)
+    const float* cscale = nullptr;      // [B][C]
+};
+
 constexpr int SGV_GN_MAX_GROUPS = 32;
 // convgn.hip: fused small convolution + GroupNorm + GELU (+ residual) forward, one workgroup per (group, sample)
 struct ConvGN {
@@ -92,6 +101,7 @@ int ew_gn_bwd(int dtype, int act, GNParams p, hipStream_t s);   // reduce + fina
 int ew_gn_bwd_reduce_act(int dtype, int act, GNParams p, hipStream_t s);   // act: 0 none, 1 gelu, 3 relu
 int ew_gn_bwd_apply_act(int dtype, int act, GNParams p, hipStream_t s);
 int ew_gn_apply(int dtype, int act, GNParams p, hipStream_t s);
+int ew_gn_tail(int dtype, GNParams p, GNTail t, hipStream_t s);    // p: y / gamma / beta / sums (given) / out; see GNTail
 size_t ew_gn_part_floats(int B, int T, int C);
 int ew_gn_max_blocks(int B, int T, int C);
 int ew_act_part_rows(int B, int T, int C);         // rows of per-block column sums an ew_act launch with dbias writes          // upper bound of the per-block <G,W_eff> partials one launch writes

@@ -51,6 +51,7 @@ class LatentConditionerImg:
         # implicit_conv: 3x3 / strided convolutions as implicit GEMMs (sgv_op_conv2d_nt); SGV_LC_IMPLICIT=0 keeps the
         # im2col + GEMM lowering (A/B runs, and the comparator of tests/test_ops_gpu.py)
         self.implicit_conv = os.environ.get("SGV_LC_IMPLICIT", "1") != "0"
+        self.fused_tail = os.environ.get("SGV_LC_FUSED_TAIL", "1") != "0"
         self.pset = None
         if any(c % 16 for c in self.filters):
             raise SgvError("latent_conditioner_filter entries must be multiples of 16 (bottleneck channels feed 8-wide GEMM tiles)")
@@ -297,7 +298,8 @@ class LatentConditionerImg:
             y = ops.gemm_nt(col, Wp, scale=inv_sigma).view(B, Ho, Wo, co)
         u, v = self.P[prefix + ".weight_u"], self.P[prefix + ".weight_v"]
 
-        def bwd(dy4):
+        def bwd(dy4, addend=None):
+            """-> dX (+ addend, a tensor of the input's shape added in the GEMM epilogue of the 1x1 stride-1 case)"""
             dy = dy4.reshape(-1, co)
             if implicit:
                 G = ops.conv_weight_unpack(ops.conv2d_tn(dy4.reshape(B, Ho, Wo, co), x4, k, k, stride, pad), W.shape)
@@ -312,9 +314,12 @@ class LatentConditionerImg:
             Wt = ops.transpose(Wp.view(1, co, -1), self.dt, 1, co, Wp.shape[1]).view(Wp.shape[1], co)
             if implicit and stride == 1 and co % 8 == 0:
                 # dX of a stride-1 convolution = convolution of dY with the reversed taps of the transposed weights
-                return ops.conv2d_nt(dy4.reshape(B, Ho, Wo, co), Wt, ci, k, k, 1, k - 1 - pad, co, ci * co, flip=True, scale=inv_sigma)
-            dcol = ops.gemm_nt(dy, Wt, scale=inv_sigma)
-            return dcol.view(x4.shape) if direct else ops.col2im(dcol, x4.shape, k, k, stride, pad)
+                dx = ops.conv2d_nt(dy4.reshape(B, Ho, Wo, co), Wt, ci, k, k, 1, k - 1 - pad, co, ci * co, flip=True, scale=inv_sigma)
+            elif direct:
+                return ops.gemm_nt(dy, Wt, scale=inv_sigma, addend=None if addend is None else addend.view(-1, ci)).view(x4.shape)
+            else:
+                dx = ops.col2im(ops.gemm_nt(dy, Wt, scale=inv_sigma), x4.shape, k, k, stride, pad)
+            return dx if addend is None else ops.add(dx, addend)
         return y, bwd
 
     def _gn(self, prefix, y4, act):
@@ -323,6 +328,14 @@ class LatentConditionerImg:
         gamma, beta = self.P[prefix + ".weight"], self.P[prefix + ".bias"]
         y3 = y4.view(B, H * Wd, Cc)
         out, sums = ops.gn_fwd(y3, G, gamma, beta, act)
+        return out.view(y4.shape), self._gn_bwd(prefix, y4, sums, act)
+
+    def _gn_bwd(self, prefix, y4, sums, act):
+        """backward closure of out = act(gn(y4)) given the forward statistics"""
+        B, H, Wd, Cc = y4.shape
+        G = _num_groups(Cc)
+        gamma, beta = self.P[prefix + ".weight"], self.P[prefix + ".bias"]
+        y3 = y4.view(B, H * Wd, Cc)
 
         def bwd(dout4):
             dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
@@ -330,7 +343,7 @@ class LatentConditionerImg:
             self._acc(prefix + ".weight", dg)
             self._acc(prefix + ".bias", db)
             return dy.view(y4.shape)
-        return out.view(y4.shape), bwd
+        return bwd
 
     def _linear(self, prefix, x, sn, act=ops.LIN_NONE):
         W = self.P[prefix + (".weight_orig" if sn else ".weight")]
@@ -399,34 +412,48 @@ class LatentConditionerImg:
         c1, bw_c1 = self._conv(p + ".conv1", x4, 1, 1, 0)
         a1, bw_g1 = self._gn(p + ".gn1", c1, ops.ACT_RELU_GN)
         c2, bw_c2 = self._conv(p + ".conv2", a1, 3, b["stride"], 1)
-        o2, bw_g2 = self._gn(p + ".gn2", c2, ops.ACT_NONE)
-        B, H, Wd, Cc = o2.shape
+        B, H, Wd, Cc = c2.shape
+        # fused_tail: the block's tail -- normalise the skip projection (and, without squeeze-excite, the main branch), scale,
+        # add, relu -- is one pass over the rows (sgv_op_gn_tail) instead of three or four
+        tail = self.fused_tail and b["skip"]
+        if b["se"] or not tail:
+            o2, bw_g2 = self._gn(p + ".gn2", c2, ops.ACT_NONE)
         if b["se"]:
             o2f = o2.view(B, H * Wd, Cc)
             pooled = ops.avgpool_fwd(o2f)
             hid, bw_f1 = self._linear(p + ".se.fc1", pooled, False, ops.LIN_RELU)
             s, bw_f2 = self._linear(p + ".se.fc2", hid, False, ops.LIN_SIGMOID)
-            o3 = ops.chan_scale_fwd(o2f, s).view(o2.shape)
-        else:
-            o3 = o2
         if b["skip"]:
             sc, bw_sc = self._conv(p + ".skip.0", x4, 1, b["stride"], 0)
-            sk, bw_sg = self._gn(p + ".skip.1", sc, ops.ACT_NONE)
+        if tail:
+            G = _num_groups(Cc)
+            sc3 = sc.view(B, H * Wd, Cc)
+            g_s, b_s = self.P[p + ".skip.1.weight"], self.P[p + ".skip.1.bias"]
+            if b["se"]:
+                out, sums_s, _ = ops.gn_tail(sc3, G, g_s, b_s, o2f, cscale=s)
+            else:
+                out, sums_s, sums_2 = ops.gn_tail(sc3, G, g_s, b_s, c2.view(B, H * Wd, Cc), self.P[p + ".gn2.weight"], self.P[p + ".gn2.bias"])
+                bw_g2 = self._gn_bwd(p + ".gn2", c2, sums_2, ops.ACT_NONE)
+            bw_sg = self._gn_bwd(p + ".skip.1", sc, sums_s, ops.ACT_NONE)
+            out = out.view(c2.shape)
         else:
-            sk = x4
-        out = ops.add_relu(o3, sk)
+            o3 = ops.chan_scale_fwd(o2f, s).view(o2.shape) if b["se"] else o2
+            if b["skip"]:
+                sk, bw_sg = self._gn(p + ".skip.1", sc, ops.ACT_NONE)
+            else:
+                sk = x4
+            out = ops.add_relu(o3, sk)
 
         def bwd(dout):
             d = ops.relu_bwd(out, dout)
             if b["se"]:
                 dx_scale, ds = ops.chan_scale_bwd(o2f, s, d.view(B, H * Wd, Cc))
                 dpool = bw_f1(bw_f2(ds))
-                d_o2 = ops.avgpool_bwd(dpool, dx_scale).view(o2.shape)
+                d_o2 = ops.avgpool_bwd(dpool, dx_scale).view(c2.shape)
             else:
                 d_o2 = d
-            dx_main = bw_c1(bw_g1(bw_c2(bw_g2(d_o2))))
             dx_skip = bw_sc(bw_sg(d)) if b["skip"] else d
-            return ops.add(dx_main, dx_skip)
+            return bw_c1(bw_g1(bw_c2(bw_g2(d_o2))), addend=dx_skip)          # + dx_skip in the epilogue of conv1's dX GEMM
         return out, bwd
 
     # ---- forward / backward -----------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -44,6 +44,7 @@ def lib():
             "sgv_op_matvec_t": [vp, vp, vp, i, i, vp],
             "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp, vp],
             "sgv_op_gn_workspace_floats": [i, i, i],
+            "sgv_op_gn_tail": [i] + [vp] * 10 + [i, i, i, i, vp, vp],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
             "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_maxpool_bwd": [i, vp, vp, vp, i, i, i, i, vp],
@@ -210,6 +211,19 @@ def gn_fwd(y, G, gamma, beta, act):
     part = torch.empty(int(lib().sgv_op_gn_workspace_floats(B, P, Cc)), dtype=torch.float32, device=y.device)
     _ck(lib().sgv_op_gn_fwd(_d(y), act, _p(y), _p(out), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _p(part), _stream()), "sgv_op_gn_fwd")
     return out, sums
+
+
+def gn_tail(y, G, gamma, beta, y2, gamma2=None, beta2=None, cscale=None):
+    """out = relu(A + gn(y)) in one pass (sgv_op_gn_tail); A = gn(y2; gamma2, beta2), or y2 * cscale[b, c] when cscale is given.
+    y, y2 [B, P, C] -> (out, sums of y, sums of y2 or None)."""
+    B, P, Cc = y.shape
+    out = torch.empty_like(y)
+    sums = torch.empty(B * G * 2, dtype=torch.float64, device=y.device)
+    sums2 = None if cscale is not None else torch.empty(B * G * 2, dtype=torch.float64, device=y.device)
+    part = torch.empty(int(lib().sgv_op_gn_workspace_floats(B, P, Cc)), dtype=torch.float32, device=y.device)
+    _ck(lib().sgv_op_gn_tail(_d(y), _p(y), _p(gamma), _p(beta), _p(sums), _p(y2), _p(gamma2), _p(beta2), _p(sums2), _p(cscale), _p(out),
+                             B, P, Cc, G, _p(part), _stream()), "sgv_op_gn_tail")
+    return out, sums, sums2
 
 
 def gn_bwd(y, dout, G, gamma, beta, sums, act, dgamma, dbeta):

@@ -125,6 +125,37 @@ def test_groupnorm_relu(dt, cfg):
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cfg", [(2, 64, 36, False), (3, 128, 4096, False), (2, 256, 300, True), (2, 1024, 64, True), (1, 32, 70000, False)])
+def test_residual_block_tail_in_one_pass(dt, cfg):
+    """sgv_op_gn_tail against the operators it replaces (two sgv_op_gn_fwd or sgv_op_gn_fwd + sgv_op_chan_scale_fwd, then
+    sgv_op_add_relu_fwd): the same roundings, so equal up to the last bit of the statistics (small slabs take a one-kernel
+    path with its own summation order in sgv_op_gn_fwd), and the statistics it leaves for the backward are those of
+    sgv_op_gn_fwd."""
+    B, Cc, P, se = cfg
+    G = 32 if Cc % 32 == 0 else 16
+    g = torch.Generator().manual_seed(3)
+    y = (torch.randn(B, P, Cc, generator=g) * 2 + 0.5).to(device="cuda", dtype=dt)
+    y2 = torch.randn(B, P, Cc, generator=g).to(device="cuda", dtype=dt)
+    gam, bet, gam2, bet2 = [(torch.randn(Cc, generator=g) * 0.5 + (1 if i % 2 == 0 else 0)).cuda() for i in range(4)]
+    sk, sums_ref = ops.gn_fwd(y, G, gam, bet, ops.ACT_NONE)
+    if se:
+        cs = torch.rand(B, Cc, generator=g).cuda()
+        a = ops.chan_scale_fwd(y2, cs)
+        out, sums, sums2 = ops.gn_tail(y, G, gam, bet, y2, cscale=cs)
+        assert sums2 is None
+    else:
+        a, sums2_ref = ops.gn_fwd(y2, G, gam2, bet2, ops.ACT_NONE)
+        out, sums, sums2 = ops.gn_tail(y, G, gam, bet, y2, gam2, bet2)
+        assert rel(sums2, sums2_ref) < 1e-6
+    ref = ops.add_relu(a, sk)
+    assert rel(sums, sums_ref) < 1e-6
+    assert rel(out, ref) < (1e-6 if dt == torch.float32 else 8e-3)
+    # bit-equal except where the statistics differ in their last bit (then a last-bit difference of the fp32 terms, which the
+    # bf16 rounding mostly hides)
+    assert float((out.float() != ref.float()).float().mean()) < (0.1 if dt == torch.float32 else 5e-3)
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 def test_maxpool_residual_se_ops(dt):
     g = torch.Generator().manual_seed(3)
     B, Cc, H, W = 2, 16, 11, 14
