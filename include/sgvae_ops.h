@@ -26,6 +26,13 @@ int sgv_op_col2im(int dtype, const void* dcol, void* dx, int B, int H, int W, in
  * (K, N multiples of 8; scale/bias/addend may be NULL; out_f32 = 1 writes fp32 instead of the compute dtype). */
 int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend,
                    int M, int N, int K, int out_f32, void* stream);
+/* The stem (nn.Conv2d(1, C, 7, padding=3), model_cnn.py:92-93) without an im2col matrix, bf16 only: x [B][H][W] one channel,
+ * wp the packed weights [N][roundup(KH*KW, 8)], y [B][H][W][N] = scale[0] * conv(x, w) (stride 1, square odd window <= 7x7,
+ * pad = (KH-1)/2), and the GroupNorm statistics of y (as stored) in sums (B*G*2 doubles: per-block partials in `part`,
+ * sgv_op_stem_conv_workspace_floats() floats, combined in a fixed order). */
+size_t sgv_op_stem_conv_workspace_floats(int B, int H, int W, int N);
+int sgv_op_stem_conv_fwd(const void* x, const void* wp, const float* scale, void* y, double* sums, float* part, int B, int H, int W, int N,
+                         int KH, int KW, int pad, int G, void* stream);
 /* The same convolution as an implicit GEMM (no im2col matrix; bf16 or fp32, Cin and N multiples of 8, KH*KW <= 31):
  *   y[b][oh][ow][n] = scale[0] * sum_{kh,kw,c} x[b][oh*stride - pad + kh][ow*stride - pad + kw][c] * Wt(kh*KW + kw)[n][c]
  * with x [B][H][W][Cin] and y [B][Ho][Wo][N] channels-last, Ho = (H + 2 pad - KH)/stride + 1 (pixels outside the image are
@@ -53,6 +60,9 @@ int sgv_op_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, i
  * no atomics, results are bitwise reproducible); dgamma/dbeta are ACCUMULATED into (+=). */
 int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
                   double* sums, float* part, void* stream);
+/* out = act(gn(y)) with the statistics given (sums as written by sgv_op_gn_fwd / sgv_op_stem_conv_fwd). */
+int sgv_op_gn_apply(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
+                    double* sums, void* stream);
 /* Tail of ResidualBlock.forward (model_cnn.py:108-124) in one streaming pass after the statistics:
  *   out = relu(A + gn(y; gamma, beta))   with  A = gn(y2; gamma2, beta2)   (cscale == NULL: blocks without squeeze-excite)
  *                                          or  A = y2 * cscale[b][c]       (y2 = the normalised main branch, cscale [B][C])

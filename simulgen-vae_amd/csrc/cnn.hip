@@ -81,6 +81,104 @@ __global__ __launch_bounds__(256) void im2col_vec_kernel(const T* x, T* col, Con
         while (ow >= g.Wo) { ow -= g.Wo; if (++oh == g.Ho) { oh = 0; ++b; } }
     }
 }
+// ---- stem: one-input-channel convolution, direct on the MFMA (no im2col matrix) -----------------------------------------
+// y[b][h][w][n] = scale * sum_{kh,kw} x[b][h - P + kh][w - P + kw] * wp[n][kh*KW + kw]   (stride 1, KH, KW <= 8, bf16)
+// A workgroup computes an 8 x 128 pixel tile of one image: the (8 + 8) x (128 + 8) input window sits in LDS (zero outside the
+// image), K is laid out as kh*8 + kw (64 slots, weights zero in the unused ones) so a lane's 8 consecutive k of an MFMA
+// operand are 8 consecutive pixels of one window row.  Each wave owns 2 rows = 8 tiles of 32 pixels x 32 channels
+// (mfma_f32_32x32x16_bf16 x 4); the tile goes through LDS so that every lane stores 16 contiguous bytes, and the wave keeps
+// per-channel (sum, sum of squares) of the stored values: per-block partials -> stem_stats_finalize_kernel (fixed order).
+constexpr int STEM_TH = 8, STEM_TW = 128, STEM_PITCH = 160, STEM_ROWS = STEM_TH + 8, STEM_SP = 40;
+__global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* scale,
+                                                            bf16_t* __restrict__ y, float* __restrict__ part, int H, int W, int N, int KH, int KW,
+                                                            int P, int Kp) {
+    __shared__ __attribute__((aligned(16))) bf16_t img[STEM_ROWS * STEM_PITCH];
+    __shared__ __attribute__((aligned(16))) bf16_t stage[4][32 * STEM_SP];
+    __shared__ float red[4][32][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int w0 = blockIdx.x * STEM_TW, h0 = blockIdx.y * STEM_TH, b = blockIdx.z;
+    const bf16_t zero = from_f32<bf16_t>(0.f);
+    for (int i = tid; i < STEM_ROWS * (STEM_TW + 8); i += 256) {
+        const int r = i / (STEM_TW + 8), c = i - r * (STEM_TW + 8);
+        const int h = h0 - P + r, w = w0 - P + c;
+        bf16_t v = zero;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = x[((long)b * H + h) * W + w];
+        img[r * STEM_PITCH + c] = v;
+    }
+    __syncthreads();
+    const float sc = scale ? *scale : 1.f;
+    const int ln = lane & 31, lh = lane >> 5;
+    const long blk = ((long)b * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+    for (int n0 = 0; n0 < N; n0 += 32) {
+        bf16x8 wf[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; ++s4) {
+            const int kh = 2 * s4 + lh;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                wf[s4][e] = (kh < KH && e < KW && n0 + ln < N) ? wp[(long)(n0 + ln) * Kp + kh * KW + e] : zero;
+        }
+        float ssum = 0.f, ssq = 0.f;
+        for (int t = 0; t < 8; ++t) {
+            const int rr = wave * 2 + (t >> 2), tc = (t & 3) * 32;
+            f32x16 acc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+            for (int s4 = 0; s4 < 4; ++s4) {
+                const bf16_t* src = img + (rr + 2 * s4 + lh) * STEM_PITCH + tc + ln;
+                bf16x8 af;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) af[e] = src[e];
+                acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, wf[s4], acc, 0, 0, 0);
+            }
+            const int h = h0 + rr;
+            bf16_t* st = stage[wave];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int pr = (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const bf16_t v = from_f32<bf16_t>(acc[r] * sc);
+                if (h < H && w0 + tc + pr < W && n0 + ln < N) { const float f = to_f32(v); ssum += f; ssq += f * f; }
+                st[pr * STEM_SP + ln] = v;
+            }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const int q = lane + 64 * j, pr = q >> 2, cc = (q & 3) * 8;
+                const bf16x8 v8 = *reinterpret_cast<const bf16x8*>(st + pr * STEM_SP + cc);
+                const int w = w0 + tc + pr;
+                if (h < H && w < W && n0 + cc < N) *reinterpret_cast<bf16x8*>(y + (((long)b * H + h) * W + w) * N + n0 + cc) = v8;
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+        ssum += __shfl_xor(ssum, 32, 64);
+        ssq += __shfl_xor(ssq, 32, 64);
+        __syncthreads();
+        if (lane < 32) { red[wave][lane][0] = ssum; red[wave][lane][1] = ssq; }
+        __syncthreads();
+        if (tid < 32 && n0 + tid < N) {
+            float a = 0.f, q2 = 0.f;
+            for (int wv = 0; wv < 4; ++wv) { a += red[wv][tid][0]; q2 += red[wv][tid][1]; }
+            part[(blk * N + n0 + tid) * 2 + 0] = a;
+            part[(blk * N + n0 + tid) * 2 + 1] = q2;
+        }
+    }
+}
+// sums[b][g] = (sum, sum of squares) over the image's blocks and the group's channels, in a fixed order
+__global__ __launch_bounds__(64) void stem_stats_finalize_kernel(const float* part, double* sums, int nblk, int N, int G, int BG) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= BG) return;
+    const int b = i / G, g = i - b * G, Cg = N / G;
+    double a = 0.0, q = 0.0;
+    for (int k = 0; k < nblk; ++k)
+        for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
+            a += (double)part[(((long)b * nblk + k) * N + c) * 2 + 0];
+            q += (double)part[(((long)b * nblk + k) * N + c) * 2 + 1];
+        }
+    sums[(long)i * 2 + 0] = a;
+    sums[(long)i * 2 + 1] = q;
+}
+
 // gather form of col2im with 8 channels per lane: cw_ = min(C / 8, 256) vector lanes
 template <typename T>
 __global__ __launch_bounds__(256) void col2im_vec_kernel(const T* dcol, T* dx, ConvGeom g, int cw_) {
@@ -781,6 +879,24 @@ int sgv_op_conv_out_shape(int H, int W, int C, int KH, int KW, int stride, int p
     if (Kp) *Kp = g.Kp;
     return 0;
 }
+// one-input-channel stride-1 convolution + GroupNorm statistics of its output: see include/sgvae_ops.h
+size_t sgv_op_stem_conv_workspace_floats(int B, int H, int W, int N) {
+    return (size_t)B * cdivi(H, STEM_TH) * cdivi(W, STEM_TW) * (size_t)N * 2;
+}
+int sgv_op_stem_conv_fwd(const void* x, const void* wp, const float* scale, void* y, double* sums, float* part, int B, int H, int W, int N,
+                         int KH, int KW, int pad, int G, void* stream) {
+    OPCHK(x && wp && y && sums && part && B > 0 && H > 0 && W > 0 && N > 0, "sgv_op_stem_conv_fwd: bad argument");
+    OPCHK(KH >= 1 && KH <= 8 && KW >= 1 && KW <= 8 && pad >= 0 && pad <= 7 && 2 * pad == KH - 1 && KH == KW,
+          "sgv_op_stem_conv_fwd: square odd windows up to 7x7 with 'same' padding only (got %dx%d pad %d)", KH, KW, pad);
+    OPCHK(N % 8 == 0 && G >= 1 && N % G == 0, "sgv_op_stem_conv_fwd: N %% 8 == 0 and N %% G == 0 required (got N=%d G=%d)", N, G);
+    OPCHK(cdivi(H, STEM_TH) <= 65535 && B <= 65535, "sgv_op_stem_conv_fwd: image too tall / batch too large for the grid");
+    const int Kp = (KH * KW + 7) / 8 * 8;
+    const dim3 grid(cdivi(W, STEM_TW), cdivi(H, STEM_TH), B);
+    hipLaunchKernelGGL(stem_conv_fwd_kernel, grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(wp),
+                       scale, reinterpret_cast<bf16_t*>(y), part, H, W, N, KH, KW, pad, Kp);
+    hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(cdivi(B * G, 64)), dim3(64), 0, ST(stream), part, sums, (int)(grid.x * grid.y), N, G, B * G);
+    return OPLAUNCH_OK();
+}
 int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
     OPCHK(x && col && B > 0 && H > 0 && W > 0 && C > 0 && stride > 0 && KH > 0 && KW > 0, "sgv_op_im2col: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, KH, KW, stride, pad);
@@ -893,6 +1009,16 @@ int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, in
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
     p.out = out; p.ldout = C; p.part = part;
     if (ew_gn_fwd(dtype, act, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_fwd: launch failed");
+    return OPLAUNCH_OK();
+}
+// out = act(gn(y)) with the statistics given (sgv_op_stem_conv_fwd leaves them)
+int sgv_op_gn_apply(int dtype, int act, const void* y, void* out, int B, int P, int C, int G, const float* gamma, const float* beta,
+                    double* sums, void* stream) {
+    OPCHK(y && out && gamma && beta && sums, "sgv_op_gn_apply: null argument");
+    OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_apply: C %% 8 == 0, 1 <= G <= %d, C %% G == 0 required", SGV_GN_MAX_GROUPS);
+    GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
+    p.out = out; p.ldout = C;
+    if (ew_gn_apply(dtype, act, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_apply: launch failed");
     return OPLAUNCH_OK();
 }
 size_t sgv_op_gn_workspace_floats(int B, int P, int C) { return ew_gn_part_floats(B, P, C); }

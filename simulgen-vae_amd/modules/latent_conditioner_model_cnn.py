@@ -286,10 +286,16 @@ class LatentConditionerImg:
         direct = (k == 1 and stride == 1 and ci % 8 == 0)
         # implicit GEMM (no im2col matrix): every convolution whose input channels fill 16-byte chunks, i.e. all but the stem
         implicit = self.implicit_conv and not direct and ci % 8 == 0 and k * k <= 24
+        # the one-channel stem: direct convolution on the MFMA, which also leaves the GroupNorm statistics of its output
+        stem = self.implicit_conv and ci == 1 and stride == 1 and k <= 7 and 2 * pad == k - 1 and self.dt == torch.bfloat16 and not need_dx
         col = None
+        self._conv_sums = None
         if direct:
             col, Ho, Wo = x4.view(-1, ci), H, Wd
-        if implicit:
+        if stem:
+            y, self._conv_sums = ops.stem_conv(x4.view(B, H, Wd), Wp, co, k, pad, _num_groups(co), scale=inv_sigma)
+            Ho, Wo = H, Wd
+        elif implicit:
             y = ops.conv2d_nt(x4, Wp, co, k, k, stride, pad, k * k * ci, ci, scale=inv_sigma)
             Ho, Wo = y.shape[1], y.shape[2]
         else:
@@ -304,7 +310,8 @@ class LatentConditionerImg:
             if implicit:
                 G = ops.conv_weight_unpack(ops.conv2d_tn(dy4.reshape(B, Ho, Wo, co), x4, k, k, stride, pad), W.shape)
             else:
-                G = ops.conv_weight_unpack(ops.gemm_tn(dy, col), W.shape)       # gradient wrt W / sigma
+                colb = col if col is not None else ops.im2col(x4, k, k, stride, pad)[0]      # stem: the matrix exists in backward only
+                G = ops.conv_weight_unpack(ops.gemm_tn(dy, colb), W.shape)      # gradient wrt W / sigma
             if sig2 is None:
                 self._acc(prefix + ".weight_orig", G)                            # chain rule applied by the fused step
             else:
@@ -322,12 +329,16 @@ class LatentConditionerImg:
             return dx if addend is None else ops.add(dx, addend)
         return y, bwd
 
-    def _gn(self, prefix, y4, act):
+    def _gn(self, prefix, y4, act, sums=None):
+        """sums: statistics the producing kernel already computed (the stem convolution)"""
         B, H, Wd, Cc = y4.shape
         G = _num_groups(Cc)
         gamma, beta = self.P[prefix + ".weight"], self.P[prefix + ".bias"]
         y3 = y4.view(B, H * Wd, Cc)
-        out, sums = ops.gn_fwd(y3, G, gamma, beta, act)
+        if sums is not None:
+            out = ops.gn_apply(y3, G, gamma, beta, sums, act)
+        else:
+            out, sums = ops.gn_fwd(y3, G, gamma, beta, act)
         return out.view(y4.shape), self._gn_bwd(prefix, y4, sums, act)
 
     def _gn_bwd(self, prefix, y4, sums, act):
@@ -475,7 +486,7 @@ class LatentConditionerImg:
         x4 = x.to(self.dt).contiguous().view(B, side, side, 1)
         c0, bw = self._conv("initial_conv.0", x4, 7, 1, 3, need_dx=False)
         back.append(bw)
-        a0, bw = self._gn("initial_conv.1", c0, ops.ACT_RELU_GN)
+        a0, bw = self._gn("initial_conv.1", c0, ops.ACT_RELU_GN, sums=self._conv_sums)
         back.append(bw)
         h, pool_idx = ops.maxpool_fwd(a0)
         back.append(lambda d, idx=pool_idx, shp=tuple(a0.shape): ops.maxpool_bwd(idx, d, shp))

@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_workspace_floats",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -44,6 +44,9 @@ def lib():
             "sgv_op_matvec_t": [vp, vp, vp, i, i, vp],
             "sgv_op_gn_fwd": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp, vp],
             "sgv_op_gn_workspace_floats": [i, i, i],
+            "sgv_op_gn_apply": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp],
+            "sgv_op_stem_conv_workspace_floats": [i, i, i, i],
+            "sgv_op_stem_conv_fwd": [vp] * 6 + [i] * 8 + [vp],
             "sgv_op_gn_tail": [i] + [vp] * 10 + [i, i, i, i, vp, vp],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
             "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
@@ -91,6 +94,7 @@ def lib():
             getattr(l, name).argtypes = args
         l.sgv_pset_sigma.restype = C.c_void_p
         l.sgv_op_gn_workspace_floats.restype = C.c_size_t
+        l.sgv_op_stem_conv_workspace_floats.restype = C.c_size_t
         _lib = l
     return _lib
 
@@ -211,6 +215,27 @@ def gn_fwd(y, G, gamma, beta, act):
     part = torch.empty(int(lib().sgv_op_gn_workspace_floats(B, P, Cc)), dtype=torch.float32, device=y.device)
     _ck(lib().sgv_op_gn_fwd(_d(y), act, _p(y), _p(out), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _p(part), _stream()), "sgv_op_gn_fwd")
     return out, sums
+
+
+def stem_conv(x, wp, N, k, pad, G, scale=None):
+    """One-input-channel convolution on the MFMA without an im2col matrix + the GroupNorm statistics of its output
+    (sgv_op_stem_conv_fwd): x [B, H, W] bf16, wp the packed weights [N, roundup(k*k, 8)] -> (y [B, H, W, N], sums)."""
+    B, H, W = x.shape
+    y = torch.empty((B, H, W, N), dtype=torch.bfloat16, device=x.device)
+    sums = torch.empty(B * G * 2, dtype=torch.float64, device=x.device)
+    part = torch.empty(int(lib().sgv_op_stem_conv_workspace_floats(B, H, W, N)), dtype=torch.float32, device=x.device)
+    _timed("gemm_nt", 2.0 * B * H * W * N * k * k,
+           lambda: _ck(lib().sgv_op_stem_conv_fwd(_p(x), _p(wp), _p(scale), _p(y), _p(sums), _p(part), B, H, W, N, k, k, pad, G, _stream()),
+                       "sgv_op_stem_conv_fwd"))
+    return y, sums
+
+
+def gn_apply(y, G, gamma, beta, sums, act):
+    """act(gn(y)) with the statistics given. y [B, P, C]."""
+    B, P, Cc = y.shape
+    out = torch.empty_like(y)
+    _ck(lib().sgv_op_gn_apply(_d(y), act, _p(y), _p(out), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _stream()), "sgv_op_gn_apply")
+    return out
 
 
 def gn_tail(y, G, gamma, beta, y2, gamma2=None, beta2=None, cscale=None):

@@ -124,6 +124,31 @@ def test_groupnorm_relu(dt, cfg):
     assert rel(dgam, gamma.grad) < max(TOL[dt], 2e-4) and rel(dbet, beta.grad) < max(TOL[dt], 2e-4)
 
 
+@pytest.mark.parametrize("cfg", [(2, 20, 24, 32, 7), (1, 37, 150, 32, 7), (2, 16, 16, 64, 5), (3, 9, 130, 16, 3), (1, 300, 260, 32, 7)])
+def test_stem_convolution_direct(cfg):
+    """sgv_op_stem_conv_fwd (one input channel, bf16): the convolution against F.conv2d in fp32 on the CPU, and the GroupNorm
+    statistics it leaves against sgv_op_gn_fwd's on the same stored output."""
+    B, H, W, N, k = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(11)
+    x = q(torch.randn(B, 1, H, W, generator=g), dt)
+    w = q(torch.randn(N, 1, k, k, generator=g) * 0.2, dt)
+    ref = 0.7 * F.conv2d(x, w, None, 1, k // 2)
+    kp = (k * k + 7) // 8 * 8
+    wp = torch.zeros(N, kp)
+    wp[:, :k * k] = w.reshape(N, -1)
+    G = 32 if N % 32 == 0 else 16
+    y, sums = ops.stem_conv(x[:, 0].contiguous().to(device="cuda", dtype=dt), wp.to(device="cuda", dtype=dt), N, k, k // 2, G,
+                            scale=torch.tensor([0.7], device="cuda"))
+    assert tuple(y.shape) == (B, H, W, N)
+    assert rel(nchw(y), ref) < TOL[dt]
+    _, sums_ref = ops.gn_fwd(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), ops.ACT_NONE)
+    assert rel(sums, sums_ref) < 1e-5
+    out = ops.gn_apply(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), sums, ops.ACT_RELU_GN)
+    out_ref, _ = ops.gn_fwd(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), ops.ACT_RELU_GN)
+    assert rel(out, out_ref) < 1e-2
+
+
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("cfg", [(2, 64, 36, False), (3, 128, 4096, False), (2, 256, 300, True), (2, 1024, 64, True), (1, 32, 70000, False)])
 def test_residual_block_tail_in_one_pass(dt, cfg):
