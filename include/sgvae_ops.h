@@ -33,6 +33,10 @@ int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float
 size_t sgv_op_stem_conv_workspace_floats(int B, int H, int W, int N);
 int sgv_op_stem_conv_fwd(const void* x, const void* wp, const float* scale, void* y, double* sums, float* part, int B, int H, int W, int N,
                          int KH, int KW, int pad, int G, void* stream);
+/* Its weight gradient, again without the im2col matrix: dW[n][kh*KW + kw] (fp32, rows padded with zeros to roundup(KH*KW, 8),
+ * the layout sgv_op_gemm_tn(dy, col) gives) = sum_{b,h,w} dy[b][h][w][n] * x[b][h - pad + kh][w - pad + kw]; part: the same
+ * workspace size as the forward. */
+int sgv_op_stem_conv_dw(const void* x, const void* dy, float* dW, float* part, int B, int H, int W, int N, int KH, int KW, int pad, void* stream);
 /* The same convolution as an implicit GEMM (no im2col matrix; bf16 or fp32, Cin and N multiples of 8, KH*KW <= 31):
  *   y[b][oh][ow][n] = scale[0] * sum_{kh,kw,c} x[b][oh*stride - pad + kh][ow*stride - pad + kw][c] * Wt(kh*KW + kw)[n][c]
  * with x [B][H][W][Cin] and y [B][Ho][Wo][N] channels-last, Ho = (H + 2 pad - KH)/stride + 1 (pixels outside the image are

@@ -55,6 +55,28 @@ __global__ __launch_bounds__(256) void im2col_kernel(const T* x, T* col, ConvGeo
         while (ow >= g.Wo) { ow -= g.Wo; if (++oh == g.Ho) { oh = 0; ++b; } }
     }
 }
+// C == 1 (the stem), stride 1: a thread gathers 8 consecutive k of one output pixel and stores them as one 16-byte (bf16) /
+// 32-byte (fp32) piece; consecutive threads -> consecutive pieces, so `col` is written as one contiguous stream
+template <typename T>
+__global__ __launch_bounds__(256) void im2col_c1_kernel(const T* __restrict__ x, T* __restrict__ col, ConvGeom g) {
+    const int nch = g.Kp >> 3;
+    const long total = (long)g.B * g.Ho * g.Wo * nch;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+        const long m = i / nch;
+        const int j = (int)(i - m * nch);
+        const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
+        const T* img = x + (long)b * g.H * g.W;
+        float v[8];
+        int kh = (j * 8) / g.KW, kw = j * 8 - kh * g.KW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int h = oh * g.S - g.P + kh, w = ow * g.S - g.P + kw;
+            v[e] = (kh < g.KH && (unsigned)h < (unsigned)g.H && (unsigned)w < (unsigned)g.W) ? to_f32(img[(long)h * g.W + w]) : 0.f;
+            if (++kw == g.KW) { kw = 0; ++kh; }
+        }
+        store8(col + m * g.Kp + j * 8, v);          // exact: the values are already of type T
+    }
+}
 // C % 8 == 0 (every layer but the 1-channel stem): a lane moves 8 channels (16 bytes for bf16) of one tap; same walk as above
 // with kw_ = min(Kp / 8, 256) vector lanes
 template <typename T>
@@ -89,6 +111,7 @@ __global__ __launch_bounds__(256) void im2col_vec_kernel(const T* x, T* col, Con
 // (mfma_f32_32x32x16_bf16 x 4); the tile goes through LDS so that every lane stores 16 contiguous bytes, and the wave keeps
 // per-channel (sum, sum of squares) of the stored values: per-block partials -> stem_stats_finalize_kernel (fixed order).
 constexpr int STEM_TH = 8, STEM_TW = 128, STEM_PITCH = 160, STEM_ROWS = STEM_TH + 8, STEM_SP = 40;
+constexpr int STEM_DW_BLOCKS = 1024;      // workgroups (= partial blocks of 2048 floats) of the weight-gradient kernel
 __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ wp, const float* scale,
                                                             bf16_t* __restrict__ y, float* __restrict__ part, int H, int W, int N, int KH, int KW,
                                                             int P, int Kp) {
@@ -164,19 +187,90 @@ __global__ __launch_bounds__(256) void stem_conv_fwd_kernel(const bf16_t* __rest
         }
     }
 }
-// sums[b][g] = (sum, sum of squares) over the image's blocks and the group's channels, in a fixed order
-__global__ __launch_bounds__(64) void stem_stats_finalize_kernel(const float* part, double* sums, int nblk, int N, int G, int BG) {
-    const int i = blockIdx.x * 64 + threadIdx.x;
-    if (i >= BG) return;
+// sums[b][g] = (sum, sum of squares) over the image's blocks and the group's channels: one wave per (b, g), lane l takes
+// blocks l, l + 64, ... in order, then a shuffle tree -- a fixed order
+__global__ __launch_bounds__(64) void stem_stats_finalize_kernel(const float* part, double* sums, int nblk, int N, int G) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     const int b = i / G, g = i - b * G, Cg = N / G;
     double a = 0.0, q = 0.0;
-    for (int k = 0; k < nblk; ++k)
+    for (int k = lane; k < nblk; k += 64)
         for (int c = g * Cg; c < (g + 1) * Cg; ++c) {
             a += (double)part[(((long)b * nblk + k) * N + c) * 2 + 0];
             q += (double)part[(((long)b * nblk + k) * N + c) * 2 + 1];
         }
-    sums[(long)i * 2 + 0] = a;
-    sums[(long)i * 2 + 1] = q;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o, 64); q += __shfl_down(q, o, 64); }
+    if (lane == 0) { sums[(long)i * 2 + 0] = a; sums[(long)i * 2 + 1] = q; }
+}
+
+// Weight gradient of the stem without the im2col matrix: dW[n][kh*8 + kw] = sum_pixels dy[pixel][n] * x[pixel + (kh, kw) - P].
+// Same tiling and LDS window as the forward; the reduction runs over 16 consecutive pixels of a row per MFMA
+// (A = dy^T: lane -> channel n, 8 pixels, gathered from global memory where 32 lanes read one pixel's 64 contiguous bytes;
+// B = window: lane -> slot kh*8 + kw, 8 consecutive pixels of window row kh).  A workgroup walks tiles with a grid stride,
+// keeps the 32 x 64 sums of each wave in registers, combines its waves through LDS and writes one partial block;
+// stem_dw_finalize_kernel adds the blocks in order into the packed [N][Kp] layout (deterministic, no atomics).
+__global__ __launch_bounds__(256) void stem_conv_dw_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ dy, float* __restrict__ part,
+                                                           int B, int H, int W, int N, int n0, int P, int tiles_x, int tiles_y) {
+    __shared__ __attribute__((aligned(16))) bf16_t img[STEM_ROWS * STEM_PITCH];
+    __shared__ float red[4][2048];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ln = lane & 31, lh = lane >> 5;
+    const bf16_t zero = from_f32<bf16_t>(0.f);
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    const int ntiles = B * tiles_y * tiles_x;
+    const bool nok = n0 + ln < N;
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int b = t / (tiles_y * tiles_x), q = t - b * tiles_y * tiles_x;
+        const int h0 = (q / tiles_x) * STEM_TH, w0 = (q % tiles_x) * STEM_TW;
+        __syncthreads();                                   // the previous tile's window has been consumed
+        for (int i = tid; i < STEM_ROWS * (STEM_TW + 8); i += 256) {
+            const int r = i / (STEM_TW + 8), c = i - r * (STEM_TW + 8);
+            const int h = h0 - P + r, w = w0 - P + c;
+            bf16_t v = zero;
+            if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) v = x[((long)b * H + h) * W + w];
+            img[r * STEM_PITCH + c] = v;
+        }
+        __syncthreads();
+        for (int g = 0; g < 16; ++g) {
+            const int rr = wave * 2 + (g >> 3), c0 = (g & 7) * 16 + 8 * lh;
+            const int h = h0 + rr;
+            bf16x8 af, b0, b1;
+            const bf16_t* drow = dy + (((long)b * H + h) * W + w0 + c0) * N + n0 + ln;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) af[e] = (nok && h < H && w0 + c0 + e < W) ? drow[(long)e * N] : zero;
+            const bf16_t* s0 = img + (rr + (ln >> 3)) * STEM_PITCH + c0 + (ln & 7);
+            const bf16_t* s1 = s0 + 4 * STEM_PITCH;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { b0[e] = s0[e]; b1[e] = s1[e]; }
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, b1, acc1, 0, 0, 0);
+        }
+    }
+    // element (n, slot): n = (r & 3) + 8 * (r >> 2) + 4 * lh, slot = ln (acc0) / 32 + ln (acc1)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int n = (r & 3) + 8 * (r >> 2) + 4 * lh;
+        red[wave][n * 64 + ln] = acc0[r];
+        red[wave][n * 64 + 32 + ln] = acc1[r];
+    }
+    __syncthreads();
+    for (int i = tid; i < 2048; i += 256)
+        part[(long)blockIdx.x * 2048 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
+}
+// dW[n0 + n][kh*KW + kw] = sum over the blocks' partials [n][kh*8 + kw]; columns past KH*KW (row padding) are zeroed
+__global__ __launch_bounds__(256) void stem_dw_finalize_kernel(const float* part, float* dW, int nblk, int N, int n0, int KH, int KW, int Kp) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= 32 * Kp) return;
+    const int n = i / Kp, kk = i - n * Kp;
+    if (n0 + n >= N) return;
+    float a = 0.f;
+    if (kk < KH * KW) {
+        const int kh = kk / KW, kw = kk - kh * KW;
+        for (int k = 0; k < nblk; ++k) a += part[(long)k * 2048 + n * 64 + kh * 8 + kw];
+    }
+    dW[(long)(n0 + n) * Kp + kk] = a;
 }
 
 // gather form of col2im with 8 channels per lane: cw_ = min(C / 8, 256) vector lanes
@@ -881,7 +975,8 @@ int sgv_op_conv_out_shape(int H, int W, int C, int KH, int KW, int stride, int p
 }
 // one-input-channel stride-1 convolution + GroupNorm statistics of its output: see include/sgvae_ops.h
 size_t sgv_op_stem_conv_workspace_floats(int B, int H, int W, int N) {
-    return (size_t)B * cdivi(H, STEM_TH) * cdivi(W, STEM_TW) * (size_t)N * 2;
+    const size_t fwd = (size_t)B * cdivi(H, STEM_TH) * cdivi(W, STEM_TW) * (size_t)N * 2, bwd = (size_t)STEM_DW_BLOCKS * 2048;
+    return fwd > bwd ? fwd : bwd;
 }
 int sgv_op_stem_conv_fwd(const void* x, const void* wp, const float* scale, void* y, double* sums, float* part, int B, int H, int W, int N,
                          int KH, int KW, int pad, int G, void* stream) {
@@ -894,7 +989,7 @@ int sgv_op_stem_conv_fwd(const void* x, const void* wp, const float* scale, void
     const dim3 grid(cdivi(W, STEM_TW), cdivi(H, STEM_TH), B);
     hipLaunchKernelGGL(stem_conv_fwd_kernel, grid, dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(wp),
                        scale, reinterpret_cast<bf16_t*>(y), part, H, W, N, KH, KW, pad, Kp);
-    hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(cdivi(B * G, 64)), dim3(64), 0, ST(stream), part, sums, (int)(grid.x * grid.y), N, G, B * G);
+    hipLaunchKernelGGL(stem_stats_finalize_kernel, dim3(B * G), dim3(64), 0, ST(stream), part, sums, (int)(grid.x * grid.y), N, G);
     return OPLAUNCH_OK();
 }
 int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int C, int KH, int KW, int stride, int pad, void* stream) {
@@ -904,6 +999,11 @@ int sgv_op_im2col(int dtype, const void* x, void* col, int B, int H, int W, int 
     if (C % 8 == 0 && g.Kp % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)col)) & 31) == 0) {
         const int kv = g.Kp / 8, kwv = kv < 256 ? kv : 256, rpb = 256 / kwv;
         ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_vec_kernel<T>, dim3((unsigned)((Mrows + 32L * rpb - 1) / (32L * rpb)), cdivi(kv, kwv)), dim3(256), 0, ST(stream), CPT(x), PT(col), g, kwv));
+        return OPLAUNCH_OK();
+    }
+    if (C == 1 && g.Kp % 8 == 0 && (((uintptr_t)col) & 31) == 0) {
+        const long pieces = Mrows * (g.Kp / 8);
+        ON_DTYPE(dtype, hipLaunchKernelGGL(im2col_c1_kernel<T>, dim3((unsigned)std::min<long>((pieces + 255) / 256, 1L << 20)), dim3(256), 0, ST(stream), CPT(x), PT(col), g));
         return OPLAUNCH_OK();
     }
     const int kw_ = g.Kp < 256 ? g.Kp : 256, rows_pb = 256 / kw_;
@@ -1009,6 +1109,19 @@ int sgv_op_gn_fwd(int dtype, int act, const void* y, void* out, int B, int P, in
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
     p.out = out; p.ldout = C; p.part = part;
     if (ew_gn_fwd(dtype, act, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_fwd: launch failed");
+    return OPLAUNCH_OK();
+}
+// weight gradient of the stem convolution, packed layout [N][Kp] fp32: see include/sgvae_ops.h
+int sgv_op_stem_conv_dw(const void* x, const void* dy, float* dW, float* part, int B, int H, int W, int N, int KH, int KW, int pad, void* stream) {
+    OPCHK(x && dy && dW && part && B > 0 && H > 0 && W > 0 && N > 0, "sgv_op_stem_conv_dw: bad argument");
+    OPCHK(KH >= 1 && KH <= 7 && KH == KW && 2 * pad == KH - 1, "sgv_op_stem_conv_dw: square odd windows up to 7x7 with 'same' padding only (got %dx%d pad %d)", KH, KW, pad);
+    const int Kp = (KH * KW + 7) / 8 * 8, tx = cdivi(W, STEM_TW), ty = cdivi(H, STEM_TH);
+    const int nblk = std::min(B * tx * ty, STEM_DW_BLOCKS);
+    for (int n0 = 0; n0 < N; n0 += 32) {
+        hipLaunchKernelGGL(stem_conv_dw_kernel, dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy),
+                           part, B, H, W, N, n0, pad, tx, ty);
+        hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3(cdivi(32 * Kp, 256)), dim3(256), 0, ST(stream), part, dW, nblk, N, n0, KH, KW, Kp);
+    }
     return OPLAUNCH_OK();
 }
 // out = act(gn(y)) with the statistics given (sgv_op_stem_conv_fwd leaves them)

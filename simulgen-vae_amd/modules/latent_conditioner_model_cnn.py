@@ -309,9 +309,10 @@ class LatentConditionerImg:
             dy = dy4.reshape(-1, co)
             if implicit:
                 G = ops.conv_weight_unpack(ops.conv2d_tn(dy4.reshape(B, Ho, Wo, co), x4, k, k, stride, pad), W.shape)
+            elif stem:
+                G = ops.conv_weight_unpack(ops.stem_conv_dw(x4.view(B, H, Wd), dy4.reshape(B, Ho, Wo, co), k, pad), W.shape)
             else:
-                colb = col if col is not None else ops.im2col(x4, k, k, stride, pad)[0]      # stem: the matrix exists in backward only
-                G = ops.conv_weight_unpack(ops.gemm_tn(dy, colb), W.shape)      # gradient wrt W / sigma
+                G = ops.conv_weight_unpack(ops.gemm_tn(dy, col), W.shape)       # gradient wrt W / sigma
             if sig2 is None:
                 self._acc(prefix + ".weight_orig", G)                            # chain rule applied by the fused step
             else:

@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_workspace_floats",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_dw", "sgv_op_stem_conv_workspace_floats",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -47,6 +47,7 @@ def lib():
             "sgv_op_gn_apply": [i, i, vp, vp, i, i, i, i, vp, vp, vp, vp],
             "sgv_op_stem_conv_workspace_floats": [i, i, i, i],
             "sgv_op_stem_conv_fwd": [vp] * 6 + [i] * 8 + [vp],
+            "sgv_op_stem_conv_dw": [vp] * 4 + [i] * 7 + [vp],
             "sgv_op_gn_tail": [i] + [vp] * 10 + [i, i, i, i, vp, vp],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
             "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
@@ -228,6 +229,18 @@ def stem_conv(x, wp, N, k, pad, G, scale=None):
            lambda: _ck(lib().sgv_op_stem_conv_fwd(_p(x), _p(wp), _p(scale), _p(y), _p(sums), _p(part), B, H, W, N, k, k, pad, G, _stream()),
                        "sgv_op_stem_conv_fwd"))
     return y, sums
+
+
+def stem_conv_dw(x, dy, k, pad):
+    """Weight gradient of the stem convolution (sgv_op_stem_conv_dw): x [B, H, W] bf16, dy [B, H, W, N] bf16 -> fp32
+    [N, roundup(k*k, 8)] in the packed layout."""
+    B, H, W = x.shape
+    N = dy.shape[-1]
+    out = torch.empty((N, (k * k + 7) // 8 * 8), dtype=torch.float32, device=x.device)
+    part = torch.empty(int(lib().sgv_op_stem_conv_workspace_floats(B, H, W, N)), dtype=torch.float32, device=x.device)
+    _timed("gemm_tn", 2.0 * B * H * W * N * k * k,
+           lambda: _ck(lib().sgv_op_stem_conv_dw(_p(x), _p(dy), _p(out), _p(part), B, H, W, N, k, k, pad, _stream()), "sgv_op_stem_conv_dw"))
+    return out
 
 
 def gn_apply(y, G, gamma, beta, sums, act):

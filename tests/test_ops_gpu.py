@@ -126,8 +126,9 @@ def test_groupnorm_relu(dt, cfg):
 
 @pytest.mark.parametrize("cfg", [(2, 20, 24, 32, 7), (1, 37, 150, 32, 7), (2, 16, 16, 64, 5), (3, 9, 130, 16, 3), (1, 300, 260, 32, 7)])
 def test_stem_convolution_direct(cfg):
-    """sgv_op_stem_conv_fwd (one input channel, bf16): the convolution against F.conv2d in fp32 on the CPU, and the GroupNorm
-    statistics it leaves against sgv_op_gn_fwd's on the same stored output."""
+    """sgv_op_stem_conv_fwd / sgv_op_stem_conv_dw (one input channel, bf16): the convolution and its weight gradient against
+    F.conv2d and its autograd in fp32 on the CPU, and the GroupNorm statistics the forward leaves against sgv_op_gn_fwd's on
+    the same stored output."""
     B, H, W, N, k = cfg
     dt = torch.bfloat16
     g = torch.Generator().manual_seed(11)
@@ -142,6 +143,12 @@ def test_stem_convolution_direct(cfg):
                             scale=torch.tensor([0.7], device="cuda"))
     assert tuple(y.shape) == (B, H, W, N)
     assert rel(nchw(y), ref) < TOL[dt]
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    dyr = q(torch.randn(ref.shape, generator=g), dt)
+    F.conv2d(xr, wr, None, 1, k // 2).backward(dyr)
+    dW = ops.stem_conv_dw(x[:, 0].contiguous().to(device="cuda", dtype=dt), nhwc(dyr, dt), k, k // 2)
+    assert tuple(dW.shape) == (N, kp) and float(dW[:, k * k:].abs().max() if kp > k * k else 0.0) == 0.0
+    assert rel(dW[:, :k * k], wr.grad.reshape(N, -1)) < TOL[dt]
     _, sums_ref = ops.gn_fwd(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), ops.ACT_NONE)
     assert rel(sums, sums_ref) < 1e-5
     out = ops.gn_apply(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), sums, ops.ACT_RELU_GN)
