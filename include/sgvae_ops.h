@@ -82,6 +82,13 @@ int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy,
 /* nn.MaxPool2d(3, 2, 1) (model_cnn.py:189); argmax: one byte per output element (window position of the first
  * maximum, may be NULL in the forward when no backward follows). */
 int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* argmax, int B, int H, int W, int C, void* stream);
+/* The stem's GroupNorm + ReLU + MaxPool (model_cnn.py:94-96,189) in one pass over the convolution output y [B][H][W][C]:
+ * out = maxpool(relu(gn(y; sums, gamma, beta))) with every normalised value rounded to the compute dtype first (the result and
+ * argmax equal sgv_op_gn_apply followed by sgv_op_maxpool_fwd); sums as left by sgv_op_gn_fwd / sgv_op_stem_conv_fwd,
+ * coef: 2*B*C floats of scratch.  The normalised activation itself is not stored: the backward (sgv_op_maxpool_bwd,
+ * sgv_op_gn_bwd with act = relu) needs only argmax, y and sums. */
+int sgv_op_gn_relu_maxpool_fwd(int dtype, const void* y, const double* sums, const float* gamma, const float* beta, int G, void* out,
+                               unsigned char* argmax, float* coef, int B, int H, int W, int C, void* stream);
 int sgv_op_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int B, int H, int W, int C, void* stream);
 /* out = relu(a + b) (model_cnn.py:131-132) and d = dout * (out > 0); plain add for gradient joins. */
 int sgv_op_add_relu_fwd(int dtype, const void* a, const void* b, void* out, long n, void* stream);

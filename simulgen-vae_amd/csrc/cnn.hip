@@ -260,17 +260,19 @@ __global__ __launch_bounds__(256) void stem_conv_dw_kernel(const bf16_t* __restr
         part[(long)blockIdx.x * 2048 + i] = red[0][i] + red[1][i] + red[2][i] + red[3][i];
 }
 // dW[n0 + n][kh*KW + kw] = sum over the blocks' partials [n][kh*8 + kw]; columns past KH*KW (row padding) are zeroed
-__global__ __launch_bounds__(256) void stem_dw_finalize_kernel(const float* part, float* dW, int nblk, int N, int n0, int KH, int KW, int Kp) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= 32 * Kp) return;
+// (one wave per output: lane l adds blocks l, l + 64, ... in order, then a shuffle tree -- a fixed order)
+__global__ __launch_bounds__(64) void stem_dw_finalize_kernel(const float* part, float* dW, int nblk, int N, int n0, int KH, int KW, int Kp) {
+    const int i = blockIdx.x, lane = threadIdx.x;
     const int n = i / Kp, kk = i - n * Kp;
     if (n0 + n >= N) return;
     float a = 0.f;
     if (kk < KH * KW) {
         const int kh = kk / KW, kw = kk - kh * KW;
-        for (int k = 0; k < nblk; ++k) a += part[(long)k * 2048 + n * 64 + kh * 8 + kw];
+        for (int k = lane; k < nblk; k += 64) a += part[(long)k * 2048 + n * 64 + kh * 8 + kw];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) a += __shfl_down(a, o, 64);
     }
-    dW[(long)(n0 + n) * Kp + kk] = a;
+    if (lane == 0) dW[(long)(n0 + n) * Kp + kk] = a;
 }
 
 // gather form of col2im with 8 channels per lane: cw_ = min(C / 8, 256) vector lanes
@@ -368,8 +370,11 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* x, T* y, unsi
     }
 }
 // 8 channels per lane (C % 8 == 0): same results, 16-byte loads / stores and one 8-byte arg-max store per lane
+// coef != null: x is a pre-norm convolution output and every element is first taken through relu(x * ka + kb) with the
+// per-(image, channel) GroupNorm coefficients coef[0][b][c] = ka, coef[1][b][c] = kb, rounded to T like the stored
+// activation it replaces (sgv_op_gn_relu_maxpool_fwd: the stem's GroupNorm + ReLU + MaxPool in one pass)
 template <typename T>
-__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const T* x, T* y, unsigned char* idx, ConvGeom g) {
+__global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const T* x, T* y, unsigned char* idx, ConvGeom g, const float* coef = nullptr) {
     const int cv = g.C / 8;
     const long total = (long)g.B * g.Ho * g.Wo * cv;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
@@ -377,6 +382,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const T* x, T* y, 
         const long m = i / cv;
         const int ow = (int)(m % g.Wo), oh = (int)((m / g.Wo) % g.Ho), b = (int)(m / ((long)g.Wo * g.Ho));
         float best[8]; int pos[8];
+        float ka[8], kb[8];
+        if (coef) { load8(coef + (long)b * g.C + c0, ka); load8(coef + ((long)g.B + b) * g.C + c0, kb); }
 #pragma unroll
         for (int e = 0; e < 8; ++e) { best[e] = -INFINITY; pos[e] = -1; }
 #pragma unroll
@@ -389,6 +396,10 @@ __global__ __launch_bounds__(256) void maxpool_fwd_vec_kernel(const T* x, T* y, 
                 if ((unsigned)w >= (unsigned)g.W) continue;
                 float v[8];
                 load8(x + (((long)b * g.H + h) * g.W + w) * g.C + c0, v);
+                if (coef) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) v[e] = to_f32(from_f32<T>(fmaxf(v[e] * ka[e] + kb[e], 0.f)));
+                }
 #pragma unroll
                 for (int e = 0; e < 8; ++e)
                     if (v[e] > best[e] || pos[e] < 0) { best[e] = v[e]; pos[e] = kh * 3 + kw; }
@@ -1027,10 +1038,34 @@ int sgv_op_maxpool_fwd(int dtype, const void* x, void* y, unsigned char* argmax,
     OPCHK(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_maxpool_fwd: bad argument");
     const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
     if (C % 8 == 0 && vec8_count(8, x, y, argmax)) {
-        ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_vec_kernel<T>, grid1((long)B * g.Ho * g.Wo * (C / 8)), dim3(256), 0, ST(stream), CPT(x), PT(y), argmax, g));
+        ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_vec_kernel<T>, grid1((long)B * g.Ho * g.Wo * (C / 8)), dim3(256), 0, ST(stream), CPT(x), PT(y), argmax, g, (const float*)nullptr));
         return OPLAUNCH_OK();
     }
     ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_kernel<T>, grid1((long)B * g.Ho * g.Wo * C), dim3(256), 0, ST(stream), CPT(x), PT(y), argmax, g));
+    return OPLAUNCH_OK();
+}
+// ka = rstd * gamma, kb = beta - mean * rstd * gamma per (image, channel) from the GroupNorm statistics (eps 1e-5, as ew.hip)
+__global__ __launch_bounds__(256) void gn_coef_kernel(const double* sums, const float* gamma, const float* beta, float* coef, int B, int C, int G, double n) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, g = c / (C / G);
+    const double s = sums[((long)b * G + g) * 2 + 0], ss = sums[((long)b * G + g) * 2 + 1];
+    const double m = s / n;
+    double var = ss / n - m * m;
+    if (var < 0.0) var = 0.0;
+    const float mean = (float)m, rstd = (float)(1.0 / sqrt(var + 1e-5));
+    const float ga = gamma[c];
+    coef[i] = rstd * ga;
+    coef[(long)B * C + i] = beta[c] - mean * rstd * ga;
+}
+// relu(gn(y)) then MaxPool2d(3, 2, 1) in one pass over y: see include/sgvae_ops.h
+int sgv_op_gn_relu_maxpool_fwd(int dtype, const void* y, const double* sums, const float* gamma, const float* beta, int G, void* out,
+                               unsigned char* argmax, float* coef, int B, int H, int W, int C, void* stream) {
+    OPCHK(y && sums && gamma && beta && out && coef && B > 0 && H > 0 && W > 0 && C > 0, "sgv_op_gn_relu_maxpool_fwd: bad argument");
+    OPCHK(C % 8 == 0 && G >= 1 && C % G == 0 && vec8_count(8, y, out, argmax), "sgv_op_gn_relu_maxpool_fwd: C %% 8 == 0, C %% G == 0 and 16-byte aligned buffers required");
+    const ConvGeom g = mk_geom(B, H, W, C, 3, 3, 2, 1);
+    hipLaunchKernelGGL(gn_coef_kernel, dim3(cdivi((long)B * C, 256)), dim3(256), 0, ST(stream), sums, gamma, beta, coef, B, C, G, (double)(C / G) * H * W);
+    ON_DTYPE(dtype, hipLaunchKernelGGL(maxpool_fwd_vec_kernel<T>, grid1((long)B * g.Ho * g.Wo * (C / 8)), dim3(256), 0, ST(stream), CPT(y), PT(out), argmax, g, (const float*)coef));
     return OPLAUNCH_OK();
 }
 int sgv_op_maxpool_bwd(int dtype, const unsigned char* argmax, const void* dy, void* dx, int B, int H, int W, int C, void* stream) {
@@ -1120,7 +1155,7 @@ int sgv_op_stem_conv_dw(const void* x, const void* dy, float* dW, float* part, i
     for (int n0 = 0; n0 < N; n0 += 32) {
         hipLaunchKernelGGL(stem_conv_dw_kernel, dim3(nblk), dim3(256), 0, ST(stream), reinterpret_cast<const bf16_t*>(x), reinterpret_cast<const bf16_t*>(dy),
                            part, B, H, W, N, n0, pad, tx, ty);
-        hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3(cdivi(32 * Kp, 256)), dim3(256), 0, ST(stream), part, dW, nblk, N, n0, KH, KW, Kp);
+        hipLaunchKernelGGL(stem_dw_finalize_kernel, dim3(32 * Kp), dim3(64), 0, ST(stream), part, dW, nblk, N, n0, KH, KW, Kp);
     }
     return OPLAUNCH_OK();
 }

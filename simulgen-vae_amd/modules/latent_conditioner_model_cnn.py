@@ -487,10 +487,17 @@ class LatentConditionerImg:
         x4 = x.to(self.dt).contiguous().view(B, side, side, 1)
         c0, bw = self._conv("initial_conv.0", x4, 7, 1, 3, need_dx=False)
         back.append(bw)
-        a0, bw = self._gn("initial_conv.1", c0, ops.ACT_RELU_GN, sums=self._conv_sums)
-        back.append(bw)
-        h, pool_idx = ops.maxpool_fwd(a0)
-        back.append(lambda d, idx=pool_idx, shp=tuple(a0.shape): ops.maxpool_bwd(idx, d, shp))
+        if self._conv_sums is not None and self.fused_tail:
+            # GroupNorm + ReLU + MaxPool in one pass over the convolution output (the normalised activation is never stored:
+            # the backward needs the arg-max, the convolution output and its statistics only)
+            h, pool_idx = ops.gn_relu_maxpool_fwd(c0, _num_groups(c0.shape[-1]), self.P["initial_conv.1.weight"], self.P["initial_conv.1.bias"],
+                                                  self._conv_sums)
+            back.append(self._gn_bwd("initial_conv.1", c0, self._conv_sums, ops.ACT_RELU_GN))
+        else:
+            a0, bw = self._gn("initial_conv.1", c0, ops.ACT_RELU_GN, sums=self._conv_sums)
+            back.append(bw)
+            h, pool_idx = ops.maxpool_fwd(a0)
+        back.append(lambda d, idx=pool_idx, shp=tuple(c0.shape): ops.maxpool_bwd(idx, d, shp))
         for b in self.blocks:
             h, bw = self._block(b, h)
             back.append(bw)

@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_dw", "sgv_op_stem_conv_workspace_floats",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_dw", "sgv_op_gn_relu_maxpool_fwd", "sgv_op_stem_conv_workspace_floats",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -51,6 +51,7 @@ def lib():
             "sgv_op_gn_tail": [i] + [vp] * 10 + [i, i, i, i, vp, vp],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
             "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_gn_relu_maxpool_fwd": [i, vp, vp, vp, vp, i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_maxpool_bwd": [i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_add_relu_fwd": [i, vp, vp, vp, lg, vp],
             "sgv_op_relu_bwd": [i, vp, vp, vp, lg, vp],
@@ -281,6 +282,18 @@ def maxpool_fwd(x):
     idx = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=x.device)
     _ck(lib().sgv_op_maxpool_fwd(_d(x), _p(x), _p(y), _p(idx), B, H, W, Cc, _stream()), "sgv_op_maxpool_fwd")
     return y, idx
+
+
+def gn_relu_maxpool_fwd(y, G, gamma, beta, sums):
+    """maxpool(relu(gn(y))) in one pass (sgv_op_gn_relu_maxpool_fwd): y [B, H, W, C] pre-norm, sums its statistics -> (out, argmax)."""
+    B, H, W, Cc = y.shape
+    Ho, Wo, _ = conv_out_shape(H, W, Cc, 3, 3, 2, 1)
+    out = torch.empty((B, Ho, Wo, Cc), dtype=y.dtype, device=y.device)
+    idx = torch.empty((B, Ho, Wo, Cc), dtype=torch.uint8, device=y.device)
+    coef = torch.empty(2 * B * Cc, dtype=torch.float32, device=y.device)
+    _ck(lib().sgv_op_gn_relu_maxpool_fwd(_d(y), _p(y), _p(sums), _p(gamma), _p(beta), G, _p(out), _p(idx), _p(coef), B, H, W, Cc, _stream()),
+        "sgv_op_gn_relu_maxpool_fwd")
+    return out, idx
 
 
 def maxpool_bwd(idx, dy, in_shape):

@@ -151,9 +151,16 @@ def test_stem_convolution_direct(cfg):
     assert rel(dW[:, :k * k], wr.grad.reshape(N, -1)) < TOL[dt]
     _, sums_ref = ops.gn_fwd(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), ops.ACT_NONE)
     assert rel(sums, sums_ref) < 1e-5
-    out = ops.gn_apply(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), sums, ops.ACT_RELU_GN)
-    out_ref, _ = ops.gn_fwd(y.view(B, H * W, N), G, torch.ones(N, device="cuda"), torch.zeros(N, device="cuda"), ops.ACT_RELU_GN)
+    gam, bet = (torch.randn(N, generator=g) * 0.5 + 1).cuda(), (torch.randn(N, generator=g) * 0.3).cuda()
+    out = ops.gn_apply(y.view(B, H * W, N), G, gam, bet, sums, ops.ACT_RELU_GN)
+    out_ref, _ = ops.gn_fwd(y.view(B, H * W, N), G, gam, bet, ops.ACT_RELU_GN)
     assert rel(out, out_ref) < 1e-2
+    # GroupNorm + ReLU + MaxPool in one pass against the two operators it replaces (same roundings; a last-bit difference of the
+    # coefficients can flip a rounding, and with it an arg-max between two near-equal window elements)
+    pooled_ref, idx_ref = ops.maxpool_fwd(out.view(B, H, W, N))
+    pooled, idx = ops.gn_relu_maxpool_fwd(y, G, gam, bet, sums)
+    assert rel(pooled, pooled_ref) < 1e-2
+    assert float((pooled.float() != pooled_ref.float()).float().mean()) < 5e-3 and float((idx != idx_ref).float().mean()) < 5e-3
 
 
 @pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
