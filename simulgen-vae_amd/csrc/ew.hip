@@ -441,7 +441,7 @@ __global__ __launch_bounds__(1024) void gn_bwd_finalize_kernel(const GNParams p,
     if (lanes) {
         int ncp = 1;
         while (ncp < ncol) ncp <<= 1;
-        const int RLn = 1024 / ncp, ci = threadIdx.x % ncp, rl = threadIdx.x / ncp;
+        const int RLn = (int)blockDim.x / ncp, ci = threadIdx.x % ncp, rl = threadIdx.x / ncp;      // gn_finalize: 256 threads here
         float A = 0.f, Bv = 0.f, X = 0.f;
         if (ci < ncol)
             for (int r = rl; r < RS; r += RLn) {
@@ -1039,7 +1039,10 @@ static void gn_fin_immediate(const GNParams& p, bool own_ptot, bool own_dots, in
 }
 static void gn_finalize(GNParams p, hipStream_t s) {
     GNGeom g_ = gn_geom(p.B, p.T, p.C, GN_REDUCE_TARGET);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(1024), 0, s, p, g_.rowsplit);
+    // narrow groups (the kernel's `lanes` path, <= 128 columns): a few dozen row blocks x a few columns per (group, sample) --
+    // 256 threads cover them and the block's two reductions cost a quarter of the barriers' wave count
+    const int ncol_max = p.C - (p.G - 1) * p.Cg > p.Cg ? p.C - (p.G - 1) * p.Cg : p.Cg;
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(p.G, p.B), dim3(ncol_max <= 128 ? 256 : 1024), 0, s, p, g_.rowsplit);
 }
 // p.sums[b][g] = (sum, sum of squares), overwritten; p.part = workspace (ew_gn_part_floats)
 int ew_gn_stats(int dtype, GNParams p, hipStream_t s) {
