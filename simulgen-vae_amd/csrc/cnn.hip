@@ -1,7 +1,10 @@
 // Operator-level C ABI for the image latent conditioner (reference
-// modules/latent_conditioner_model_cnn.py:28-362): 2-D convolutions as im2col + the MFMA GEMMs of gemm.hip,
-// GroupNorm(+ReLU) through the kernels of ew.hip, max-pool, squeeze-excitation, residual add+ReLU and the small
-// fp32 layers of the prediction heads (Linear, LayerNorm, BatchNorm1d, dropout with an injected mask, MSE).
+// modules/latent_conditioner_model_cnn.py:28-362): 2-D convolutions as implicit GEMMs on the MFMA kernels of gemm.hip /
+// gemm256.hip (2-D tap mode; sgv_op_conv2d_nt / sgv_op_conv2d_tn), the one-channel stem as a direct MFMA convolution with
+// its GroupNorm statistics and its weight gradient (stem_conv_*), the im2col / col2im lowering they replace (still the path
+// of fp32 stems, stride-2 input gradients and the A/B comparator), GroupNorm(+ReLU) through the kernels of ew.hip incl. the
+// one-pass block tail and GroupNorm + ReLU + max-pool, max-pool, squeeze-excitation, residual add+ReLU and the small fp32
+// layers of the prediction heads (Linear, LayerNorm, BatchNorm1d, dropout with an injected mask, MSE).
 // Feature maps are channels-last [B][H][W][C] (= [B*H*W][C] rows, compute dtype bf16 or fp32), so a 1x1 convolution
 // is a plain GEMM and GroupNorm sees the same [rows][C] layout as in the VAE; everything [B][features] is fp32.
 // Stateless entry points on caller-owned device buffers; the host-side mirror

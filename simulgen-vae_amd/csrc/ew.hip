@@ -623,23 +623,35 @@ int ew_fin_dots(const FinDot* items, int n, hipStream_t s) {
     }
     return 0;
 }
-// GroupNorm affine + conv bias gradients: one thread per (item, column) sums the per-sample totals in sample order
+// GroupNorm affine + conv bias gradients: a block takes 32 columns of one item; row lane r (of 8) adds the per-sample / per-block
+// totals r, r + 8, ... in order and the lanes are combined in lane order -- a fixed order.  (One thread per column walking all
+// the rows left a 5120-column layer with 256 row blocks on 20 workgroups, 0.3 ms of pure load latency per step.)
 struct FinAffineArgs { int n; int chunk0[FIN_MAX_ITEMS + 1]; FinAffine it[FIN_MAX_ITEMS]; };
+constexpr int FIN_COLS = 32, FIN_LANES = 8;
 __global__ __launch_bounds__(256) void fin_affine_kernel(const FinAffineArgs a) {
+    __shared__ float sm[3][FIN_LANES][FIN_COLS];
     int i = 0;
     while (i + 1 < a.n && (int)blockIdx.x >= a.chunk0[i + 1]) ++i;
     const FinAffine it = a.it[i];
-    const int c = ((int)blockIdx.x - a.chunk0[i]) * 256 + threadIdx.x;
-    if (c >= it.C) return;
+    const int cl = threadIdx.x % FIN_COLS, rl = threadIdx.x / FIN_COLS;
+    const int c = ((int)blockIdx.x - a.chunk0[i]) * FIN_COLS + cl;
     float A = 0.f, Bv = 0.f, D = 0.f;
-    if (it.arrays == 1) {                 // [B][C] column-sum partials (bias gradient of a convolution without GroupNorm)
-        for (int b = 0; b < it.B; ++b) A += it.ptot[(long)b * it.C + c];
-    } else {
-        for (int b = 0; b < it.B; ++b) {
-            const float* pt = it.ptot + (long)b * 3 * it.C + c;
-            A += pt[0]; Bv += pt[it.C]; D += pt[2L * it.C];
+    if (c < it.C) {
+        if (it.arrays == 1) {             // [B][C] column-sum partials (bias gradient of a convolution without GroupNorm)
+            for (int b = rl; b < it.B; b += FIN_LANES) A += it.ptot[(long)b * it.C + c];
+        } else {
+            for (int b = rl; b < it.B; b += FIN_LANES) {
+                const float* pt = it.ptot + (long)b * 3 * it.C + c;
+                A += pt[0]; Bv += pt[it.C]; D += pt[2L * it.C];
+            }
         }
     }
+    sm[0][rl][cl] = A; sm[1][rl][cl] = Bv; sm[2][rl][cl] = D;
+    __syncthreads();
+    if (rl != 0 || c >= it.C) return;
+    A = Bv = D = 0.f;
+#pragma unroll
+    for (int r = 0; r < FIN_LANES; ++r) { A += sm[0][r][cl]; Bv += sm[1][r][cl]; D += sm[2][r][cl]; }
     if (it.dbeta) it.dbeta[c] = (it.accum ? it.dbeta[c] : 0.f) + A;
     if (it.dgamma) it.dgamma[c] = (it.accum ? it.dgamma[c] : 0.f) + Bv;
     if (it.dbias) it.dbias[c] = (it.accum ? it.dbias[c] : 0.f) + D;
@@ -648,7 +660,7 @@ int ew_fin_affine(const FinAffine* items, int n, hipStream_t s) {
     for (int i0 = 0; i0 < n; i0 += FIN_MAX_ITEMS) {
         FinAffineArgs a; a.n = std::min(n - i0, FIN_MAX_ITEMS);
         int ch = 0;
-        for (int i = 0; i < a.n; ++i) { a.it[i] = items[i0 + i]; a.chunk0[i] = ch; ch += cdiv_i(a.it[i].C, 256); }
+        for (int i = 0; i < a.n; ++i) { a.it[i] = items[i0 + i]; a.chunk0[i] = ch; ch += cdiv_i(a.it[i].C, FIN_COLS); }
         a.chunk0[a.n] = ch;
         if (ch > 0) hipLaunchKernelGGL(fin_affine_kernel, dim3(ch), dim3(256), 0, s, a);
     }

@@ -2,8 +2,10 @@
 modules.latent_conditioner_model_cnn.LatentConditionerImg (latent_conditioner_model_cnn.py:138-362), on the MI355X.
 
 The layer graph and its hand-derived backward live here on the host; every tensor operation is a HIP kernel behind the
-operator-level C ABI (include/sgvae_ops.h, `simulgen_vae_amd.ops`): convolutions are im2col + the MFMA GEMMs of the VAE
-path, feature maps are channels-last [B, H, W, C] in the compute dtype, the heads are fp32.  torch supplies device
+operator-level C ABI (include/sgvae_ops.h, `simulgen_vae_amd.ops`): convolutions are implicit GEMMs on the MFMA kernels of
+the VAE path (no im2col matrix; SGV_LC_IMPLICIT=0 restores the im2col lowering), the tail of a residual block and the stem's
+GroupNorm + ReLU + max-pool are single passes (SGV_LC_FUSED_TAIL=0: separate operators), feature maps are channels-last
+[B, H, W, C] in the compute dtype, the heads are fp32.  torch supplies device
 memory, the stream and the random bits of the dropout masks -- nothing else (the two data-dependent input-range lines
 of the reference forward, `if x.min() < -0.1: x = (x + 1) / 2`, are kept as a torch expression on the input batch).
 

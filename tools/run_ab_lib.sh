@@ -1,8 +1,8 @@
 #!/bin/bash
 # default bench with the library of the previous commit (tests/micro/ab/libsgvae_prev.so, built by hand) and the current one, interleaved
-O=gpurun_out/${1:-ablib}; mkdir -p $O
-for i in 1 2; do
-  SGV_LIB=$PWD/tests/micro/ab/libsgvae_prev.so python3 bench.py --steps 30 --warmup 5 --cpu-baseline skip > $O/prev$i.json 2> $O/prev$i.err || exit 1
-  python3 bench.py --steps 30 --warmup 5 --cpu-baseline skip > $O/cur$i.json 2> $O/cur$i.err || exit 1
+O=gpurun_out/${1:-ablib}; mkdir -p $O; N=${2:-2}
+for i in $(seq 1 $N); do
+  SGV_LIB=$PWD/tests/micro/ab/libsgvae_prev.so python3 bench.py --steps 40 --warmup 5 --cpu-baseline skip > $O/prev$i.json 2> $O/prev$i.err || exit 1
+  python3 bench.py --steps 40 --warmup 5 --cpu-baseline skip > $O/cur$i.json 2> $O/cur$i.err || exit 1
 done
-for f in prev1 cur1 prev2 cur2; do echo -n "$f "; python3 -c "import json,sys; d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"; done
+for i in $(seq 1 $N); do for f in prev$i cur$i; do echo -n "$f "; python3 -c "import json,sys; d=json.loads(open('$O/$f.json').read().strip().splitlines()[-1]); print(d['value'], d['ms_per_step'], d['roofline']['frac'])"; done; done
