@@ -140,7 +140,7 @@ def bench_latent_conditioner(args):
                       "filters": filters, "image": side, "per_gpu_batch": B},
            "step_tflops": round(3 * fwd_gf * (B / 16) / (el / args.steps) / 1e3, 2) if fwd_gf else None, "roofline": None, "cpu_baseline": None}
     # roofline of the dominant GEMM class: events on torch's current stream (the operators' stream) around every GEMM operator
-    # call of two extra steps; algorithmic FLOPs 2*M*N*K per call (convolutions = im2col rows x K = kh*kw*Cin)
+    # call of two extra steps; algorithmic FLOPs 2*M*N*K per call (convolutions: M = output pixels, K = kh*kw*Cin)
     from simulgen_vae_amd import ops as _ops
     _ops.GEMM_TIMING = []
     for _ in range(2):
@@ -156,8 +156,10 @@ def bench_latent_conditioner(args):
         st = cls.setdefault(c, [0.0, 0.0, 0])
         st[0] += fl; st[1] += e0.elapsed_time(e1); st[2] += 1
     _ops.GEMM_TIMING = None
-    names = {"gemm_nt": "gemm_nt_t256_kernel / gemm_nt_kernel (convolution forward and input-gradient GEMMs on im2col rows, sgv_op_gemm_nt)",
-             "gemm_tn": "gemm_tn_w2_kernel / gemm_tn_kernel (weight-gradient GEMMs: a million rows reduced into a small matrix, split-K slabs)"}
+    names = {"gemm_nt": "gemm_nt_t256_kernel / gemm_nt_kernel (convolution forward and input-gradient contractions: implicit GEMMs with 2-D taps, "
+                        "1x1 layers as plain GEMMs, the direct one-channel stem; sgv_op_conv2d_nt / sgv_op_gemm_nt / sgv_op_stem_conv_fwd)",
+             "gemm_tn": "gemm_tn_w2_kernel / gemm_tn_kernel (weight-gradient contractions through a virtual im2col operand: up to a million rows "
+                        "reduced into a small matrix, split-K slabs; sgv_op_conv2d_tn / sgv_op_gemm_tn / sgv_op_stem_conv_dw)"}
     traffic = load_traffic()
     for c, (fl, tms, calls) in sorted(cls.items(), key=lambda kv: -kv[1][1]):
         ach = fl / (tms * 1e-3) / 1e12

@@ -93,10 +93,10 @@ def traffic_lc(fetch_csv, write_csv):
         corr = 2.0 if name == "FETCH_SIZE" else 1.0
         for x in rows:
             k = x["Kernel_Name"]
-            if "gemm_tn" in k or "sum_slabs" in k:
-                fam, main = "lc_gemm_tn", "gemm_tn" in k
-            elif "gemm_nt" in k or "t256_reduce" in k:
-                fam, main = "lc_gemm_nt", ("reduce" not in k)
+            if "gemm_tn" in k or "sum_slabs" in k or "stem_conv_dw" in k or "stem_dw_finalize" in k:
+                fam, main = "lc_gemm_tn", ("gemm_tn" in k or "stem_conv_dw" in k)
+            elif "gemm_nt" in k or "t256_reduce" in k or "stem_conv_fwd" in k or "stem_stats_finalize" in k:
+                fam, main = "lc_gemm_nt", ("reduce" not in k and "finalize" not in k)
             else:
                 continue
             d = out.setdefault(fam, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
