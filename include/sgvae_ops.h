@@ -104,7 +104,7 @@ int sgv_op_chan_scale_bwd(int dtype, const void* x, const float* s, const void* 
 
 /* Small fp32 layers of the SE blocks and heads (model_cnn.py:41-50,220-277).
  * linear: y = act(scale[0] * x W^T + bias), act: 0 none, 1 relu, 2 sigmoid; act_bwd: dz = dy * act'(y) from the stored
- * output; linear_bwd: dx (= or +=) scale * dz W, dW = scale * dz^T x, db = sum_b dz (dx, db may be NULL). */
+ * output; linear_bwd: dx (= or +=) scale * dz W, dW = scale * dz^T x, db = sum_b dz (dx, db may be NULL; dW and db NULL: dx only). */
 int sgv_op_linear_fwd(const float* x, const float* W, const float* bias, const float* scale, float* y, int B, int K, int O, int act, void* stream);
 int sgv_op_act_fwd(const float* x, float* y, long n, int act, void* stream);
 int sgv_op_act_bwd(const float* y, const float* dy, float* dz, long n, int act, void* stream);

@@ -367,10 +367,13 @@ class LatentConditionerImg:
 
         def bwd(dy):
             dz = ops.act_bwd(y, dy, act) if act != ops.LIN_NONE else dy
-            dx, dW, db = ops.linear_bwd(dz, x, W, scale)        # dx = scale * dz W ; dW = scale * dz^T x
+            if sn:       # sn_grad wants G = dz^T x, the gradient wrt W / sigma: one weight-gradient pass (unscaled) + the scaled dX
+                dx = ops.linear_bwd(dz, x, W, scale, need_dw=False)[0]
+                _, G, db = ops.linear_bwd(dz, x, W, None, need_dx=False)
+            else:
+                dx, dW, db = ops.linear_bwd(dz, x, W, scale)    # dx = scale * dz W ; dW = scale * dz^T x
             self._acc(prefix + ".bias", db)
-            if sn:       # sn_grad wants G = dz^T x, the gradient wrt W / sigma
-                G = ops.linear_bwd(dz, x, W, None, need_dx=False, has_bias=False)[1]
+            if sn:
                 if sig2 is None:
                     self._acc(prefix + ".weight_orig", G)
                 else:

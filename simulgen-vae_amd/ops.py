@@ -375,11 +375,12 @@ def act_bwd(y, dy, act):
     return dz
 
 
-def linear_bwd(dz, x, W, scale=None, need_dx=True, has_bias=True, dx_accumulate=None):
+def linear_bwd(dz, x, W, scale=None, need_dx=True, has_bias=True, dx_accumulate=None, need_dw=True):
+    """-> (dx = scale * dz W or None, dW = scale * dz^T x or None, db or None); need_dw=False: the input gradient only."""
     B, K = x.shape
     O = W.shape[0]
-    dW = torch.empty_like(W)
-    db = torch.empty(O, dtype=torch.float32, device=x.device) if has_bias else None
+    dW = torch.empty_like(W) if need_dw else None
+    db = torch.empty(O, dtype=torch.float32, device=x.device) if has_bias and need_dw else None
     dx = dx_accumulate if dx_accumulate is not None else (torch.empty_like(x) if need_dx else None)
     _ck(lib().sgv_op_linear_bwd(_p(dz), _p(x), _p(W), _p(scale), _p(dx), int(dx_accumulate is not None), _p(dW), _p(db), B, K, O,
                                 _stream()), "sgv_op_linear_bwd")
