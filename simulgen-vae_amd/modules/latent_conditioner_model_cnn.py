@@ -55,6 +55,7 @@ class LatentConditionerImg:
         self.implicit_conv = os.environ.get("SGV_LC_IMPLICIT", "1") != "0"
         self.fused_tail = os.environ.get("SGV_LC_FUSED_TAIL", "1") != "0"
         self.pset = None
+        self._conv_sums = None          # GroupNorm statistics left by the last _conv call (the direct stem produces them), else None
         if any(c % 16 for c in self.filters):
             raise SgvError("latent_conditioner_filter entries must be multiples of 16 (bottleneck channels feed 8-wide GEMM tiles)")
         self.blocks = []
