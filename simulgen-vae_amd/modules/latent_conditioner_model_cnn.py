@@ -172,7 +172,7 @@ class LatentConditionerImg:
     def __getstate__(self):
         d = dict(self.__dict__)
         d["P"] = {k: v.detach().cpu().numpy() for k, v in self.P.items()}
-        d["grads"], d["_tape"], d["pset"], d["_pending"] = {}, None, None, None
+        d["grads"], d["_tape"], d["pset"], d["_pending"], d["_conv_sums"] = {}, None, None, None, None
         d.pop("G", None)
         d.pop("_entry", None)
         return d
