@@ -58,7 +58,9 @@ __device__ __forceinline__ uint4 bload16(__amdgpu_buffer_rsrc_t r, uint32_t off)
 // NT
 // =========================================================================================
 // C2D: 2-D taps (GemmNT::cv_*): rows are output pixels of a channels-last image batch, a tap is a (kh, kw) window offset
-template <typename T, int KCH, bool C2D = false>
+// NW: narrow form for N <= 64 (the conditioner's 16-64 channel layers on a million rows): 128 x 64 tile, the four waves stacked
+//     along M (32 rows x 64 columns each) -- half the MFMAs, weight-tile loads, fragment reads and epilogue work of the square tile
+template <typename T, int KCH, bool C2D = false, bool NW = false>
 __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const GemmNT p) {
     constexpr int EPC = ElemTraits<T>::EPC;
     constexpr int BK = KCH * EPC;
@@ -71,8 +73,9 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     __shared__ __attribute__((aligned(16))) unsigned char smem[4 * TILEB];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int tiles_n = (p.N + 127) >> 7, tiles_m = (p.M - p.row0 + 127) >> 7;
+    const int wm = NW ? wave : wave >> 1, wn = NW ? 0 : wave & 1;
+    constexpr int TN_ = NW ? 64 : 128;           // tile width
+    const int tiles_n = (p.N + TN_ - 1) / TN_, tiles_m = (p.M - p.row0 + 127) >> 7;
     const int ntiles = tiles_n * tiles_m;
     // 1-D grid of ntiles*splitk blocks: XCD-chunked, split-K slice slowest, grouped tile raster within.
     const int logical = xcd_remap(blockIdx.x, ntiles * p.splitk);
@@ -80,7 +83,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     const int tile = logical - z * ntiles;
     int tm, tn;
     grouped_raster(tile, tiles_m, tiles_n, tm, tn);
-    const int m0 = p.row0 + (tm << 7), n0 = tn << 7;
+    const int m0 = p.row0 + (tm << 7), n0 = tn * TN_;
     const int kchunks = (p.K + BK - 1) / BK;
     const int total = p.taps * kchunks;
     const int s_begin = (int)((long)total * z / p.splitk);
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
     const int am0 = m0 + r0, am1 = m0 + r0 + RSTEP;
     const int wn0 = n0 + r0, wn1 = n0 + r0 + RSTEP;
     const bool aok0 = am0 < p.M, aok1 = am1 < p.M;
-    const bool wok0 = wn0 < p.N, wok1 = wn1 < p.N;
+    const bool wok0 = wn0 < p.N, wok1 = !NW && wn1 < p.N;
     constexpr int ESZ = (int)sizeof(T);
     // per-tap validity of this thread's two activation rows as bit masks (taps <= 31)
     uint32_t am0_mask = 0u, am1_mask = 0u;
@@ -164,7 +167,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
         ra0##X = bload16(rsA, pa0 ? abase0 + (uint32_t)ld_aoff : OOB_OFF);                                    \
         ra1##X = bload16(rsA, pa1 ? abase1 + (uint32_t)ld_aoff : OOB_OFF);                                    \
         rw0##X = bload16(rsW, kok_ ? wbase0 + (uint32_t)ld_woff : OOB_OFF);                                   \
-        rw1##X = bload16(rsW, kok_ ? wbase1 + (uint32_t)ld_woff : OOB_OFF);                                   \
+        if constexpr (!NW) rw1##X = bload16(rsW, kok_ ? wbase1 + (uint32_t)ld_woff : OOB_OFF);                \
         ++ld_j; ld_aoff += lda_b; ld_woff += wstep_b;                                                         \
         if constexpr (C2D) { if (++ld_jw == p.cv_kw) { ld_jw = 0; ld_aoff += rowskip_b; } }                   \
         if (ld_j == p.taps) { ld_j = 0; ld_jw = 0; ld_kcb += BK * ESZ; ld_aoff = ld_kcb + a0_b; ld_woff = ld_kcb + w0_b; } \
@@ -177,7 +180,8 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
         unsigned char* sa_ = smem + (BUF) * 2 * TILEB + r0 * ROWB + kq * 16;                                  \
         unsigned char* sw_ = sa_ + TILEB;                                                                     \
         SGV_NT_ST1(sa_, ra0##X) SGV_NT_ST1(sa_ + RSTEP * ROWB, ra1##X)                                        \
-        SGV_NT_ST1(sw_, rw0##X) SGV_NT_ST1(sw_ + RSTEP * ROWB, rw1##X)                                        \
+        SGV_NT_ST1(sw_, rw0##X)                                                                               \
+        if constexpr (!NW) { SGV_NT_ST1(sw_ + RSTEP * ROWB, rw1##X) }                                         \
     }
 
     f32x16 acc[2][2];
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
 
     const int lr = lane & 31, lh = lane >> 5;
-    const int a_frag_off = (wm * 64 + lr) * ROWB;
+    const int a_frag_off = (NW ? wm * 32 + lr : wm * 64 + lr) * ROWB;
     const int w_frag_off = (wn * 64 + lr) * ROWB;
 #define SGV_NT_COMPUTE(BUF)                                                                                   \
     {                                                                                                         \
@@ -198,13 +202,15 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
         if constexpr (IS_BF16) {                                                                              \
             _Pragma("unroll") for (int ks = 0; ks < BK / 16; ++ks) {                                          \
                 const bf16x8 a0_ = *reinterpret_cast<const bf16x8*>(sa_ + (ks * 2 + lh) * 16);                \
-                const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * ROWB + (ks * 2 + lh) * 16);    \
                 const bf16x8 b0_ = *reinterpret_cast<const bf16x8*>(sw_ + (ks * 2 + lh) * 16);                \
                 const bf16x8 b1_ = *reinterpret_cast<const bf16x8*>(sw_ + 32 * ROWB + (ks * 2 + lh) * 16);    \
                 acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b0_, acc[0][0], 0, 0, 0);            \
                 acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a0_, b1_, acc[0][1], 0, 0, 0);            \
-                acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);            \
-                acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);            \
+                if constexpr (!NW) {                                                                          \
+                    const bf16x8 a1_ = *reinterpret_cast<const bf16x8*>(sa_ + 32 * ROWB + (ks * 2 + lh) * 16); \
+                    acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b0_, acc[1][0], 0, 0, 0);        \
+                    acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a1_, b1_, acc[1][1], 0, 0, 0);        \
+                }                                                                                             \
             }                                                                                                 \
         } else {                                                                                              \
             _Pragma("unroll") for (int ks = 0; ks < BK / 2; ++ks) {                                           \
@@ -267,7 +273,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
 
     // epilogue: C/D layout of the 32x32 MFMA: col = lane&31, row = (r&3) + 8*(r>>2) + 4*(lane>>5)
     const float sc = p.scale ? *p.scale : 1.0f;
-    const bool full = (m0 + 128 <= p.M) && (n0 + 128 <= p.N);
+    const bool full = (m0 + 128 <= p.M) && (n0 + TN_ <= p.N);
     const T* addp = reinterpret_cast<const T*>(p.addend);
     if constexpr (IS_BF16) {
         if (p.splitk == 1 && !p.out_f32) {
@@ -278,7 +284,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
             static_assert(128 * CP <= 4 * TILEB, "C tile must fit in the staging buffers");
             __syncthreads();          // every wave is done reading its last operand tile
 #pragma unroll
-            for (int a = 0; a < 2; ++a) {
+            for (int a = 0; a < (NW ? 1 : 2); ++a) {
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     const int lcol = wn * 64 + b * 32 + lr;
@@ -286,7 +292,7 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
                     const float bv = (p.bias && gcol < p.N) ? p.bias[gcol] : 0.f;
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int lrow = wm * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        const int lrow = (NW ? wm * 32 : wm * 64 + a * 32) + (r & 3) + 8 * (r >> 2) + 4 * lh;
                         *reinterpret_cast<bf16_t*>(smem + lrow * CP + lcol * 2) = (bf16_t)(acc[a][b][r] * sc + bv);
                     }
                 }
@@ -303,9 +309,9 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
             const bool csplit = cb < n0 + 128;
             float sA1 = 0.f, sA2 = 0.f, sR1 = 0.f, sR2 = 0.f, sC1 = 0.f, sC2 = 0.f, sB1 = 0.f, sB2 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int c = tid + i * 256;          // 2048 chunks of 8 bf16
-                const int lrow = c >> 4, lc8 = (c & 15) * 8;
+            for (int i = 0; i < (NW ? 4 : 8); ++i) {
+                const int c = tid + i * 256;          // 2048 chunks of 8 bf16 (NW: 1024, 8 per row)
+                const int lrow = NW ? c >> 3 : c >> 4, lc8 = (NW ? c & 7 : c & 15) * 8;
                 const int grow = m0 + lrow, gcol = n0 + lc8;
                 if (grow < p.M && gcol < p.N) {       // N % 8 == 0: a chunk is entirely in or out
                     bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
@@ -362,13 +368,13 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
         }
     }
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < (NW ? 1 : 2); ++a) {
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             const int col = n0 + wn * 64 + b * 32 + lr;
             const bool cok = full || (col < p.N);
             const int colc = cok ? col : 0;
-            const int rbase = m0 + wm * 64 + a * 32 + 4 * lh;
+            const int rbase = m0 + (NW ? wm * 32 : wm * 64 + a * 32) + 4 * lh;
             if (p.splitk > 1) {
                 float* dst = p.partial + ((long)z * (p.M - p.row0) - p.row0) * p.N + colc;      // slab rows are relative to row0
 #pragma unroll
@@ -1336,7 +1342,14 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (p.gn_sums && (dtype != 1 || gemm_nt_is_wide(dtype, p.N, total_steps) || p.splitk != 1 || p.out_f32 || p.Tlen < 128 ||
                       p.gn_Cg < 128 || p.gn_G < 1))
         return -1;                                   // only the bf16 128x128 epilogue accumulates statistics
-    if (c2d) {
+    // N <= 64 (bf16, no statistics epilogue): the 128 x 64 form of the kernel
+    static const int narrow_on = getenv("SGV_GEMM_NARROW") ? atoi(getenv("SGV_GEMM_NARROW")) : 1;
+    const bool narrow = narrow_on && dtype == 1 && p.N <= 64 && !p.gn_sums;
+    if (narrow) {
+        dim3 grid(cdiv(Mr, 128) * p.splitk);
+        if (c2d) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4, true, true>), grid, dim3(256), 0, s, q);
+        else hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4, false, true>), grid, dim3(256), 0, s, q);
+    } else if (c2d) {
         dim3 grid(cdiv(Mr, 128) * cdiv(p.N, 128) * p.splitk);
         if (dtype == 1) hipLaunchKernelGGL((gemm_nt_kernel<bf16_t, 4, true>), grid, dim3(256), 0, s, q);
         else hipLaunchKernelGGL((gemm_nt_kernel<float, 4, true>), grid, dim3(256), 0, s, q);

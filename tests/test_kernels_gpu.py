@@ -70,6 +70,11 @@ NT_CASES = [
     (400, 200, 160, 5, 20, 3),
     (96, 264, 1032, 1, 12, 4),
     (520, 320, 320, 5, 40, 2),
+    # N <= 64: the 128 x 64 form of the bf16 kernel (ragged rows, taps, split-K slabs)
+    (300, 64, 96, 1, 20, 1),
+    (1000, 32, 72, 3, 25, 1),
+    (644, 48, 160, 5, 23, 3),
+    (130, 16, 1032, 1, 13, 4),
 ]
 
 
