@@ -78,6 +78,9 @@ int sgv_op_gn_tail(int dtype, const void* y, const float* gamma, const float* be
 size_t sgv_op_gn_workspace_floats(int B, int P, int C);
 int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
                   const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream);
+/* sgv_op_gn_bwd with dgamma / dbeta WRITTEN (=) instead of accumulated (a layer applied once per step needs no zero-fill). */
+int sgv_op_gn_bwd_set(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
+                      const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream);
 
 /* nn.MaxPool2d(3, 2, 1) (model_cnn.py:189); argmax: one byte per output element (window position of the first
  * maximum, may be NULL in the forward when no backward follows). */

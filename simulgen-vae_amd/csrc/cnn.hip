@@ -1215,15 +1215,24 @@ int sgv_op_gn_tail(int dtype, const void* y, const float* gamma, const float* be
 }
 // backward of out = act(gn(y)): dy (same dtype) and dgamma/dbeta (+= , fp32); sums from the forward; sums2: B*G*2 doubles
 // scratch; part: sgv_op_gn_workspace_floats floats scratch
-int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
-                  const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream) {
+static int gn_bwd_impl(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
+                       const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, int accumulate, void* stream) {
     OPCHK(y && dout && dy && gamma && beta && sums && sums2 && part && dgamma && dbeta, "sgv_op_gn_bwd: null argument");
     OPCHK(C % 8 == 0 && G >= 1 && G <= SGV_GN_MAX_GROUPS && C % G == 0, "sgv_op_gn_bwd: bad channel / group counts");
     GNParams p = gn_params(y, B, P, C, G, gamma, beta, sums);
     p.sums2 = sums2; p.dout = dout; p.lddout = C; p.rscale = 1.f; p.dgamma = dgamma; p.dbeta = dbeta; p.part = part;
-    p.out = dy; p.ldout = C; p.accum_affine = 1;
+    p.out = dy; p.ldout = C; p.accum_affine = accumulate;
     if (ew_gn_bwd(dtype, act, p, ST(stream))) return sgv_set_error(-1, "sgv_op_gn_bwd: launch failed");
     return OPLAUNCH_OK();
+}
+int sgv_op_gn_bwd(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
+                  const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream) {
+    return gn_bwd_impl(dtype, act, y, dout, dy, B, P, C, G, gamma, beta, sums, sums2, part, dgamma, dbeta, 1, stream);
+}
+// the same with dgamma / dbeta written (=) instead of accumulated: no zero-fill needed in front of it
+int sgv_op_gn_bwd_set(int dtype, int act, const void* y, const void* dout, void* dy, int B, int P, int C, int G, const float* gamma,
+                      const float* beta, double* sums, double* sums2, float* part, float* dgamma, float* dbeta, void* stream) {
+    return gn_bwd_impl(dtype, act, y, dout, dy, B, P, C, G, gamma, beta, sums, sums2, part, dgamma, dbeta, 0, stream);
 }
 
 // ---- small fp32 layers ------------------------------------------------------------------------------------

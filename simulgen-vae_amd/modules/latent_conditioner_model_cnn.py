@@ -353,8 +353,8 @@ class LatentConditionerImg:
         y3 = y4.view(B, H * Wd, Cc)
 
         def bwd(dout4):
-            dg, db = torch.zeros_like(gamma), torch.zeros_like(beta)
-            dy = ops.gn_bwd(y3, dout4.reshape(B, H * Wd, Cc), G, gamma, beta, sums, act, dg, db)
+            dg, db = torch.empty_like(gamma), torch.empty_like(beta)          # written, not accumulated: no zero-fill launches
+            dy = ops.gn_bwd(y3, dout4.reshape(B, H * Wd, Cc), G, gamma, beta, sums, act, dg, db, accumulate=False)
             self._acc(prefix + ".weight", dg)
             self._acc(prefix + ".bias", db)
             return dy.view(y4.shape)

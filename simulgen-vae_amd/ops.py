@@ -13,7 +13,7 @@ from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-e
 
 OPS_SYMBOLS = [
     "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_dw", "sgv_op_gn_relu_maxpool_fwd", "sgv_op_stem_conv_workspace_floats",
-    "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
+    "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_gn_bwd_set", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
     "sgv_op_layernorm_bwd", "sgv_op_batchnorm_fwd", "sgv_op_batchnorm_bwd", "sgv_op_mask_scale", "sgv_op_addf",
@@ -50,6 +50,7 @@ def lib():
             "sgv_op_stem_conv_dw": [vp] * 4 + [i] * 7 + [vp],
             "sgv_op_gn_tail": [i] + [vp] * 10 + [i, i, i, i, vp, vp],
             "sgv_op_gn_bwd": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
+            "sgv_op_gn_bwd_set": [i, i, vp, vp, vp, i, i, i, i, vp, vp, vp, vp, vp, vp, vp, vp],
             "sgv_op_maxpool_fwd": [i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_gn_relu_maxpool_fwd": [i, vp, vp, vp, vp, i, vp, vp, vp, i, i, i, i, vp],
             "sgv_op_maxpool_bwd": [i, vp, vp, vp, i, i, i, i, vp],
@@ -265,13 +266,15 @@ def gn_tail(y, G, gamma, beta, y2, gamma2=None, beta2=None, cscale=None):
     return out, sums, sums2
 
 
-def gn_bwd(y, dout, G, gamma, beta, sums, act, dgamma, dbeta):
+def gn_bwd(y, dout, G, gamma, beta, sums, act, dgamma, dbeta, accumulate=True):
+    """dy; dgamma / dbeta += (accumulate=True, the buffers must hold valid numbers) or = (accumulate=False: any buffer)."""
     B, P, Cc = y.shape
     dy = torch.empty_like(y)
     sums2 = torch.empty_like(sums)
     part = torch.empty(int(lib().sgv_op_gn_workspace_floats(B, P, Cc)), dtype=torch.float32, device=y.device)
-    _ck(lib().sgv_op_gn_bwd(_d(y), act, _p(y), _p(dout), _p(dy), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _p(sums2), _p(part),
-                            _p(dgamma), _p(dbeta), _stream()), "sgv_op_gn_bwd")
+    fn = lib().sgv_op_gn_bwd if accumulate else lib().sgv_op_gn_bwd_set
+    _ck(fn(_d(y), act, _p(y), _p(dout), _p(dy), B, P, Cc, G, _p(gamma), _p(beta), _p(sums), _p(sums2), _p(part),
+           _p(dgamma), _p(dbeta), _stream()), "sgv_op_gn_bwd")
     return dy
 
 
