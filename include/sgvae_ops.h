@@ -46,6 +46,12 @@ int sgv_op_stem_conv_dw(const void* x, const void* dy, float* dW, float* part, i
  * weights [(kh,kw,ci)][Cout] with ldw = Cout, w_tap_stride = Cin*Cout, flip = 1, pad = KH-1-pad. */
 int sgv_op_conv2d_nt(int dtype, const void* x, const void* W, void* y, const float* scale, int B, int H, int Wd, int Cin, int N,
                      int KH, int KW, int stride, int pad, long ldw, long w_tap_stride, int flip, void* stream);
+/* C[M][N] = scale[0] * A[M][K] . W[N][K]^T + up2(addend) (bf16): the rows of C are the pixels of [B][H][W] images and addend is a
+ * half-resolution batch [B][ceil(H/2)][ceil(W/2)][N] added at the even pixels only -- ResidualBlock's block-input gradient when
+ * the skip projection has stride 2: conv1's input-gradient GEMM takes the (compact) input gradient of the 1x1 stride-2
+ * projection as its addend instead of a zero-filled full-resolution copy (sgv_op_col2im).  N < 256 or K < 2048. */
+int sgv_op_gemm_nt_add_s2(int dtype, const void* A, const void* W, void* C, const float* scale, const void* addend, int M, int N, int K,
+                          int H, int Wd, void* stream);
 /* dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]  (N1, N2 multiples of 8).  The reduction runs over M = B*H*W rows:
  * sgv_op_gemm_tn_splitk() returns the number of row slices to use, the caller passes that many N1*N2 fp32 slabs
  * (slabs may be NULL when splitk == 1). */

@@ -1405,6 +1405,21 @@ int sgv_op_conv2d_nt(int dtype, const void* x, const void* W, void* y, const flo
     if (r) return sgv_set_error(-1, "sgv_op_conv2d_nt: launch rejected (%d) for B=%d H=%d W=%d Cin=%d N=%d %dx%d/%d", r, B, H, Wd, Cin, N, KH, KW, stride);
     return 0;
 }
+// C = scale * A W^T + up2(addend): see include/sgvae_ops.h
+int sgv_op_gemm_nt_add_s2(int dtype, const void* A, const void* W, void* C, const float* scale, const void* addend, int M, int N, int K,
+                          int H, int Wd, void* stream) {
+    OPCHK(A && W && C && addend && M > 0 && N > 0 && K > 0 && H > 0 && Wd > 0, "sgv_op_gemm_nt_add_s2: bad argument");
+    OPCHK(dtype == 1, "sgv_op_gemm_nt_add_s2: bf16 only");
+    OPCHK(K % 8 == 0 && N % 8 == 0 && M % (H * Wd) == 0, "sgv_op_gemm_nt_add_s2: K, N multiples of 8 and M a multiple of H*W required (got M=%d N=%d K=%d H=%d W=%d)", M, N, K, H, Wd);
+    GemmNT p; memset(&p, 0, sizeof(p));
+    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N;
+    p.addend = addend; p.ldadd = N; p.scale = scale; p.add_H = H; p.add_W = Wd;
+    p.M = M; p.N = N; p.K = K; p.taps = 1; p.pad = 0; p.Tlen = M; p.splitk = 1;
+    const GemmPlan pl = gemm_nt_plan(dtype, p, 0, 0);
+    const int r = launch_gemm_nt_planned(dtype, p, pl, ST(stream));
+    if (r) return sgv_set_error(-1, "sgv_op_gemm_nt_add_s2: launch rejected (%d) for M=%d N=%d K=%d (K >= 2048 with N >= 256 is not served)", r, M, N, K);
+    return 0;
+}
 // dW[N1][N2] (fp32) = A[M][N1]^T . B[M][N2]; N1, N2 multiples of 8.  The reduction runs over the M = B*H*W rows, up to
 // a million of them for a handful of output tiles: sgv_op_gemm_tn_splitk() says how many row slices to use and the caller
 // provides splitk * N1 * N2 floats of slab workspace (deterministic: plain stores + one sum pass).

@@ -316,9 +316,20 @@ __global__ __launch_bounds__(256, SGV_GEMM_MIN_WAVES) void gemm_nt_kernel(const 
                 if (grow < p.M && gcol < p.N) {       // N % 8 == 0: a chunk is entirely in or out
                     bf16x8 v = *reinterpret_cast<const bf16x8*>(smem + lrow * CP + lc8 * 2);
                     if (addp) {
-                        const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + (long)grow * p.ldadd + gcol);
+                        // add_W > 0: the addend is a half-resolution image batch [B][ceil(add_H/2)][ceil(add_W/2)][ldadd] added at the
+                        // even pixels of this output's [B][add_H][add_W] rows only (input gradient of a stride-2 1x1 convolution)
+                        long arow = grow;
+                        bool aon = true;
+                        if (p.add_W > 0) {
+                            const int hw = p.add_H * p.add_W, bb = grow / hw, q = grow - bb * hw, h = q / p.add_W, w = q - h * p.add_W;
+                            aon = !((h | w) & 1);
+                            arow = ((long)bb * ((p.add_H + 1) >> 1) + (h >> 1)) * ((p.add_W + 1) >> 1) + (w >> 1);
+                        }
+                        if (aon) {
+                            const bf16x8 ad = *reinterpret_cast<const bf16x8*>(addp + arow * p.ldadd + gcol);
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
+                            for (int e = 0; e < 8; ++e) v[e] = (bf16_t)((float)v[e] + (float)ad[e]);
+                        }
                     }
                     *reinterpret_cast<bf16x8*>(Cg + (long)grow * p.ldc + gcol) = v;
                     if (st) {
@@ -1324,6 +1335,10 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     if (p.row0 < 0 || p.row0 >= p.M || (p.row0 && p.gn_sums)) return -1;
     const int Mr = p.M - p.row0;                                           // rows this launch computes
     const bool c2d = p.cv_kw > 0;
+    // strided addend (add_W > 0): the staged bf16 epilogue of gemm_nt_kernel only
+    if (p.add_W > 0 && (!p.addend || dtype != 1 || p.splitk != 1 || p.out_f32 || p.add_H < 1 || p.M % (p.add_H * p.add_W) || p.vendor ||
+                        (!c2d && gemm_nt_is_wide(dtype, p.N, (long)p.taps * cdiv(p.K, 32)))))
+        return -1;
     if (c2d) {
         if (p.taps > 31 || p.taps % p.cv_kw || p.cv_S < 1 || p.cv_P < 0 || p.cv_H < 1 || p.cv_W < 1 || p.cv_Ho < 1 || p.cv_Wo < 1) return -1;
         if (p.M % (p.cv_Ho * p.cv_Wo) || p.a_rows != (long)(p.M / (p.cv_Ho * p.cv_Wo)) * p.cv_H * p.cv_W) return -1;

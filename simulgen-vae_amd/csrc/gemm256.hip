@@ -706,6 +706,7 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
     const long total_kt = (long)p.taps * t256_cdiv(p.K, 64);
     if (p.splitk < 1 || total_kt / p.splitk < 4) return -1;
     if (p.gn_part && (p.splitk != 1 || p.out_f32 || p.Tlen < 128 || p.gn_Cg < 64 || p.gn_Cg % 4 || p.gn_G < 1 || !p.gn_sums)) return -1;
+    if (p.add_W > 0) return -1;          // the strided addend is the 128-row kernel's (gemm_nt_plan keeps such a product there)
     GemmNT q = p;
     const long arows = p.a_rows > p.M ? p.a_rows : p.M;
     q.a_bytes = ((arows - 1) * p.lda + p.K) * 2;
@@ -766,7 +767,7 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
     const long total_kt = (long)p.taps * t256_cdiv(p.K, 64);
     const double gf = 2.0e-9 * p.M * p.N * p.K * p.taps;
     const long tiles256 = (long)t256_cdiv(p.M, 256) * t256_cdiv(p.N, 256);
-    const bool big = gemm_nt256_eligible(dtype, p) && (p.N >= 1024 || tiles256 >= 200) && gf >= min_gf && !p.out_f32 && total_kt >= 8;
+    const bool big = gemm_nt256_eligible(dtype, p) && (p.N >= 1024 || tiles256 >= 200) && gf >= min_gf && !p.out_f32 && total_kt >= 8 && p.add_W <= 0;
     if (!big) {
         pl.sk_main = gemm_nt_pick_splitk(p.M, p.N, p.K, p.taps, dtype);
         if ((size_t)pl.sk_main * p.M * p.N > partial_floats) pl.sk_main = 1;

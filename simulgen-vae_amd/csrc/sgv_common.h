@@ -157,6 +157,10 @@ struct GemmNT {
     // and a_rows must be B*cv_H*cv_W.  cv_flip: tap j multiplies W[taps-1-j] (the input gradient of a stride-1 convolution
     // is the convolution of dY with the taps reversed).  128x128 bf16/fp32 kernel and the 256x256 kernel only.
     int cv_kw, cv_H, cv_W, cv_S, cv_P, cv_Ho, cv_Wo, cv_flip;
+    // strided addend (add_W > 0; bf16 128-row kernel, split-K 1): rows are the pixels of [B][add_H][add_W] images and `addend` is a
+    // half-resolution batch [B][ceil(add_H/2)][ceil(add_W/2)][ldadd] that is added at the even pixels only -- the input gradient
+    // of a stride-2 1x1 convolution folded into the GEMM that produces the other branch's input gradient
+    int add_H, add_W;
 };
 // gemm256.hip
 bool gemm_nt256_eligible(int dtype, const GemmNT& p);

@@ -30,6 +30,18 @@ from ..engine import SgvError
 _GROUPS = (32, 16, 8, 4, 2, 1)
 
 
+class _HalfRes:
+    """Input gradient of a 1x1 stride-2 convolution kept at the resolution of its output: `half` [B, ceil(H/2), ceil(W/2), C] holds
+    the values of the even pixels of the [B, H, W, C] gradient, every other pixel is zero.  conv1's input-gradient GEMM adds it
+    in its epilogue (sgv_op_gemm_nt_add_s2); `full()` materialises it (sgv_op_col2im) for any other consumer."""
+
+    def __init__(self, half, shape):
+        self.half, self.shape = half, shape
+
+    def full(self):
+        return ops.col2im(self.half.reshape(-1, self.half.shape[-1]), self.shape, 1, 1, 2, 0)
+
+
 def _num_groups(channels):
     for g in _GROUPS:
         if channels % g == 0 and g <= channels:
@@ -323,11 +335,19 @@ class LatentConditionerImg:
             if not need_dx:
                 return None
             Wt = ops.transpose(Wp.view(1, co, -1), self.dt, 1, co, Wp.shape[1]).view(Wp.shape[1], co)
+            if isinstance(addend, _HalfRes) and not (direct and self.dt == torch.bfloat16 and (ci < 256 or co < 2048)):
+                addend = addend.full()          # no epilogue for it here: materialise the zero-filled full-resolution tensor
             if implicit and stride == 1 and co % 8 == 0:
                 # dX of a stride-1 convolution = convolution of dY with the reversed taps of the transposed weights
                 dx = ops.conv2d_nt(dy4.reshape(B, Ho, Wo, co), Wt, ci, k, k, 1, k - 1 - pad, co, ci * co, flip=True, scale=inv_sigma)
+            elif direct and isinstance(addend, _HalfRes):
+                # + the stride-2 skip projection's input gradient, read at half resolution by the GEMM epilogue
+                return ops.gemm_nt_add_s2(dy, Wt, addend.half, H, Wd, scale=inv_sigma).view(x4.shape)
             elif direct:
                 return ops.gemm_nt(dy, Wt, scale=inv_sigma, addend=None if addend is None else addend.view(-1, ci)).view(x4.shape)
+            elif implicit and k == 1 and stride == 2 and pad == 0 and addend is None and self.fused_tail:
+                # 1x1 stride-2 projection: its input gradient is non-zero at the even pixels only; hand the compact tensor on
+                return _HalfRes(ops.gemm_nt(dy, Wt, scale=inv_sigma).view(B, Ho, Wo, ci), tuple(x4.shape))
             else:
                 dx = ops.col2im(ops.gemm_nt(dy, Wt, scale=inv_sigma), x4.shape, k, k, stride, pad)
             return dx if addend is None else ops.add(dx, addend)

@@ -12,7 +12,7 @@ import torch
 from .engine import DTYPES, SgvError, load_library  # noqa: F401  (SgvError re-exported)
 
 OPS_SYMBOLS = [
-    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_dw", "sgv_op_gn_relu_maxpool_fwd", "sgv_op_stem_conv_workspace_floats",
+    "sgv_op_conv_out_shape", "sgv_op_im2col", "sgv_op_col2im", "sgv_op_conv2d_nt", "sgv_op_conv2d_tn", "sgv_op_gemm_nt", "sgv_op_gemm_nt_add_s2", "sgv_op_gemm_tn", "sgv_op_gemm_tn_splitk", "sgv_op_matvec_t", "sgv_op_gn_fwd", "sgv_op_gn_tail", "sgv_op_gn_apply", "sgv_op_stem_conv_fwd", "sgv_op_stem_conv_dw", "sgv_op_gn_relu_maxpool_fwd", "sgv_op_stem_conv_workspace_floats",
     "sgv_op_gn_workspace_floats", "sgv_op_gn_bwd", "sgv_op_gn_bwd_set", "sgv_op_maxpool_fwd", "sgv_op_maxpool_bwd", "sgv_op_add_relu_fwd",
     "sgv_op_relu_bwd", "sgv_op_add", "sgv_op_avgpool_fwd", "sgv_op_avgpool_bwd", "sgv_op_chan_scale_fwd",
     "sgv_op_chan_scale_bwd", "sgv_op_linear_fwd", "sgv_op_act_fwd", "sgv_op_act_bwd", "sgv_op_linear_bwd", "sgv_op_layernorm_fwd",
@@ -37,6 +37,7 @@ def lib():
             "sgv_op_im2col": [i, vp, vp] + [i] * 8 + [vp],
             "sgv_op_col2im": [i, vp, vp] + [i] * 8 + [vp],
             "sgv_op_gemm_nt": [i, vp, vp, vp, vp, vp, vp, i, i, i, i, vp],
+            "sgv_op_gemm_nt_add_s2": [i, vp, vp, vp, vp, vp, i, i, i, i, i, vp],
             "sgv_op_conv2d_nt": [i, vp, vp, vp, vp] + [i] * 9 + [C.c_long, C.c_long, i, vp],
             "sgv_op_gemm_tn": [i, vp, vp, vp, i, i, i, vp, i, vp],
             "sgv_op_conv2d_tn": [i, vp, vp, vp] + [i] * 9 + [vp, i, vp],
@@ -169,6 +170,16 @@ def gemm_nt(A, W, bias=None, scale=None, addend=None, out_f32=False):
     out = torch.empty((M, N), dtype=torch.float32 if out_f32 else A.dtype, device=A.device)
     _timed("gemm_nt", 2.0 * M * N * K, lambda: _ck(lib().sgv_op_gemm_nt(_d(A), _p(A), _p(W), _p(out), _p(bias), _p(scale), _p(addend), M, N, K,
                                                                          int(out_f32), _stream()), "sgv_op_gemm_nt"))
+    return out
+
+
+def gemm_nt_add_s2(A, W, addend_half, H, Wd, scale=None):
+    """A [B*H*W, K] . W [N, K]^T + addend_half [B, ceil(H/2), ceil(W/2), N] added at the even pixels (sgv_op_gemm_nt_add_s2) -> [M, N]."""
+    M, K = A.shape
+    N = W.shape[0]
+    out = torch.empty((M, N), dtype=A.dtype, device=A.device)
+    _timed("gemm_nt", 2.0 * M * N * K, lambda: _ck(lib().sgv_op_gemm_nt_add_s2(_d(A), _p(A), _p(W), _p(out), _p(scale), _p(addend_half), M, N, K, H, Wd,
+                                                                                _stream()), "sgv_op_gemm_nt_add_s2"))
     return out
 
 

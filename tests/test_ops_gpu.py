@@ -124,6 +124,23 @@ def test_groupnorm_relu(dt, cfg):
     assert rel(dgam, gamma.grad) < max(TOL[dt], 2e-4) and rel(dbet, beta.grad) < max(TOL[dt], 2e-4)
 
 
+@pytest.mark.parametrize("cfg", [(2, 16, 16, 64, 32), (3, 9, 11, 40, 24), (1, 64, 48, 256, 128), (2, 7, 6, 136, 72)])
+def test_gemm_with_half_resolution_addend(cfg):
+    """sgv_op_gemm_nt_add_s2: the GEMM whose epilogue adds a half-resolution tensor at the even pixels equals the plain GEMM with
+    the zero-filled full-resolution addend (sgv_op_col2im of a 1x1 stride-2 convolution) -- bit for bit, odd sizes included."""
+    B, H, W, N, K = cfg
+    dt = torch.bfloat16
+    g = torch.Generator().manual_seed(9)
+    a = torch.randn(B * H * W, K, generator=g).to(device="cuda", dtype=dt)
+    w = (torch.randn(N, K, generator=g) * 0.2).to(device="cuda", dtype=dt)
+    half = torch.randn(B, (H + 1) // 2, (W + 1) // 2, N, generator=g).to(device="cuda", dtype=dt)
+    scale = torch.tensor([0.6], device="cuda")
+    full = ops.col2im(half.view(-1, N), (B, H, W, N), 1, 1, 2, 0)
+    ref = ops.gemm_nt(a, w, scale=scale, addend=full.view(-1, N))
+    out = ops.gemm_nt_add_s2(a, w, half, H, W, scale=scale)
+    assert torch.equal(out, ref)
+
+
 @pytest.mark.parametrize("cfg", [(2, 20, 24, 32, 7), (1, 37, 150, 32, 7), (2, 16, 16, 64, 5), (3, 9, 130, 16, 3), (1, 300, 260, 32, 7)])
 def test_stem_convolution_direct(cfg):
     """sgv_op_stem_conv_fwd / sgv_op_stem_conv_dw (one input channel, bf16): the convolution and its weight gradient against
