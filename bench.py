@@ -324,11 +324,11 @@ def main():
         roof = {"kernel": "gemm_nt_t256_kernel + gemm_nt_wide64p_kernel + gemm_nt_kernel (conv forward + input-gradient implicit GEMMs)", "bound": "mfma",
                 "achieved": None, "peak": peak, "unit": "TFLOP/s", "frac": None, "traffic": None,
                 "flop_per_step": fwd + dx}
-        result = {"metric": f"simulation samples/sec/node (preset-1 {args.size}, batch 16)", "value": round(value, 3),
+        result = {"metric": f"simulation samples/sec/node (preset-1 {args.size}, batch {B})", "value": round(value, 3),
                   "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(ms, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                   "dtype": args.dtype, "data": "synthetic U(-0.7,0.7) [P x 95008 x 200], random-init weights",
-                  "config": {"workload": f"preset=1 --size={args.size}, synthetic [P x 200 x 95008], batch 16 per GPU "
+                  "config": {"workload": f"preset=1 --size={args.size}, synthetic [P x 200 x 95008], batch {B} per GPU "
                                          f"(BASELINE.json configs[{1 if args.size == 'small' else 3}])", "per_gpu_batch": B, "global_batch": B * world,
                              "num_node": N_NODE, "num_time": N_TIME, "filters": ENC, "dataset_samples_per_gpu": P,
                              "parallelism": f"dp{world}", "losses_finite": finite},
@@ -344,6 +344,7 @@ def main():
         eng.kernel_time_reset(False)
         if rank == 0:
             cls_stat = {}
+            enc = [0.0, 0.0, 0]      # north_star: "the encoder conv stack" = every convolution under encoder.* (forward, dX, dW)
             for tag, tms, calls in tags:
                 if "|" not in tag:
                     continue
@@ -352,6 +353,15 @@ def main():
                 fl = 2.0 * int(d["M"]) * int(d["N"]) * int(d["K"]) * int(d["taps"]) * calls
                 st = cls_stat.setdefault(cls, [0.0, 0.0, 0])
                 st[0] += fl; st[1] += tms; st[2] += calls
+                if _layer.startswith("encoder."):
+                    enc[0] += fl; enc[1] += tms; enc[2] += calls
+            if enc[2] and enc[1] > 0:
+                ach = enc[0] / (enc[1] * 1e-3) / 1e12
+                result["encoder_conv_stack"] = {
+                    "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                    "launches_per_step": enc[2] // nt, "ms_per_step": round(enc[1] / nt, 3), "flop_per_step": round(enc[0] / nt),
+                    "note": "all convolution launches of encoder.* (forward, input gradient, weight gradient; the fused Conv+GroupNorm+GELU "
+                            "stage kernels are counted with their whole duration): sum of 2*M*N*K*taps / sum of hipEvent durations"}
             traffic = load_traffic()
 
             def roof_obj(cls, kernel, note):

@@ -1731,7 +1731,14 @@ int sgv_rccl_unique_id(void* id128) {
     return rc ? rccl_fail("ncclGetUniqueId", rc) : SGV_OK;
 }
 static std::map<void*, int> g_comm_ranks;      // communicator -> number of ranks (one rank: the mean is the identity, nothing is issued)
-static bool comm_is_single(void* comm) { auto it = g_comm_ranks.find(comm); return it != g_comm_ranks.end() && it->second == 1; }
+// a one-rank communicator exchanges nothing: its all-reduces are skipped -- unless SGV_FORCE_COLLECTIVE=1 asks for the one-GPU
+// rehearsal of the N > 1 path (every bucket packed, handed to ncclAllReduce and unpacked as with more ranks)
+static bool comm_is_single(void* comm) {
+    const char* f = getenv("SGV_FORCE_COLLECTIVE");      // read per call: tests switch it inside one process
+    if (f && atoi(f) == 1) return false;
+    auto it = g_comm_ranks.find(comm);
+    return it != g_comm_ranks.end() && it->second == 1;
+}
 int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank) {
     if (!comm_out || !id128 || nranks < 1 || rank < 0 || rank >= nranks) return fail(SGV_ERR_ARG, "bad argument");
     CHK(rccl_load());

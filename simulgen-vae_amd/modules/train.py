@@ -90,13 +90,17 @@ class GradAllReduce:
     updates every layer whose bucket has arrived while the last, first-encoder-layer bucket is still in flight).
     Under a gloo group (tests, debugging) the mean is SUM followed by a scale, same bucket order."""
 
-    def __init__(self, engine, group=None, payload=None):
+    def __init__(self, engine, group=None, payload=None, force_collective=None):
         ptr, n = engine.grad_buffer()
         self.flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         self.group = group
         self.native_avg = dist.get_backend(group) == "nccl"
         self.inv_world = 1.0 / dist.get_world_size(group)
-        self.single = dist.get_world_size(group) == 1      # one rank: the mean over ranks is the identity, no collective is issued
+        # one rank: the mean over ranks is the identity, no collective is issued -- unless asked for (SGV_FORCE_COLLECTIVE=1 /
+        # force_collective: the one-GPU rehearsal of the N > 1 path, every bucket goes through RCCL as it does with more ranks)
+        if force_collective is None:
+            force_collective = os.environ.get("SGV_FORCE_COLLECTIVE") == "1"
+        self.single = dist.get_world_size(group) == 1 and not force_collective
         self.pending = []          # (bucket, work) in issue order == completion order on the RCCL stream
         self.nb = engine.bucket_count()
         # bf16 wire copy of the weight buckets (the engine packs at the fire point and unpacks in front of the bucket's AdamW)
@@ -178,8 +182,9 @@ class NativeAllReduce:
         if lib.sgv_rccl_comm_init(C.byref(comm), world, ident, rank) != 0:
             raise RuntimeError(lib.sgv_last_error().decode())
         self.comm = comm.value
-        self.single = world == 1
-        if world > 1 and grad_payload_dtype(engine) == "bf16":
+        forced = os.environ.get("SGV_FORCE_COLLECTIVE") == "1"     # one-GPU rehearsal of the N > 1 path (see GradAllReduce)
+        self.single = world == 1 and not forced
+        if not self.single and grad_payload_dtype(engine) == "bf16":
             engine.set_grad_payload("bf16")      # the engine packs, all-reduces the bf16 copy and unpacks by itself
         self.stream = torch.cuda.Stream()
         if not self.single:

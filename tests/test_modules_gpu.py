@@ -416,6 +416,82 @@ def test_two_rank_data_parallel_steps(tmp_path, payload):
         assert np.mean(np.abs(a - b)) <= tol, k
 
 
+@pytest.mark.parametrize("path,payload", [("torch", "f32"), ("torch", "bf16"), ("native", "f32"), ("native", "bf16")])
+def test_one_rank_forced_collectives_through_rccl(monkeypatch, path, payload):
+    """One-GPU rehearsal of the N > 1 step with REAL RCCL calls (SGV_FORCE_COLLECTIVE=1: a one-rank group normally issues no
+    collective at all, so nothing else on a one-GPU box runs ncclAllReduce(ncclAvg) on the fp32 arena / the bf16 wire copy,
+    the pack / unpack kernels around it and the stream-side waits of the bucket-ranged AdamW).  AVG over one rank is the
+    identity on what travels: the expected state is the plain step with, for payload bf16, every weight bucket rounded to
+    bf16 before AdamW (the small bucket stays fp32).  Both issue paths: torch.distributed (bucket callback) and the
+    engine's own communicator (sgv_set_rccl)."""
+    import torch.distributed as dist
+    from modules.train import GradAllReduce, NativeAllReduce, _DevArray
+    from simulgen_vae_amd.engine import Engine
+    from simulgen_vae_amd.init import init_state
+    from tests.gpu_common import G1
+    monkeypatch.setenv("SGV_FORCE_COLLECTIVE", "1")
+    monkeypatch.setenv("SGV_GRAD_PAYLOAD", payload)
+    cfg = make_cfg(G1)
+    B = 4
+    x = torch.from_numpy(synthetic_samples(5, range(B), cfg.num_node, cfg.num_time)).cuda()
+    state = init_state(cfg, 11, reference_init=True)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29523", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        outs = []
+        for mode in ("expect", path):
+            eng = Engine(cfg, max_batch=B, compute_dtype="f32")
+            eng.load_state(state)
+            eng.seed(99)
+            ar = None
+            if mode == "torch":
+                ar = GradAllReduce(eng)
+                assert not ar.single and (ar.flat_lp is not None) == (payload == "bf16")
+            elif mode == "native":
+                ar = NativeAllReduce(eng)
+                assert not ar.single
+            ranges = []
+            if mode == "expect":
+                ptr, n = eng.grad_buffer()
+                flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
+                eng.set_bucket_callback(lambda b, off, cnt: ranges.append((b, off, cnt)))
+            norms = []
+            for step in range(3):
+                eng.set_input(x)
+                eng.forward(train=True)
+                if ar is not None:
+                    ar.backward_step(eng, 1e6, 1e-4, 1e-3)
+                else:
+                    eng.backward(1e6, 1e-4)
+                    if step == 0:
+                        eng.set_bucket_callback(None)
+                    if payload == "bf16":
+                        small = eng.bucket_count() - 1
+                        for b, off, cnt in ranges:
+                            if b != small:
+                                flat[off:off + cnt] = flat[off:off + cnt].bfloat16().float()
+                    eng.adamw_step(1e-3)
+                norms.append(eng.last_grad_norm())
+            torch.cuda.synchronize()
+            outs.append((eng.state_dict(), norms))
+            if mode == "native":
+                eng.set_rccl(None, None)
+                ar.close()
+            eng.close()
+        (sa, na), (sb, nb_) = outs
+        assert all(np.isfinite(nb_))
+        np.testing.assert_allclose(na, nb_, rtol=1e-4)
+        for k in sa:
+            a, b = sa[k].astype(np.float64), sb[k].astype(np.float64)
+            assert np.mean(np.abs(a - b)) <= 3e-4 * np.mean(np.abs(a)) + 1e-9, k
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_fused_backward_step_equals_separate_calls():
     """sgv_backward_step (AdamW of finished buckets started on the side stream under the rest of backward) leaves the
     state of sgv_backward + sgv_adamw_step; gradients stay exportable afterwards.  fp32 compute, compared in the mean
