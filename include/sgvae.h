@@ -180,6 +180,19 @@ int sgv_adamw_step(sgv_engine* e, float lr);
  * optimisation step, last=1 on the final one; every bucket must be covered exactly once per step. */
 int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last);
 int sgv_bucket_count(const sgv_engine* e);
+/* Optimizer overlap for the data-parallel step (the reference's loop is optimizer.step() after backward, modules/train.py:153-168;
+ * torch's DDP hides the all-reduce under backward, this also hides the update).  The <G,W> scalars of the conv layers of weight
+ * bucket b sit together at the head of the small bucket's range: sgv_bucket_dots returns that sub-range, and they are final when
+ * the bucket's callback fires.  A caller that averages [offset, +count) together with bucket b -- and leaves the union of those
+ * sub-ranges (the first sum-of-counts elements of the small bucket) out of the small bucket's collective -- may then call
+ * sgv_adamw_bucket_async(lr, b) as soon as it has made the optimizer stream (sgv_opt_stream) wait for both collectives: the
+ * bucket's conv weights are updated on that stream under the rest of backward.  The sgv_adamw_step_range calls that close the
+ * step (same bucket coverage as without the overlap) skip what was updated ahead, and last=1 joins the optimizer stream.
+ * With sgv_set_rccl, sgv_backward_step does all of this by itself (option "ddp_early_adamw", default 1).  Linear-head weights,
+ * biases and GroupNorm affine are updated by the closing calls: their <G,W> scalars are computed at the end of backward. */
+int sgv_bucket_dots(const sgv_engine* e, int bucket, size_t* offset_elems, size_t* count_elems);
+int sgv_opt_stream(sgv_engine* e, void** hip_stream);
+int sgv_adamw_bucket_async(sgv_engine* e, float lr, int bucket);
 /* Wire format of the data-parallel gradient exchange (the reference's DDP all-reduces fp32 gradients, modules/utils.py:209-238
  * sets the process group up and torch does the rest; this is the build's own choice for bf16 engines).  SGV_DTYPE_F32: the
  * buckets are ranges of the fp32 arena (default).  SGV_DTYPE_BF16: at its fire point every weight bucket is rounded (RNE) into a

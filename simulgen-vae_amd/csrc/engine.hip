@@ -127,6 +127,7 @@ struct sgv_engine {
     WorkItem* items_ts = nullptr; WorkItem* items_ss = nullptr; int n_items_ts = 0, n_items_ss = 0;
     float* lin_dot_part = nullptr;                   // per-work-item <G,W>/sigma partials of the Linear layers
     std::vector<FinDot> fin_lin_dots;
+    std::vector<int> dot_off, fin_lin_off;           // [bucket] -> first Linear <G,W> work item / first fin_lin_dots entry (tables sorted by bucket)
     double* gnorm_part = nullptr; int n_gnorm_part = 0;   // per-work-item sums of squared gradients of the AdamW passes
     float* sn_sigma = nullptr;
     float* sn_alpha = nullptr; size_t n_sn_alpha = 0;   // per-layer vectors of 1/sigma (Layer::alpha)
@@ -145,6 +146,19 @@ struct sgv_engine {
     // data-parallel wire format of the weight buckets: 0 = the fp32 arena itself, 1 = a bf16 copy (packed at the bucket's fire point,
     // averaged by the collective, unpacked into the arena in front of the bucket's AdamW).  The small bucket always travels in fp32.
     int payload_bf16 = 0; void* grads_lp = nullptr; std::vector<char> bucket_packed;
+    // data-parallel optimizer overlap: the <G,W_eff> scalars of a weight bucket's layers sit together at the head of the small zone
+    // (bucket_dots[b] = their range), so they can be averaged WITH the bucket instead of with the small bucket at the end of backward;
+    // the bucket's conv-weight AdamW then runs on `opt` as soon as both collectives have landed, under the rest of backward
+    // (sgv_adamw_bucket_async; the engine's own RCCL path does it by itself in sgv_backward_step).  bucket_updated[b]: done this step.
+    std::vector<std::pair<size_t, size_t>> bucket_dots; size_t dots_total = 0;
+    hipStream_t opt = nullptr; bool opt_dirty = false, adam_open = false;
+    std::vector<char> bucket_updated;
+    int ddp_early = getenv("SGV_DDP_EARLY") ? atoi(getenv("SGV_DDP_EARLY")) : 1;
+    // bf16 wire format: the conv-weight AdamW reads a packed bucket straight from the averaged bf16 copy (no unpack pass; the fp32
+    // arena keeps this rank's own gradients); only the few weights of a bucket that the flat pass updates (Linear heads:
+    // bucket_flat_w) are unpacked.  bucket_packed[b]: bit 0 = conv-weight part still packed, bit 1 = flat part still packed.
+    int lp_direct = getenv("SGV_LP_DIRECT") ? atoi(getenv("SGV_LP_DIRECT")) : 1;
+    std::vector<std::vector<std::pair<size_t, size_t>>> bucket_flat_w;
     float* partial_tn = nullptr; size_t partial_tn_floats = 0;
     std::vector<hipEvent_t> ev_pool; size_t ev_next = 0;
     bool use_side = true, side_dirty = false;
@@ -440,18 +454,29 @@ static int layout_grads(sgv_engine* e) {
     size_t ng = 0;
     auto take = [&](size_t n) { size_t o = ng; ng = align_up(ng + n, 4); return o; };
     e->buckets.clear();
-    for (auto& sec : sections) {
+    std::vector<int> placed;          // sections that became buckets
+    for (size_t si = 0; si < sections.size(); ++si) {
         size_t start = ng;
-        for (int li : sec) {
+        for (int li : sections[si]) {
             Layer& l = e->layers[li];
             if (!l.has_grad) continue;
             l.gw = take((size_t)l.nw());
         }
-        if (ng > start) e->buckets.push_back({start, ng - start});
+        if (ng > start) { e->buckets.push_back({start, ng - start}); placed.push_back((int)si); }
     }
     e->n_grads_w = ng;
     size_t small_start = ng;
-    for (auto& l : e->layers) if (l.has_grad) { l.gdot = take(SGV_DOT_SLOTS); l.gb = take(l.cout); }
+    // head of the small zone: the <G,W_eff> slots of the CONV layers, bucket by bucket (bucket_dots: final once the bucket's dY
+    // kernels are enqueued); then the Linear layers' slots (computed from G itself at the end of backward, they travel with the
+    // small bucket), biases and GroupNorm affine
+    e->bucket_dots.clear();
+    for (int si : placed) {
+        const size_t d0 = ng;
+        for (int li : sections[si]) { Layer& l = e->layers[li]; if (l.has_grad && l.op != OP_LINEAR && l.gdot == NPOS) l.gdot = take(SGV_DOT_SLOTS); }
+        e->bucket_dots.push_back({d0, ng - d0});
+    }
+    e->dots_total = ng - small_start;
+    for (auto& l : e->layers) if (l.has_grad) { if (l.gdot == NPOS) l.gdot = take(SGV_DOT_SLOTS); l.gb = take(l.cout); }
     for (auto& g : e->gns) if (g.has_grad) { g.ggamma = take(g.C); g.gbeta = take(g.C); }
     e->buckets.push_back({small_start, ng - small_start});
     e->n_grads = ng;
@@ -640,7 +665,8 @@ static int upload_tables(sgv_engine* e) {
     std::vector<WorkItem> i_sn, i_sn_unf, i_dot, i_adam, i_adam_flat, i_adam_2d, i_copy, i_wct, i_ts, i_ss;
     e->fin_lin_dots.clear();
     const int nbk = (int)e->buckets.size();
-    std::vector<std::vector<WorkItem>> flat_b(nbk), tile_b(nbk);
+    std::vector<std::vector<WorkItem>> flat_b(nbk), tile_b(nbk), dot_b(nbk);
+    std::vector<std::vector<FinDot>> fin_lin_b(nbk);
     auto bucket_of = [&](size_t goff) {
         for (int b = 0; b < nbk; ++b) if (goff >= e->buckets[b].first && goff < e->buckets[b].first + e->buckets[b].second) return b;
         return nbk - 1;
@@ -668,10 +694,21 @@ static int upload_tables(sgv_engine* e) {
         }
         if (l.has_grad && l.op == OP_LINEAR) {   // conv layers get <G,W_eff> from their dY kernels (ew.hip)
             const long nch = (l.nw() + OPT_CHUNK - 1) / OPT_CHUNK;
-            e->fin_lin_dots.push_back({(const float*)(uintptr_t)i_dot.size(), e->grads + l.gdot, (int)nch, 0});   // src = index for now, rebased below
-            for (long c = 0; c < nch; ++c) i_dot.push_back({i, (int)c});
+            const int bk = bucket_of(l.gw);
+            fin_lin_b[bk].push_back({(const float*)(uintptr_t)dot_b[bk].size(), e->grads + l.gdot, (int)nch, 0});   // src = index inside the bucket for now, rebased below
+            for (long c = 0; c < nch; ++c) dot_b[bk].push_back({i, (int)c});
         }
     }
+    // Linear <G,W> items sorted by gradient bucket: a data-parallel backward computes a bucket's share before the bucket is
+    // released (the collective may reduce the bucket's gradients in place while backward goes on)
+    e->dot_off.assign(nbk + 1, 0); e->fin_lin_off.assign(nbk + 1, 0);
+    for (int b = 0; b < nbk; ++b) {
+        for (auto f : fin_lin_b[b]) { f.src = (const float*)((uintptr_t)f.src + i_dot.size()); e->fin_lin_dots.push_back(f); }
+        i_dot.insert(i_dot.end(), dot_b[b].begin(), dot_b[b].end());
+        e->dot_off[b + 1] = (int)i_dot.size(); e->fin_lin_off[b + 1] = (int)e->fin_lin_dots.size();
+    }
+    // the small bucket (which carries these scalars) is released before the last weight bucket: that one must hold no Linear layer
+    if (nbk >= 2 && e->dot_off[nbk] != e->dot_off[nbk - 2]) return fail(SGV_ERR_STATE, "a Linear layer sits in the last weight bucket");
     e->adam_host.clear();
     auto add_adam = [&](size_t p, size_t g, long n, int sn, int rows, int cols, int taps, void* wc, void* wct, bool tiled = false) {
         AdamDesc a;
@@ -717,6 +754,8 @@ static int upload_tables(sgv_engine* e) {
         add_adam(g.gamma, g.ggamma, g.C, -1, 1, g.C, 1, nullptr, nullptr);
         add_adam(g.beta, g.gbeta, g.C, -1, 1, g.C, 1, nullptr, nullptr);
     }
+    e->bucket_flat_w.assign(nbk, {});
+    for (auto& l : e->layers) if (l.has_grad && !layer_fused_adam(l)) e->bucket_flat_w[bucket_of(l.gw)].push_back({l.gw, (size_t)l.nw()});
     e->flat_off.assign(nbk + 1, 0); e->tile_off.assign(nbk + 1, 0);
     for (int b = 0; b < nbk; ++b) {
         i_adam_flat.insert(i_adam_flat.end(), flat_b[b].begin(), flat_b[b].end());
@@ -1243,6 +1282,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     }
     ALLOC(e->red, e->red_floats * 4);
     if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { e->side = nullptr; e->use_side = false; }
+    if (hipStreamCreateWithFlags(&e->opt, hipStreamNonBlocking) != hipSuccess) e->opt = nullptr;
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
     ALLOC(e->colpart, e->colpart_floats * 4);
@@ -1263,6 +1303,7 @@ int sgv_destroy(sgv_engine* e) {
                     e->items_sn_unf, e->items_adam_flat, e->items_adam_2d, e->items_ts, e->items_ss, e->lin_dot_part, e->gnorm_part};
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->side) { hipStreamSynchronize(e->side); gemm_nt_vendor_release_stream(e->side); hipStreamDestroy(e->side); }
+    if (e->opt) { hipStreamSynchronize(e->opt); hipStreamDestroy(e->opt); }
     if (e->lane2) { hipStreamSynchronize(e->lane2); gemm_nt_vendor_release_stream(e->lane2); hipStreamDestroy(e->lane2); }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
     if (e->lane_join) hipEventDestroy(e->lane_join);
@@ -1482,6 +1523,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     if (!strcmp(key, "write_xhat")) e->write_xhat = value != 0;
     else if (!strcmp(key, "use_tr")) e->use_tr = value != 0;
     else if (!strcmp(key, "dw_side_stream")) e->use_side = value != 0 && e->side != nullptr;
+    else if (!strcmp(key, "ddp_early_adamw")) e->ddp_early = value != 0;
     else if (!strcmp(key, "vendor_gemm")) e->vendor_gemm = value != 0;
     else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
     else if (!strcmp(key, "lanes")) e->use_lanes = value != 0 && e->lane2 != nullptr;          // second compute lane (schedule only: results are bitwise the same)
@@ -1754,19 +1796,28 @@ int sgv_rccl_comm_destroy(void* comm) {
     const int rc = g_rccl.CommDestroy(comm);
     return rc ? rccl_fail("ncclCommDestroy", rc) : SGV_OK;
 }
-// bucket b: wait (on the communication stream) for what the engine stream holds so far, average it over the ranks
-static int rccl_bucket(sgv_engine* e, void* comm, hipStream_t cs, int b, hipEvent_t done) {
+// bucket b: wait (on the communication stream) for what the engine stream holds so far, average it over the ranks.
+// split_dots: the <G,W_eff> slots of a weight bucket's conv layers travel with the bucket (a second, tiny fp32 all-reduce of
+// bucket_dots[b]) and the small bucket leaves them out -- the bucket's AdamW then needs nothing from the end of backward.
+static int rccl_bucket(sgv_engine* e, void* comm, hipStream_t cs, int b, hipEvent_t done, bool split_dots = false) {
     hipEvent_t ev = next_event(e);
     if (!ev) return fail(SGV_ERR_HIP, "event creation failed");
     HIPCHK(hipEventRecord(ev, e->stream));
     HIPCHK(hipStreamWaitEvent(cs, ev, 0));
     float* g = e->grads + e->buckets[b].first;
-    auto it = g_comm_ranks.find(comm);
-    if (it == g_comm_ranks.end() || it->second != 1) {
+    if (!comm_is_single(comm)) {
+        const bool small = b == (int)e->buckets.size() - 1;
         const bool lp = b < (int)e->bucket_packed.size() && e->bucket_packed[b];
         void* w = lp ? (void*)((char*)e->grads_lp + 2 * e->buckets[b].first) : (void*)g;
-        const int rc = g_rccl.AllReduce(w, w, e->buckets[b].second, lp ? kNcclBfloat16 : kNcclFloat32, kNcclAvg, comm, cs);
+        size_t cnt = e->buckets[b].second;
+        if (small && split_dots) { w = (void*)(g + e->dots_total); cnt -= e->dots_total; }
+        int rc = g_rccl.AllReduce(w, w, cnt, lp ? kNcclBfloat16 : kNcclFloat32, kNcclAvg, comm, cs);
         if (rc) return rccl_fail("ncclAllReduce", rc);
+        if (!small && split_dots && e->bucket_dots[b].second) {
+            float* d = e->grads + e->bucket_dots[b].first;
+            rc = g_rccl.AllReduce(d, d, e->bucket_dots[b].second, kNcclFloat32, kNcclAvg, comm, cs);
+            if (rc) return rccl_fail("ncclAllReduce(<G,W> slots)", rc);
+        }
     }
     if (done) HIPCHK(hipEventRecord(done, cs));
     return 0;
@@ -1822,7 +1873,9 @@ int sgv_scale_grads(sgv_engine* e, float factor) {
 }
 
 static int adamw_begin(sgv_engine* e);
+static int adamw_finish(sgv_engine* e);
 static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int which, hipStream_t st);
+static int adamw_bucket_async(sgv_engine* e, float lr, int b, hipStream_t st);
 int sgv_adamw_step(sgv_engine* e, float lr);
 // fuse_lr >= 0: also run the optimizer, and start the AdamW of every conv-weight bucket on the side stream as soon as
 // that bucket's gradients are final, under the rest of backward (single-GPU path: no bucket callback registered)
@@ -1832,7 +1885,11 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     const bool fuse = fuse_lr >= 0.f;
     static const int early_on = getenv("SGV_EARLY_ADAM") ? atoi(getenv("SGV_EARLY_ADAM")) : 1;
     const bool early = early_on && fuse && !e->cb && !e->comm && e->side && e->use_side && !e->timing;
-    if (early) CHK(adamw_begin(e));
+    // engine-issued collectives with the learning rate in hand (sgv_backward_step on a registered communicator): every weight
+    // bucket's <G,W> slots are averaged with the bucket and its conv-weight AdamW starts on the optimizer stream as soon as both
+    // have landed, under the rest of backward -- the data-parallel mirror of `early`
+    const bool dearly = e->ddp_early && fuse && e->comm && !comm_is_single(e->comm) && e->opt && !e->timing;
+    if (early || dearly) CHK(adamw_begin(e));
     const int B = e->batch, n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
     const float coefB = beta / (float)B;
@@ -1844,11 +1901,16 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         if (e->payload_bf16 && (e->comm || e->cb) && b != (int)e->buckets.size() - 1 && !(e->comm && comm_is_single(e->comm))) {
             if (join_side(e)) { early_err = 1; return; }
             ew_pack_bf16(e->grads + e->buckets[b].first, (char*)e->grads_lp + 2 * e->buckets[b].first, (long)e->buckets[b].second, e->stream);
-            e->bucket_packed[b] = 1;
+            e->bucket_packed[b] = 3;
         }
         if (e->comm) {
-            if (join_side(e) || rccl_bucket(e, e->comm, e->comm_stream, b, e->bucket_done[b])) { early_err = 1; return; }
+            if (join_side(e) || rccl_bucket(e, e->comm, e->comm_stream, b, e->bucket_done[b], dearly)) { early_err = 1; return; }
             e->bucket_pending[b] = 1;
+            if (dearly && b < (int)e->buckets.size() - 2) {
+                if (hipStreamWaitEvent(e->opt, e->bucket_done[b], 0) != hipSuccess) { early_err = 1; return; }
+                e->bucket_pending[b] = 0;
+                if (adamw_bucket_async(e, fuse_lr, b, e->opt)) early_err = 1;
+            }
         } else if (e->cb) {
             join_side(e);     // the bucket's weight gradients come from the side stream
             e->cb(e->cb_user, b, e->buckets[b].first, e->buckets[b].second);
@@ -1868,7 +1930,17 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         if (affine && !e->fin_affine.empty()) { ew_fin_affine(e->fin_affine.data(), (int)e->fin_affine.size(), e->stream); e->fin_affine.clear(); }
     };
     e->fin_dots.clear(); e->fin_affine.clear();
-    auto fire = [&]() { flush_fin(false); fire_at(bucket); ++bucket; };
+    // <G,W_eff> of the Linear layers is computed from G itself: in one launch at the end of backward -- unless a collective may
+    // already be reducing a released bucket's gradients in place by then (fp32 wire format): with a callback or a communicator
+    // every bucket's Linear layers get theirs at the bucket's fire point.  Same per-item partials, same fixed-order sums.
+    const bool dots_per_bucket = e->cb || e->comm;
+    int lin_err = 0;
+    auto lin_dots = [&](int b0, int b1) {
+        const int d0 = e->dot_off[b0], d1 = e->dot_off[b1];
+        if (d1 > d0 && opt_sn_grad_dot(e->sn_dev, e->items_dot + d0, d1 - d0, e->lin_dot_part + d0, e->stream)) lin_err = 1;
+        e->fin_dots.insert(e->fin_dots.end(), e->fin_lin_dots.begin() + e->fin_lin_off[b0], e->fin_lin_dots.begin() + e->fin_lin_off[b1]);
+    };
+    auto fire = [&]() { if (dots_per_bucket) lin_dots(bucket, bucket + 1); flush_fin(false); fire_at(bucket); ++bucket; };
     const int small_bucket = (int)e->buckets.size() - 1;
     // no zero-fills: every gradient of the small zone (biases, GroupNorm affine, <G,W_eff> slot 0) and every backward group sum
     // is written, not accumulated, by its fixed-order reduction; tensors that get no gradient stay at their initial zero
@@ -1945,8 +2017,8 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         if (i == 0) {
             fire();   // everything but the first block's weight gradients is now enqueued
             // <G,W_eff> of the (small) Linear layers from their weights; conv layers accumulated theirs in the dY kernels
-            if (opt_sn_grad_dot(e->sn_dev, e->items_dot, e->n_items_dot, e->lin_dot_part, e->stream)) return fail(SGV_ERR_HIP, "grad-dot launch failed");
-            e->fin_dots.insert(e->fin_dots.end(), e->fin_lin_dots.begin(), e->fin_lin_dots.end());
+            if (!dots_per_bucket) lin_dots(0, (int)e->buckets.size());
+            if (lin_err) return fail(SGV_ERR_HIP, "grad-dot launch failed");
             // the small zone (biases, GroupNorm affine, <G,W_eff> scalars) is complete once the first conv's dY exists:
             // release it BEFORE the first-layer weight-gradient GEMM so that its all-reduce (and, with it, the AdamW
             // of every other layer) does not queue behind the 390 MB first-layer bucket
@@ -1966,9 +2038,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             CHK(adamw_range(e, fuse_lr, 0, nbk, 2, e->stream));           // every flat item
             e->side_dirty = true;                                          // AdamW launches may still run on the side stream
             CHK(join_side(e));
-            ew_rowsum_d(e->gnorm_part, e->n_items_adam_flat + e->n_items_adam_2d, 1, e->scal + 15, 1.0, e->stream);
-            e->copies_fresh = true;
-            e->wtu_fresh = true;
+            CHK(adamw_finish(e));
         } else {
             CHK(join_side(e));
             if (!e->cb) CHK(sgv_adamw_step(e, fuse_lr));
@@ -1998,10 +2068,50 @@ int sgv_grad_norm(sgv_engine* e, double* out) {
 
 // which: 1 = conv-weight tiles, 2 = flat items (biases, GroupNorm affine, Linear heads), 3 = both
 static int adamw_begin(sgv_engine* e) {
+    if (e->adam_open) return 0;          // a bucket of this step was updated ahead of the caller's first=1 call
     e->step += 1;
     e->copies_fresh = false;
     e->wtu_fresh = false;
+    e->adam_open = true;
+    e->bucket_updated.assign(e->buckets.size(), 0);
     return 0;
+}
+// end of an optimisation step: whatever ran on the optimizer stream joins the engine stream, gradient norm^2 in a fixed order
+static int adamw_finish(sgv_engine* e) {
+    if (e->opt_dirty) {
+        hipEvent_t ev = next_event(e);
+        if (!ev) return fail(SGV_ERR_HIP, "event creation failed");
+        HIPCHK(hipEventRecord(ev, e->opt));
+        HIPCHK(hipStreamWaitEvent(e->stream, ev, 0));
+        e->opt_dirty = false;
+    }
+    e->copies_fresh = true;
+    e->wtu_fresh = true;
+    e->adam_open = false;
+    ew_rowsum_d(e->gnorm_part, e->n_items_adam_flat + e->n_items_adam_2d, 1, e->scal + 15, 1.0, e->stream);
+    return 0;
+}
+struct AdamCoef { float b1, b2, bc1, bc2s; };
+static AdamCoef adam_coef(const sgv_engine* e) {
+    const double b1 = 0.9, b2 = 0.999;
+    return {(float)b1, (float)b2, (float)(1.0 - pow(b1, (double)e->step)), (float)sqrt(1.0 - pow(b2, (double)e->step))};
+}
+static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, bool from_lp = false) {
+    if (t1 <= t0) return 0;
+    const AdamCoef c = adam_coef(e);
+    if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, c.b1, c.b2, 1e-8f, 0.01f, c.bc1, c.bc2s, e->gnorm_part + e->n_items_adam_flat + t0, e->dt, st,
+                     e->grads, from_lp ? e->grads_lp : nullptr))
+        return fail(SGV_ERR_HIP, "adamw launch failed");
+    return 0;
+}
+static void unpack_bucket(sgv_engine* e, int b, hipStream_t st) {
+    ew_unpack_bf16((const char*)e->grads_lp + 2 * e->buckets[b].first, e->grads + e->buckets[b].first, (long)e->buckets[b].second, st);
+    e->bucket_packed[b] = 0;
+}
+// what the flat pass reads of a packed weight bucket (Linear heads)
+static void unpack_bucket_flat(sgv_engine* e, int b, hipStream_t st) {
+    for (auto& r : e->bucket_flat_w[b]) ew_unpack_bf16((const char*)e->grads_lp + 2 * r.first, e->grads + r.first, (long)r.second, st);
+    e->bucket_packed[b] &= ~2;
 }
 static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int which, hipStream_t st) {
     // native RCCL path: the all-reduce of every bucket touched here must have landed, and so must the small bucket's
@@ -2012,35 +2122,75 @@ static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, in
             HIPCHK(hipStreamWaitEvent(st, e->bucket_done[b], 0));
             e->bucket_pending[b] = 0;
         }
-    for (int b = bucket_lo; b < bucket_hi && b < (int)e->bucket_packed.size(); ++b)
-        if (e->bucket_packed[b]) {      // the averaged bf16 wire copy back into the fp32 arena AdamW reads
-            ew_unpack_bf16((const char*)e->grads_lp + 2 * e->buckets[b].first, e->grads + e->buckets[b].first, (long)e->buckets[b].second, st);
-            e->bucket_packed[b] = 0;
-        }
-    const double b1 = 0.9, b2 = 0.999;
-    const float bc1 = (float)(1.0 - pow(b1, (double)e->step));
-    const float bc2s = (float)sqrt(1.0 - pow(b2, (double)e->step));
+    // the averaged bf16 wire copy: the tiled pass reads it in place (lp_direct), the flat pass gets its few weights unpacked
+    const int np = (int)e->bucket_packed.size();
+    for (int b = bucket_lo; b < bucket_hi && b < np; ++b) {
+        if (!e->bucket_packed[b]) continue;
+        if (!e->lp_direct) unpack_bucket(e, b, st);
+        else if ((which & 2) && (e->bucket_packed[b] & 2)) unpack_bucket_flat(e, b, st);
+    }
     // biases, GroupNorm affine and the Linear heads: flat pass.  Conv weights: tiled pass that also writes both
-    // compute copies and W_new^T u for the next forward's power iteration.
-    const int f0 = e->flat_off[bucket_lo], f1 = e->flat_off[bucket_hi], t0 = e->tile_off[bucket_lo], t1 = e->tile_off[bucket_hi];
-    if ((which & 2) && opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->gnorm_part + f0, e->dt, st))
+    // compute copies and W_new^T u for the next forward's power iteration; buckets updated ahead (adamw_bucket_async) are skipped.
+    const AdamCoef c = adam_coef(e);
+    const int f0 = e->flat_off[bucket_lo], f1 = e->flat_off[bucket_hi];
+    if ((which & 2) && opt_adamw(e->adam_dev, e->sn_dev, e->items_adam_flat + f0, f1 - f0, lr, c.b1, c.b2, 1e-8f, 0.01f, c.bc1, c.bc2s, e->gnorm_part + f0, e->dt, st))
         return fail(SGV_ERR_HIP, "adamw launch failed");
-    if ((which & 1) && opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, (float)b1, (float)b2, 1e-8f, 0.01f, bc1, bc2s, e->gnorm_part + e->n_items_adam_flat + t0, e->dt, st))
-        return fail(SGV_ERR_HIP, "adamw launch failed");
+    if (which & 1) {
+        const int nu = (int)e->bucket_updated.size();
+        auto skip = [&](int b) { return b < nu && e->bucket_updated[b]; };
+        auto lp = [&](int b) { return b < np && (e->bucket_packed[b] & 1); };
+        for (int b = bucket_lo; b < bucket_hi;) {
+            if (skip(b)) { ++b; continue; }
+            int h = b + 1;
+            while (h < bucket_hi && !skip(h) && lp(h) == lp(b)) ++h;          // runs of buckets read from the same place
+            CHK(adamw_tiles(e, lr, e->tile_off[b], e->tile_off[h], st, lp(b)));
+            for (int k = b; k < h; ++k) if (k < np) e->bucket_packed[k] &= ~1;
+            b = h;
+        }
+    }
     return 0;
+}
+// conv-weight AdamW of ONE weight bucket on `st`, ahead of the rest of the step: the caller has made `st` wait for the bucket's
+// gradients (and their all-reduce) and for the <G,W> slots of its layers (bucket_dots)
+static int adamw_bucket_async(sgv_engine* e, float lr, int b, hipStream_t st) {
+    CHK(adamw_begin(e));
+    const bool packed = b < (int)e->bucket_packed.size() && e->bucket_packed[b];
+    if (packed && !e->lp_direct) unpack_bucket(e, b, st);
+    const bool from_lp = packed && e->lp_direct && (e->bucket_packed[b] & 1);
+    CHK(adamw_tiles(e, lr, e->tile_off[b], e->tile_off[b + 1], st, from_lp));
+    if (from_lp) e->bucket_packed[b] &= ~1;
+    e->bucket_updated[b] = 1;
+    if (st != e->stream) e->opt_dirty = e->opt_dirty || st == e->opt;
+    return 0;
+}
+int sgv_bucket_dots(const sgv_engine* e, int bucket, size_t* offset_elems, size_t* count_elems) {
+    if (!e || !offset_elems || !count_elems) return fail(SGV_ERR_ARG, "null argument");
+    if (bucket < 0 || bucket >= (int)e->bucket_dots.size()) return fail(SGV_ERR_ARG, "bucket %d is not a weight bucket [0,%d)", bucket, (int)e->bucket_dots.size());
+    *offset_elems = e->bucket_dots[bucket].first; *count_elems = e->bucket_dots[bucket].second;
+    return SGV_OK;
+}
+int sgv_opt_stream(sgv_engine* e, void** stream) {
+    if (!e || !stream) return fail(SGV_ERR_ARG, "null argument");
+    if (!e->opt) return fail(SGV_ERR_HIP, "the engine has no optimizer stream");
+    *stream = (void*)e->opt;
+    return SGV_OK;
+}
+int sgv_adamw_bucket_async(sgv_engine* e, float lr, int bucket) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (lr < 0.f) return fail(SGV_ERR_ARG, "negative learning rate");
+    if (!e->opt) return fail(SGV_ERR_HIP, "the engine has no optimizer stream");
+    if (bucket < 0 || bucket >= (int)e->buckets.size() - 1) return fail(SGV_ERR_ARG, "bucket %d is not a weight bucket [0,%d)", bucket, (int)e->buckets.size() - 1);
+    if (e->adam_open && e->bucket_updated[bucket]) return fail(SGV_ERR_STATE, "bucket %d was already updated in this step", bucket);
+    return adamw_bucket_async(e, lr, bucket, e->opt);
 }
 int sgv_adamw_step_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int first, int last) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
     const int nbk = (int)e->buckets.size();
     if (bucket_lo < 0 || bucket_hi > nbk || bucket_lo > bucket_hi) return fail(SGV_ERR_ARG, "bucket range [%d,%d) outside [0,%d)", bucket_lo, bucket_hi, nbk);
     if (first) CHK(adamw_begin(e));
-    if (e->step < 1) return fail(SGV_ERR_STATE, "sgv_adamw_step_range: the first call of a step must pass first=1");
+    if (e->step < 1 || !e->adam_open) return fail(SGV_ERR_STATE, "sgv_adamw_step_range: the first call of a step must pass first=1");
     CHK(adamw_range(e, lr, bucket_lo, bucket_hi, 3, e->stream));
-    if (last) {
-        e->copies_fresh = true;
-        e->wtu_fresh = true;
-        ew_rowsum_d(e->gnorm_part, e->n_items_adam_flat + e->n_items_adam_2d, 1, e->scal + 15, 1.0, e->stream);   // gradient norm^2, fixed order
-    }
+    if (last) CHK(adamw_finish(e));
     return SGV_OK;
 }
 int sgv_adamw_step(sgv_engine* e, float lr) {

@@ -286,10 +286,12 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
 // registers: the compute-dtype copy wc, the transposed/tap-flipped copy wct (through an LDS tile) and the
 // first half of the NEXT forward's power iteration, tpart[row tile][tap][c] = sum_{r in tile} W_new[r][c] * u[r]  (u is only
 // modified by the forward itself).  Saves two full passes over the 1.6 GB of master weights per step.
-template <typename T>
+// GLP: the gradient is read from the bf16 data-parallel wire copy (g_lp, same element offsets as the fp32 arena g_base) instead of
+// the arena -- the averaged bucket goes straight from the collective into the update, no unpack pass in between.
+template <typename T, bool GLP = false>
 __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
                                                       float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
-                                                      double* gnorm_sq) {
+                                                      double* gnorm_sq, const float* g_base = nullptr, const uint16_t* g_lp = nullptr) {
     constexpr int PITCH = 64 + (sizeof(T) == 2 ? 2 : 1);
     __shared__ T tile[64 * PITCH];
     __shared__ float tus[16][64];
@@ -320,7 +322,14 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
         float4 p = make_float4(0.f, 0.f, 0.f, 0.f);
         if (cok && row < a.rows) {
             const long i = base + (long)row * a.cols + col;
-            float4 g = *reinterpret_cast<const float4*>(a.g + i);
+            float4 g;
+            if constexpr (GLP) {
+                const uint2 raw = *reinterpret_cast<const uint2*>(g_lp + ((a.g + i) - g_base));       // 4 bf16, 8-byte aligned
+                g.x = __builtin_bit_cast(float, raw.x << 16); g.y = __builtin_bit_cast(float, raw.x & 0xFFFF0000u);
+                g.z = __builtin_bit_cast(float, raw.y << 16); g.w = __builtin_bit_cast(float, raw.y & 0xFFFF0000u);
+            } else {
+                g = *reinterpret_cast<const float4*>(a.g + i);
+            }
             p = *reinterpret_cast<const float4*>(a.p + i);
             float4 m = *reinterpret_cast<const float4*>(a.m + i);
             float4 vs = *reinterpret_cast<const float4*>(a.v + i);
@@ -373,10 +382,16 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
     }
 }
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
-                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s) {
+                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* g_base, const void* g_lp) {
     if (n <= 0) return 0;
-    if (compute_dtype == 1) hipLaunchKernelGGL((adamw_sn_kernel<bf16_t>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
-    else hipLaunchKernelGGL((adamw_sn_kernel<float>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq);
+    if (g_lp) {
+        const uint16_t* lp = reinterpret_cast<const uint16_t*>(g_lp);
+        if (compute_dtype == 1) hipLaunchKernelGGL((adamw_sn_kernel<bf16_t, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp);
+        else hipLaunchKernelGGL((adamw_sn_kernel<float, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+    if (compute_dtype == 1) hipLaunchKernelGGL((adamw_sn_kernel<bf16_t, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, (const float*)nullptr, (const uint16_t*)nullptr);
+    else hipLaunchKernelGGL((adamw_sn_kernel<float, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, (const float*)nullptr, (const uint16_t*)nullptr);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,

@@ -188,7 +188,8 @@ int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* it
 // table base + the offset of `items` in the table; the caller sums the whole table in index order (ew_rowsum_d)
 // 64x64-tile AdamW for spectrally-normalised conv weights; also writes wc/wct and accumulates W_new^T u into tmp_t
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
-                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s);
+                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s,
+                 const float* g_base = nullptr, const void* g_lp = nullptr);      // g_lp: gradients from the bf16 wire copy (offsets relative to g_base)
 int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
                   hipStream_t s);
 int opt_make_copies(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s);

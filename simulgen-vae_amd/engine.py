@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
-    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
+    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_rccl_unique_id", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_lib", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn",
@@ -88,6 +88,9 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_backward_step.argtypes = [vp, f32, f32, f32]
     lib.sgv_adamw_step_range.argtypes = [vp, f32, i32, i32, i32, i32]
     lib.sgv_bucket_count.argtypes = [vp]
+    lib.sgv_bucket_dots.argtypes = [vp, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    lib.sgv_opt_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.sgv_adamw_bucket_async.argtypes = [vp, f32, i32]
     lib.sgv_set_grad_payload.argtypes = [vp, C.c_int]
     lib.sgv_grad_payload_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
     lib.sgv_grad_payload_unpack.argtypes = [vp]
@@ -303,6 +306,23 @@ class Engine:
 
     def bucket_count(self) -> int:
         return int(self.lib.sgv_bucket_count(self.h))
+
+    def bucket_dots(self, bucket: int):
+        """(offset, count) in the fp32 gradient arena of the <G,W> scalars of weight bucket `bucket`'s conv layers."""
+        off, cnt = C.c_size_t(), C.c_size_t()
+        _check(self.lib, self.lib.sgv_bucket_dots(self.h, int(bucket), C.byref(off), C.byref(cnt)), "sgv_bucket_dots")
+        return off.value, cnt.value
+
+    def opt_stream(self) -> int:
+        """Raw HIP stream the ahead-of-step bucket updates run on (wrap with torch.cuda.ExternalStream)."""
+        p = C.c_void_p()
+        _check(self.lib, self.lib.sgv_opt_stream(self.h, C.byref(p)), "sgv_opt_stream")
+        return p.value
+
+    def adamw_bucket_async(self, lr: float, bucket: int):
+        """AdamW of one weight bucket's conv weights on the optimizer stream (include/sgvae.h: the caller has made that stream
+        wait for the bucket's and its <G,W> scalars' all-reduce); the closing adamw_step_range calls skip it."""
+        _check(self.lib, self.lib.sgv_adamw_bucket_async(self.h, float(lr), int(bucket)), "sgv_adamw_bucket_async")
 
     def last_grad_norm(self) -> float:
         d = C.c_double()

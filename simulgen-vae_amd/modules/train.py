@@ -84,6 +84,17 @@ class _Done:
         pass
 
 
+class _Both:
+    """Two collectives that belong together (a weight bucket and the <G,W> scalars of its layers)."""
+
+    def __init__(self, *works):
+        self.works = [w for w in works if w is not None]
+
+    def wait(self):
+        for w in self.works:
+            w.wait()
+
+
 class GradAllReduce:
     """Bucketed mean all-reduce of the engine's flat gradient arena over RCCL, overlapped with backward (the
     engine calls `_on_bucket` as soon as the kernels producing a bucket are enqueued) and with AdamW (`step`
@@ -91,7 +102,9 @@ class GradAllReduce:
     Under a gloo group (tests, debugging) the mean is SUM followed by a scale, same bucket order."""
 
     def __init__(self, engine, group=None, payload=None, force_collective=None):
+        import weakref
         ptr, n = engine.grad_buffer()
+        self._engine = weakref.ref(engine)
         self.flat = torch.as_tensor(_DevArray(ptr, n), device="cuda")
         self.group = group
         self.native_avg = dist.get_backend(group) == "nccl"
@@ -109,6 +122,15 @@ class GradAllReduce:
             engine.set_grad_payload("bf16")
             lp_ptr, lp_n = engine.grad_payload_buffer()
             self.flat_lp = torch.as_tensor(_DevArray(lp_ptr, lp_n, "<i2"), device="cuda").view(torch.bfloat16)
+        # optimizer overlap (include/sgvae.h: sgv_bucket_dots / sgv_adamw_bucket_async; SGV_DDP_EARLY=0 turns it off): inside
+        # backward_step every weight bucket travels with the <G,W> scalars of its layers and is updated on the engine's optimizer
+        # stream as soon as both collectives have landed, under the rest of backward
+        self.early = not self.single and os.environ.get("SGV_DDP_EARLY", "1") != "0"
+        self.lr = None
+        if self.early:
+            self.opt = torch.cuda.ExternalStream(engine.opt_stream())
+            self.dots = [engine.bucket_dots(b) for b in range(self.nb - 1)]
+            self.dots_total = sum(c for _, c in self.dots)
         if not self.single:
             engine.set_bucket_callback(self._on_bucket)        # one rank: nothing to exchange, the engine keeps its single-GPU schedule
 
@@ -118,18 +140,37 @@ class GradAllReduce:
         if self.single:
             engine.backward_step(alpha, beta, lr)
         else:
-            engine.backward(alpha, beta)
+            self.lr = lr if self.early else None      # the callbacks update finished buckets ahead of step()
+            try:
+                engine.backward(alpha, beta)
+            finally:
+                self.lr = None
             self.step(engine, lr)
 
+    def _mean(self, seg):
+        if self.native_avg:
+            return dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
+        return _SumThenScale(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg, self.inv_world)
+
     def _on_bucket(self, b, off, cnt):
-        seg = self.flat[off:off + cnt] if self.flat_lp is None or b == self.nb - 1 else self.flat_lp[off:off + cnt]
         if self.single:
             self.pending.append((b, _Done()))
             return
-        if self.native_avg:
-            w = dist.all_reduce(seg, op=dist.ReduceOp.AVG, group=self.group, async_op=True)
-        else:
-            w = _SumThenScale(dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True), seg, self.inv_world)
+        small = b == self.nb - 1
+        ahead = self.lr is not None
+        if small and ahead:                                   # the conv layers' <G,W> scalars went with their buckets
+            off, cnt = off + self.dots_total, cnt - self.dots_total
+        seg = self.flat[off:off + cnt] if self.flat_lp is None or small else self.flat_lp[off:off + cnt]
+        w = self._mean(seg)
+        if ahead and not small:
+            doff, dcnt = self.dots[b]
+            w = _Both(w, self._mean(self.flat[doff:doff + dcnt]) if dcnt else None)
+            if b < self.nb - 2:                               # the first-encoder-layer bucket (fired last) is step()'s
+                with torch.cuda.stream(self.opt):
+                    w.wait()                                  # stream-side: the optimizer stream waits, backward goes on
+                    engine = self._engine()
+                    engine.adamw_bucket_async(self.lr, b)
+                w = _Done()
         self.pending.append((b, w))
 
     def __call__(self, engine):
@@ -191,11 +232,10 @@ class NativeAllReduce:
             engine.set_rccl(self.comm, self.stream.cuda_stream)      # one rank: nothing to exchange, single-GPU schedule
 
     def backward_step(self, engine, alpha, beta, lr):
-        if self.single:
-            engine.backward_step(alpha, beta, lr)
-        else:
-            engine.backward(alpha, beta)
-            self.step(engine, lr)
+        # one rank: the single-GPU schedule.  Several: sgv_backward_step on a registered communicator -- the engine averages every
+        # weight bucket together with the <G,W> scalars of its layers, updates it on its optimizer stream as soon as both have
+        # landed (option "ddp_early_adamw") and closes the step with sgv_adamw_step
+        engine.backward_step(alpha, beta, lr)
 
     def step(self, engine, lr):
         engine.adamw_step(lr)           # waits for the buckets in the overlapped order (sgv_adamw_step with a communicator)
