@@ -191,6 +191,11 @@ int sgv_bucket_count(const sgv_engine* e);
  * With sgv_set_rccl, sgv_backward_step does all of this by itself (option "ddp_early_adamw", default 1).  Linear-head weights,
  * biases and GroupNorm affine are updated by the closing calls: their <G,W> scalars are computed at the end of backward. */
 int sgv_bucket_dots(const sgv_engine* e, int bucket, size_t* offset_elems, size_t* count_elems);
+/* Where a released bucket is complete.  By default on the engine stream: before the callback the engine stream joins the
+ * weight-gradient side stream and, for the bf16 wire format, runs the pack pass.  With sgv_set_option("wire_stream", 1) both
+ * happen on the wire stream instead (sgv_wire_stream): the callback must issue its collective ordered after THAT stream, and
+ * backward never waits for the side stream or the pack pass at a release point. */
+int sgv_wire_stream(sgv_engine* e, void** hip_stream);
 int sgv_opt_stream(sgv_engine* e, void** hip_stream);
 int sgv_adamw_bucket_async(sgv_engine* e, float lr, int bucket);
 /* Wire format of the data-parallel gradient exchange (the reference's DDP all-reduces fp32 gradients, modules/utils.py:209-238

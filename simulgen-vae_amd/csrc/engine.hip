@@ -152,6 +152,7 @@ struct sgv_engine {
     // (sgv_adamw_bucket_async; the engine's own RCCL path does it by itself in sgv_backward_step).  bucket_updated[b]: done this step.
     std::vector<std::pair<size_t, size_t>> bucket_dots; size_t dots_total = 0;
     hipStream_t opt = nullptr; bool opt_dirty = false, adam_open = false;
+    hipStream_t wire = nullptr; int use_wire = 0;     // callback path: buckets are complete (and packed) on this stream, not on the engine stream
     std::vector<char> bucket_updated;
     int ddp_early = getenv("SGV_DDP_EARLY") ? atoi(getenv("SGV_DDP_EARLY")) : 1;
     // bf16 wire format: the conv-weight AdamW reads a packed bucket straight from the averaged bf16 copy (no unpack pass; the fp32
@@ -1196,6 +1197,28 @@ extern "C" {
 
 const char* sgv_last_error(void) { return g_err; }
 
+// Auxiliary streams.  The HIP runtime maps streams onto a handful of hardware queues PER PRIORITY LEVEL (GPU_MAX_HW_QUEUES = 4),
+// round-robin in creation order, and two streams on one queue run their kernels strictly one after the other: a kernel trace showed
+// the second compute lane and the collective's stream sharing the main stream's queue (no overlap at all) depending on how many
+// streams the process had created before.  A stream of another priority level comes from another queue pool, so it can never land
+// on the main stream's queue: level -1 = high, 0 = normal (the main stream's), 1 = low; SGV_PRIO_* override the defaults.
+constexpr int SGV_PRIO_LANE_DEFAULT = 0, SGV_PRIO_SIDE_DEFAULT = 0, SGV_PRIO_OPT_DEFAULT = 0;
+static hipError_t make_stream(hipStream_t* s, const char* env, int level);
+static hipStream_t ensure_opt(sgv_engine* e) {
+    if (!e->opt && make_stream(&e->opt, "SGV_PRIO_OPT", SGV_PRIO_OPT_DEFAULT) != hipSuccess) e->opt = nullptr;
+    return e->opt;
+}
+static hipStream_t ensure_wire(sgv_engine* e) {
+    if (!e->wire && make_stream(&e->wire, "SGV_PRIO_WIRE", SGV_PRIO_OPT_DEFAULT) != hipSuccess) e->wire = nullptr;
+    return e->wire;
+}
+static hipError_t make_stream(hipStream_t* s, const char* env, int level) {
+    if (getenv(env)) level = atoi(getenv(env));
+    if (level == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    if (hipDeviceGetStreamPriorityRange(&least, &greatest) != hipSuccess || least == greatest) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, level < 0 ? greatest : least);
+}
 int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     if (!cfg || !out) return fail(SGV_ERR_ARG, "null argument");
     int ndev = 0;
@@ -1266,7 +1289,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     e->gn_part_floats = 0;
     for (auto& l : e->layers) if (l.used && l.op != OP_LINEAR) e->gn_part_floats = std::max(e->gn_part_floats, gemm_nt256_part_floats((int)M, l.cout, 1));
     ALLOC(e->gn_part, e->gn_part_floats * 4);
-    if (e->use_lanes && hipStreamCreateWithFlags(&e->lane2, hipStreamNonBlocking) == hipSuccess &&
+    if (e->use_lanes && make_stream(&e->lane2, "SGV_PRIO_LANE", SGV_PRIO_LANE_DEFAULT) == hipSuccess &&
         hipEventCreateWithFlags(&e->lane_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->lane_join, hipEventDisableTiming) == hipSuccess) {
         ALLOC(e->partial2, e->partial_floats * 4);
         ALLOC(e->gn_part2, e->gn_part_floats * 4);
@@ -1281,8 +1304,9 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
         e->red_floats = nr;
     }
     ALLOC(e->red, e->red_floats * 4);
-    if (hipStreamCreateWithFlags(&e->side, hipStreamNonBlocking) != hipSuccess) { e->side = nullptr; e->use_side = false; }
-    if (hipStreamCreateWithFlags(&e->opt, hipStreamNonBlocking) != hipSuccess) e->opt = nullptr;
+    if (make_stream(&e->side, "SGV_PRIO_SIDE", SGV_PRIO_SIDE_DEFAULT) != hipSuccess) { e->side = nullptr; e->use_side = false; }
+    // the optimizer and wire streams of the data-parallel step are created on first use (ensure_opt / ensure_wire): every stream a
+    // process creates shifts the runtime's stream -> hardware-queue assignment of the ones created after it
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
     ALLOC(e->xpose_tmp, e->xpose_floats * 4);
     ALLOC(e->colpart, e->colpart_floats * 4);
@@ -1304,6 +1328,7 @@ int sgv_destroy(sgv_engine* e) {
     for (void* p : ptrs) if (p) hipFree(p);
     if (e->side) { hipStreamSynchronize(e->side); gemm_nt_vendor_release_stream(e->side); hipStreamDestroy(e->side); }
     if (e->opt) { hipStreamSynchronize(e->opt); hipStreamDestroy(e->opt); }
+    if (e->wire) { hipStreamSynchronize(e->wire); hipStreamDestroy(e->wire); }
     if (e->lane2) { hipStreamSynchronize(e->lane2); gemm_nt_vendor_release_stream(e->lane2); hipStreamDestroy(e->lane2); }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
     if (e->lane_join) hipEventDestroy(e->lane_join);
@@ -1524,6 +1549,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     else if (!strcmp(key, "use_tr")) e->use_tr = value != 0;
     else if (!strcmp(key, "dw_side_stream")) e->use_side = value != 0 && e->side != nullptr;
     else if (!strcmp(key, "ddp_early_adamw")) e->ddp_early = value != 0;
+    else if (!strcmp(key, "wire_stream")) e->use_wire = value != 0 && ensure_wire(e) != nullptr;
     else if (!strcmp(key, "vendor_gemm")) e->vendor_gemm = value != 0;
     else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
     else if (!strcmp(key, "lanes")) e->use_lanes = value != 0 && e->lane2 != nullptr;          // second compute lane (schedule only: results are bitwise the same)
@@ -1888,7 +1914,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     // engine-issued collectives with the learning rate in hand (sgv_backward_step on a registered communicator): every weight
     // bucket's <G,W> slots are averaged with the bucket and its conv-weight AdamW starts on the optimizer stream as soon as both
     // have landed, under the rest of backward -- the data-parallel mirror of `early`
-    const bool dearly = e->ddp_early && fuse && e->comm && !comm_is_single(e->comm) && e->opt && !e->timing;
+    const bool dearly = e->ddp_early && fuse && e->comm && !comm_is_single(e->comm) && !e->timing && ensure_opt(e);
     if (early || dearly) CHK(adamw_begin(e));
     const int B = e->batch, n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
@@ -1896,15 +1922,32 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     int bucket = 0;
     e->ev_next = 0;
     int early_err = 0;
+    // the inputs of a bucket's collective are what the main stream and the side stream hold so far.  They are gathered on the
+    // stream the collective is issued from (the communicator's stream; with a callback the wire stream, option "wire_stream"), and
+    // the bf16 wire copy is packed THERE: the main stream neither waits for the side stream's weight-gradient GEMMs nor runs the
+    // pack pass (0.45 ms per step at preset 1).  Without a wire stream (a caller that orders itself after the engine stream) the
+    // main stream joins the side stream and packs, as before.
+    auto gather_on = [&](hipStream_t t) -> int {
+        hipEvent_t ev = next_event(e);
+        if (!ev || hipEventRecord(ev, e->stream) != hipSuccess || hipStreamWaitEvent(t, ev, 0) != hipSuccess) return 1;
+        if (e->side_dirty) {
+            hipEvent_t ev2 = next_event(e);
+            if (!ev2 || hipEventRecord(ev2, e->side) != hipSuccess || hipStreamWaitEvent(t, ev2, 0) != hipSuccess) return 1;
+        }
+        return 0;
+    };
     auto fire_at = [&](int b) {
         if (b < 0 || b >= (int)e->buckets.size()) return;
-        if (e->payload_bf16 && (e->comm || e->cb) && b != (int)e->buckets.size() - 1 && !(e->comm && comm_is_single(e->comm))) {
-            if (join_side(e)) { early_err = 1; return; }
-            ew_pack_bf16(e->grads + e->buckets[b].first, (char*)e->grads_lp + 2 * e->buckets[b].first, (long)e->buckets[b].second, e->stream);
-            e->bucket_packed[b] = 3;
+        if (e->comm || e->cb) {
+            const hipStream_t ws = e->comm ? e->comm_stream : (e->use_wire ? e->wire : nullptr);
+            if (ws ? gather_on(ws) : join_side(e)) { early_err = 1; return; }
+            if (e->payload_bf16 && b != (int)e->buckets.size() - 1 && !(e->comm && comm_is_single(e->comm))) {
+                ew_pack_bf16(e->grads + e->buckets[b].first, (char*)e->grads_lp + 2 * e->buckets[b].first, (long)e->buckets[b].second, ws ? ws : e->stream);
+                e->bucket_packed[b] = 3;
+            }
         }
         if (e->comm) {
-            if (join_side(e) || rccl_bucket(e, e->comm, e->comm_stream, b, e->bucket_done[b], dearly)) { early_err = 1; return; }
+            if (rccl_bucket(e, e->comm, e->comm_stream, b, e->bucket_done[b], dearly)) { early_err = 1; return; }
             e->bucket_pending[b] = 1;
             if (dearly && b < (int)e->buckets.size() - 2) {
                 if (hipStreamWaitEvent(e->opt, e->bucket_done[b], 0) != hipSuccess) { early_err = 1; return; }
@@ -1912,7 +1955,6 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
                 if (adamw_bucket_async(e, fuse_lr, b, e->opt)) early_err = 1;
             }
         } else if (e->cb) {
-            join_side(e);     // the bucket's weight gradients come from the side stream
             e->cb(e->cb_user, b, e->buckets[b].first, e->buckets[b].second);
         } else if (early && b < (int)e->buckets.size() - 2) {
             // the bucket's weight gradients (and the <G,W> slots of its conv layers) are final once everything enqueued
@@ -2169,16 +2211,22 @@ int sgv_bucket_dots(const sgv_engine* e, int bucket, size_t* offset_elems, size_
     *offset_elems = e->bucket_dots[bucket].first; *count_elems = e->bucket_dots[bucket].second;
     return SGV_OK;
 }
+int sgv_wire_stream(sgv_engine* e, void** stream) {
+    if (!e || !stream) return fail(SGV_ERR_ARG, "null argument");
+    if (!ensure_wire(e)) return fail(SGV_ERR_HIP, "the engine has no wire stream");
+    *stream = (void*)e->wire;
+    return SGV_OK;
+}
 int sgv_opt_stream(sgv_engine* e, void** stream) {
     if (!e || !stream) return fail(SGV_ERR_ARG, "null argument");
-    if (!e->opt) return fail(SGV_ERR_HIP, "the engine has no optimizer stream");
+    if (!ensure_opt(e)) return fail(SGV_ERR_HIP, "the engine has no optimizer stream");
     *stream = (void*)e->opt;
     return SGV_OK;
 }
 int sgv_adamw_bucket_async(sgv_engine* e, float lr, int bucket) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
     if (lr < 0.f) return fail(SGV_ERR_ARG, "negative learning rate");
-    if (!e->opt) return fail(SGV_ERR_HIP, "the engine has no optimizer stream");
+    if (!ensure_opt(e)) return fail(SGV_ERR_HIP, "the engine has no optimizer stream");
     if (bucket < 0 || bucket >= (int)e->buckets.size() - 1) return fail(SGV_ERR_ARG, "bucket %d is not a weight bucket [0,%d)", bucket, (int)e->buckets.size() - 1);
     if (e->adam_open && e->bucket_updated[bucket]) return fail(SGV_ERR_STATE, "bucket %d was already updated in this step", bucket);
     return adamw_bucket_async(e, lr, bucket, e->opt);

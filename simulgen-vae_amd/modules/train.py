@@ -131,6 +131,14 @@ class GradAllReduce:
             self.opt = torch.cuda.ExternalStream(engine.opt_stream())
             self.dots = [engine.bucket_dots(b) for b in range(self.nb - 1)]
             self.dots_total = sum(c for _, c in self.dots)
+        # SGV_DDP_WIRE=1: released buckets are gathered (main + weight-gradient side stream) and packed on the engine's wire stream
+        # and the collectives are issued from there, so backward itself never waits at a release point.  Off by default: in the
+        # one-GPU rehearsal it bought nothing (the pack pass is HBM-bound wherever it runs) and one more stream shifts the
+        # runtime's stream -> hardware-queue map
+        self.wire = None
+        if not self.single and os.environ.get("SGV_DDP_WIRE", "0") == "1":
+            engine.set_option("wire_stream", 1)
+            self.wire = torch.cuda.ExternalStream(engine.wire_stream())
         if not self.single:
             engine.set_bucket_callback(self._on_bucket)        # one rank: nothing to exchange, the engine keeps its single-GPU schedule
 
@@ -161,10 +169,12 @@ class GradAllReduce:
         if small and ahead:                                   # the conv layers' <G,W> scalars went with their buckets
             off, cnt = off + self.dots_total, cnt - self.dots_total
         seg = self.flat[off:off + cnt] if self.flat_lp is None or small else self.flat_lp[off:off + cnt]
-        w = self._mean(seg)
+        with torch.cuda.stream(self.wire if self.wire is not None else torch.cuda.current_stream()):
+            w = self._mean(seg)
+            if ahead and not small:
+                doff, dcnt = self.dots[b]
+                w = _Both(w, self._mean(self.flat[doff:doff + dcnt]) if dcnt else None)
         if ahead and not small:
-            doff, dcnt = self.dots[b]
-            w = _Both(w, self._mean(self.flat[doff:doff + dcnt]) if dcnt else None)
             if b < self.nb - 2:                               # the first-encoder-layer bucket (fired last) is step()'s
                 with torch.cuda.stream(self.opt):
                     w.wait()                                  # stream-side: the optimizer stream waits, backward goes on
