@@ -166,6 +166,10 @@ int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank)
 int sgv_rccl_comm_destroy(void* comm);
 int sgv_allreduce_grads(sgv_engine* e, void* rccl_comm, void* comm_stream);
 int sgv_set_rccl(sgv_engine* e, void* rccl_comm, void* comm_stream);
+/* A communication stream owned by the engine for sgv_set_rccl, chosen so that it shares its hardware queue with neither the engine
+ * stream nor the engine's weight-gradient / second-lane streams (the HIP runtime maps streams onto four hardware queues; kernels of
+ * two streams on one queue never overlap, and a collective on the engine stream's queue would serialise with backward). */
+int sgv_comm_stream(sgv_engine* e, void** hip_stream);
 
 /* Gradient 2-norm as train.py:156-161 computes it.  [sync] */
 int sgv_grad_norm(sgv_engine* e, double* out);

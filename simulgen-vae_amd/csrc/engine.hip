@@ -152,6 +152,7 @@ struct sgv_engine {
     // (sgv_adamw_bucket_async; the engine's own RCCL path does it by itself in sgv_backward_step).  bucket_updated[b]: done this step.
     std::vector<std::pair<size_t, size_t>> bucket_dots; size_t dots_total = 0;
     hipStream_t opt = nullptr; bool opt_dirty = false, adam_open = false;
+    hipStream_t comm_own = nullptr;                   // sgv_comm_stream: a probed communication stream the engine owns
     hipStream_t wire = nullptr; int use_wire = 0;     // callback path: buckets are complete (and packed) on this stream, not on the engine stream
     std::vector<char> bucket_updated;
     int ddp_early = getenv("SGV_DDP_EARLY") ? atoi(getenv("SGV_DDP_EARLY")) : 1;
@@ -1204,12 +1205,64 @@ const char* sgv_last_error(void) { return g_err; }
 // on the main stream's queue: level -1 = high, 0 = normal (the main stream's), 1 = low; SGV_PRIO_* override the defaults.
 constexpr int SGV_PRIO_LANE_DEFAULT = 0, SGV_PRIO_SIDE_DEFAULT = 0, SGV_PRIO_OPT_DEFAULT = 0;
 static hipError_t make_stream(hipStream_t* s, const char* env, int level);
+// ---- which hardware queue did a new stream land on? ----
+// Not visible through the API, but observable: a kernel on stream b cannot finish while a kernel on stream a spins if both sit
+// on one queue.  probe_spin_kernel waits on the constant-rate clock for a bounded time (always exits), probe_nop_kernel is empty.
+__global__ void probe_spin_kernel(long long ticks) {
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+__global__ void probe_nop_kernel() {}
+// true: kernels of a and b run concurrently (different hardware queues); on any API error: true (no reason to reject the stream)
+static bool streams_overlap(hipStream_t a, hipStream_t b) {
+    hipEvent_t ev = nullptr;
+    if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return true;
+    bool overlap = true;
+    hipLaunchKernelGGL(probe_spin_kernel, dim3(1), dim3(64), 0, a, 30000LL);      // 300 us at the 100 MHz constant clock
+    if (hipEventRecord(ev, a) == hipSuccess) {
+        hipLaunchKernelGGL(probe_nop_kernel, dim3(1), dim3(64), 0, b);
+        if (hipStreamSynchronize(b) == hipSuccess) overlap = hipEventQuery(ev) == hipErrorNotReady;
+    }
+    hipStreamSynchronize(a);
+    hipEventDestroy(ev);
+    (void)hipGetLastError();
+    return overlap;
+}
+// A new auxiliary stream that shares its hardware queue with none of `avoid` (up to 6 candidates: the runtime hands queues out
+// round-robin, so the next stream lands elsewhere; the rejected ones are destroyed afterwards so that the keeper holds its place).
+// SGV_STREAM_PROBE=0: take the first.  If every candidate collides the last one is kept.
+static hipError_t make_aux_stream(hipStream_t* out, const char* env, int level, std::initializer_list<hipStream_t> avoid) {
+    static const int probe = getenv("SGV_STREAM_PROBE") ? atoi(getenv("SGV_STREAM_PROBE")) : 1;
+    std::vector<hipStream_t> rejected;
+    hipStream_t s = nullptr;
+    hipError_t rc = hipSuccess;
+    for (int attempt = 0; attempt < 6; ++attempt) {
+        s = nullptr;
+        rc = make_stream(&s, env, level);
+        if (rc != hipSuccess || !probe) break;
+        bool ok = true;
+        for (hipStream_t a : avoid) if (a != s && !streams_overlap(a, s)) { ok = false; break; }      // a == nullptr is the null stream: probed too
+        if (getenv("SGV_STREAM_LOG")) fprintf(stderr, "[sgvae] %s: candidate %d %s\n", env, attempt, ok ? "kept" : "shares a hardware queue with a stream it must not, rejected");
+        if (ok || attempt == 5) break;
+        rejected.push_back(s);
+    }
+    for (hipStream_t r : rejected) hipStreamDestroy(r);
+    *out = rc == hipSuccess ? s : nullptr;
+    return rc;
+}
 static hipStream_t ensure_opt(sgv_engine* e) {
-    if (!e->opt && make_stream(&e->opt, "SGV_PRIO_OPT", SGV_PRIO_OPT_DEFAULT) != hipSuccess) e->opt = nullptr;
+    // never on the main stream's queue: an AdamW launch that waits for a collective there would hold back every kernel behind it
+    if (!e->opt && make_aux_stream(&e->opt, "SGV_PRIO_OPT", SGV_PRIO_OPT_DEFAULT, {e->stream, e->side, e->lane2}) != hipSuccess) e->opt = nullptr;
     return e->opt;
 }
+// a communication stream for sgv_set_rccl that is guaranteed not to sit on the main stream's hardware queue (a collective there
+// would run strictly between the main stream's kernels instead of beside them)
+static hipStream_t ensure_comm_own(sgv_engine* e) {
+    if (!e->comm_own && make_aux_stream(&e->comm_own, "SGV_PRIO_COMM", 0, {e->stream, e->side, e->lane2}) != hipSuccess) e->comm_own = nullptr;
+    return e->comm_own;
+}
 static hipStream_t ensure_wire(sgv_engine* e) {
-    if (!e->wire && make_stream(&e->wire, "SGV_PRIO_WIRE", SGV_PRIO_OPT_DEFAULT) != hipSuccess) e->wire = nullptr;
+    if (!e->wire && make_aux_stream(&e->wire, "SGV_PRIO_WIRE", SGV_PRIO_OPT_DEFAULT, {e->stream, e->side}) != hipSuccess) e->wire = nullptr;
     return e->wire;
 }
 static hipError_t make_stream(hipStream_t* s, const char* env, int level) {
@@ -1289,7 +1342,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     e->gn_part_floats = 0;
     for (auto& l : e->layers) if (l.used && l.op != OP_LINEAR) e->gn_part_floats = std::max(e->gn_part_floats, gemm_nt256_part_floats((int)M, l.cout, 1));
     ALLOC(e->gn_part, e->gn_part_floats * 4);
-    if (e->use_lanes && make_stream(&e->lane2, "SGV_PRIO_LANE", SGV_PRIO_LANE_DEFAULT) == hipSuccess &&
+    if (e->use_lanes && make_aux_stream(&e->lane2, "SGV_PRIO_LANE", SGV_PRIO_LANE_DEFAULT, {e->stream}) == hipSuccess &&
         hipEventCreateWithFlags(&e->lane_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->lane_join, hipEventDisableTiming) == hipSuccess) {
         ALLOC(e->partial2, e->partial_floats * 4);
         ALLOC(e->gn_part2, e->gn_part_floats * 4);
@@ -1304,7 +1357,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
         e->red_floats = nr;
     }
     ALLOC(e->red, e->red_floats * 4);
-    if (make_stream(&e->side, "SGV_PRIO_SIDE", SGV_PRIO_SIDE_DEFAULT) != hipSuccess) { e->side = nullptr; e->use_side = false; }
+    if (make_aux_stream(&e->side, "SGV_PRIO_SIDE", SGV_PRIO_SIDE_DEFAULT, {e->stream, e->lane2}) != hipSuccess) { e->side = nullptr; e->use_side = false; }
     // the optimizer and wire streams of the data-parallel step are created on first use (ensure_opt / ensure_wire): every stream a
     // process creates shifts the runtime's stream -> hardware-queue assignment of the ones created after it
     if (getenv("SGV_DW_SIDE")) e->use_side = atoi(getenv("SGV_DW_SIDE")) != 0 && e->side != nullptr;
@@ -1329,6 +1382,7 @@ int sgv_destroy(sgv_engine* e) {
     if (e->side) { hipStreamSynchronize(e->side); gemm_nt_vendor_release_stream(e->side); hipStreamDestroy(e->side); }
     if (e->opt) { hipStreamSynchronize(e->opt); hipStreamDestroy(e->opt); }
     if (e->wire) { hipStreamSynchronize(e->wire); hipStreamDestroy(e->wire); }
+    if (e->comm_own) { hipStreamSynchronize(e->comm_own); hipStreamDestroy(e->comm_own); }
     if (e->lane2) { hipStreamSynchronize(e->lane2); gemm_nt_vendor_release_stream(e->lane2); hipStreamDestroy(e->lane2); }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
     if (e->lane_join) hipEventDestroy(e->lane_join);
@@ -2209,6 +2263,12 @@ int sgv_bucket_dots(const sgv_engine* e, int bucket, size_t* offset_elems, size_
     if (!e || !offset_elems || !count_elems) return fail(SGV_ERR_ARG, "null argument");
     if (bucket < 0 || bucket >= (int)e->bucket_dots.size()) return fail(SGV_ERR_ARG, "bucket %d is not a weight bucket [0,%d)", bucket, (int)e->bucket_dots.size());
     *offset_elems = e->bucket_dots[bucket].first; *count_elems = e->bucket_dots[bucket].second;
+    return SGV_OK;
+}
+int sgv_comm_stream(sgv_engine* e, void** stream) {
+    if (!e || !stream) return fail(SGV_ERR_ARG, "null argument");
+    if (!ensure_comm_own(e)) return fail(SGV_ERR_HIP, "stream creation failed");
+    *stream = (void*)e->comm_own;
     return SGV_OK;
 }
 int sgv_wire_stream(sgv_engine* e, void** stream) {

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
     "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_wire_stream", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
-    "sgv_rccl_unique_id", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl",
+    "sgv_rccl_unique_id", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_lib", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn",
 ]
 
@@ -91,6 +91,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_bucket_dots.argtypes = [vp, i32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     lib.sgv_opt_stream.argtypes = [vp, C.POINTER(vp)]
     lib.sgv_wire_stream.argtypes = [vp, C.POINTER(vp)]
+    lib.sgv_comm_stream.argtypes = [vp, C.POINTER(vp)]
     lib.sgv_adamw_bucket_async.argtypes = [vp, f32, i32]
     lib.sgv_set_grad_payload.argtypes = [vp, C.c_int]
     lib.sgv_grad_payload_buffer.argtypes = [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]
@@ -313,6 +314,12 @@ class Engine:
         off, cnt = C.c_size_t(), C.c_size_t()
         _check(self.lib, self.lib.sgv_bucket_dots(self.h, int(bucket), C.byref(off), C.byref(cnt)), "sgv_bucket_dots")
         return off.value, cnt.value
+
+    def comm_stream(self) -> int:
+        """Raw HIP stream for set_rccl that the engine placed on a hardware queue of its own (include/sgvae.h: sgv_comm_stream)."""
+        p = C.c_void_p()
+        _check(self.lib, self.lib.sgv_comm_stream(self.h, C.byref(p)), "sgv_comm_stream")
+        return p.value
 
     def wire_stream(self) -> int:
         """Raw HIP stream released buckets are complete (and packed) on once option "wire_stream" is set."""

@@ -128,7 +128,12 @@ class GradAllReduce:
         self.early = not self.single and os.environ.get("SGV_DDP_EARLY", "1") != "0"
         self.lr = None
         if self.early:
-            self.opt = torch.cuda.ExternalStream(engine.opt_stream())
+            # the optimizer stream is asked for AFTER the first collective has been issued (_on_bucket): the HIP runtime hands its
+            # four hardware queues out round-robin in stream-creation order, the engine's main / lane / side streams hold three
+            # of them, and torch creates its NCCL stream at the first collective -- which so gets the free queue, and the
+            # optimizer stream (probed by the engine against main, lane and side) the one the NCCL stream sits on: AdamW(b)
+            # follows all-reduce(b) anyway.  The other order put the NCCL stream on the MAIN stream's queue.
+            self.opt = None
             self.dots = [engine.bucket_dots(b) for b in range(self.nb - 1)]
             self.dots_total = sum(c for _, c in self.dots)
         # SGV_DDP_WIRE=1: released buckets are gathered (main + weight-gradient side stream) and packed on the engine's wire stream
@@ -176,9 +181,11 @@ class GradAllReduce:
                 w = _Both(w, self._mean(self.flat[doff:doff + dcnt]) if dcnt else None)
         if ahead and not small:
             if b < self.nb - 2:                               # the first-encoder-layer bucket (fired last) is step()'s
+                engine = self._engine()
+                if self.opt is None:
+                    self.opt = torch.cuda.ExternalStream(engine.opt_stream())
                 with torch.cuda.stream(self.opt):
                     w.wait()                                  # stream-side: the optimizer stream waits, backward goes on
-                    engine = self._engine()
                     engine.adamw_bucket_async(self.lr, b)
                 w = _Done()
         self.pending.append((b, w))
@@ -237,7 +244,8 @@ class NativeAllReduce:
         self.single = world == 1 and not forced
         if not self.single and grad_payload_dtype(engine) == "bf16":
             engine.set_grad_payload("bf16")      # the engine packs, all-reduces the bf16 copy and unpacks by itself
-        self.stream = torch.cuda.Stream()
+        # the engine's own communication stream: probed so that it never shares a hardware queue with the main stream
+        self.stream = torch.cuda.ExternalStream(engine.comm_stream())
         if not self.single:
             engine.set_rccl(self.comm, self.stream.cuda_stream)      # one rank: nothing to exchange, single-GPU schedule
 
@@ -283,8 +291,29 @@ def broadcast_replica_state(engine, group=None, src=0):
 
 
 def make_allreduce(engine, group=None):
-    """GradAllReduce (torch.distributed issues the bucket collectives) or, with SGV_DDP_NATIVE=1, NativeAllReduce."""
-    return NativeAllReduce(engine, group) if os.environ.get("SGV_DDP_NATIVE") == "1" else GradAllReduce(engine, group)
+    """The data-parallel step's gradient exchange.  On an RCCL (`nccl`) group the engine issues the collectives itself
+    (NativeAllReduce: its own communicator on a communication stream it placed on a hardware queue away from the main stream's,
+    every bucket updated on that queue right behind its all-reduce); if ANY rank fails to set that up, every rank falls back
+    to GradAllReduce (torch.distributed issues the bucket collectives from the engine's callbacks), which is also what other
+    backends get.  SGV_DDP_NATIVE=1 / 0 forces one or the other."""
+    want = os.environ.get("SGV_DDP_NATIVE", "")
+    if want == "0" or (want != "1" and dist.get_backend(group) != "nccl"):
+        return GradAllReduce(engine, group)
+    if want == "1":
+        return NativeAllReduce(engine, group)
+    ar, err = None, None
+    try:
+        ar = NativeAllReduce(engine, group)
+    except Exception as ex:       # noqa: BLE001 -- whatever went wrong, all ranks must agree on the path they take
+        err = ex
+    ok = torch.tensor([0 if ar is None else 1], dtype=torch.int32, device="cuda")
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
+    if int(ok.item()) == 1:
+        return ar
+    if ar is not None:
+        ar.close()
+    logging.warning("engine-issued RCCL path unavailable on some rank (%s): torch.distributed issues the bucket collectives", err)
+    return GradAllReduce(engine, group)
 
 
 def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_enc, num_filter_dec, num_node, latent_dim,
