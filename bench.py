@@ -428,6 +428,12 @@ def main():
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)
+    if allreduce is not None and hasattr(allreduce, "close"):
+        torch.cuda.synchronize()
+        try:
+            allreduce.close()             # the engine's own RCCL communicator (rank 0 with --cpu-baseline has closed its engine already)
+        except Exception:                 # noqa: BLE001
+            pass
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()

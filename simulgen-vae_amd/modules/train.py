@@ -263,7 +263,7 @@ class NativeAllReduce:
 
     def close(self):
         if self.comm:
-            if not self.single:
+            if not self.single and getattr(self.engine, "h", None):      # an engine closed before us holds nothing of ours any more
                 self.engine.set_rccl(None, None)
             self.engine.lib.sgv_rccl_comm_destroy(self.comm)
             self.comm = None
@@ -409,6 +409,9 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
                              epoch + 1, epochs, loss_print[epoch], loss_val_print[epoch], recon_print[epoch],
                              recon_loss_val_print[epoch], kl_print[epoch], beta, grad_sum / nb, dur,
                              (epochs - epoch) * dur / 3600, lr))
+    if allreduce is not None and hasattr(allreduce, "close"):
+        torch.cuda.synchronize()
+        allreduce.close()                 # the engine's own communicator (NativeAllReduce): unregister and destroy it
     if rank == 0:
         torch.save(model.state_dict(), "checkpoints/SimulGen-VAE.pth")
         torch.save(model, "model_save/SimulGen-VAE")
