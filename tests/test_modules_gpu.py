@@ -502,6 +502,49 @@ def test_one_rank_forced_collectives_through_rccl(monkeypatch, path, payload):
             dist.destroy_process_group()
 
 
+def test_make_allreduce_picks_the_engine_issued_path_and_falls_back_together(monkeypatch):
+    """modules.train.make_allreduce on an RCCL group: the engine-issued path (own communicator on the engine's probed
+    communication stream) by default; if setting it up fails on a rank, the ranks agree (MIN all-reduce of a flag) to take the
+    callback path; SGV_DDP_NATIVE=0 / 1 force either.  One-rank group: what can be checked on one card is the choice itself, that
+    the chosen object runs a step, and that the communication stream is the engine's (sgv_comm_stream)."""
+    import torch.distributed as dist
+    import modules.train as T
+    from simulgen_vae_amd.engine import Engine
+    from simulgen_vae_amd.init import init_state
+    from tests.gpu_common import G1
+    monkeypatch.delenv("SGV_DDP_NATIVE", raising=False)
+    cfg = make_cfg(G1)
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29527", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        eng = Engine(cfg, max_batch=2, compute_dtype="f32")
+        eng.load_state(init_state(cfg, 11, reference_init=True))
+        x = torch.from_numpy(synthetic_samples(5, range(2), cfg.num_node, cfg.num_time)).cuda()
+        ar = T.make_allreduce(eng)
+        assert isinstance(ar, T.NativeAllReduce) and ar.stream.cuda_stream == eng.comm_stream()
+        eng.set_input(x); eng.forward(train=True); ar.backward_step(eng, 1e6, 1e-4, 1e-3)
+        assert np.isfinite(eng.last_grad_norm())
+        ar.close()
+        monkeypatch.setenv("SGV_DDP_NATIVE", "0")
+        assert isinstance(T.make_allreduce(eng), T.GradAllReduce)
+        monkeypatch.delenv("SGV_DDP_NATIVE")
+
+        class Broken:
+            def __init__(self, *a, **k):
+                raise RuntimeError("no RCCL here")
+        monkeypatch.setattr(T, "NativeAllReduce", Broken)
+        ar = T.make_allreduce(eng)
+        assert isinstance(ar, T.GradAllReduce)
+        eng.set_input(x); eng.forward(train=True); ar.backward_step(eng, 1e6, 1e-4, 1e-3)
+        assert np.isfinite(eng.last_grad_norm())
+        eng.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_fused_backward_step_equals_separate_calls():
     """sgv_backward_step (AdamW of finished buckets started on the side stream under the rest of backward) leaves the
     state of sgv_backward + sgv_adamw_step; gradients stay exportable afterwards.  fp32 compute, compared in the mean
