@@ -156,6 +156,13 @@ struct sgv_engine {
     hipStream_t wire = nullptr; int use_wire = 0;     // callback path: buckets are complete (and packed) on this stream, not on the engine stream
     std::vector<char> bucket_updated;
     int ddp_early = getenv("SGV_DDP_EARLY") ? atoi(getenv("SGV_DDP_EARLY")) : 1;
+    // the last weight bucket (the first encoder layer: 97 M gradients that exist only when backward ends) is produced, exchanged and
+    // updated in row chunks of the weight-gradient GEMM: chunk c's pack / all-reduce / AdamW run under chunk c + 1's GEMM, so only
+    // the last chunk's exchange is exposed (engine-issued path; SGV_DDP_LAST_CHUNKS=1 turns it off).  Two chunks: 512 rows keep the
+    // GEMM's 128 x 256 tiles at whole rounds of the chip, four chunks of 256 rows cost 27 % of the GEMM
+    int ddp_last_chunks = getenv("SGV_DDP_LAST_CHUNKS") ? atoi(getenv("SGV_DDP_LAST_CHUNKS")) : 2;
+    int dw_chunks = 1, dw_chunk_layer = -1;
+    std::function<int(int, int, int, int)> dw_chunk_hook;        // (chunk, chunks, first row, end row) after the chunk's GEMM is enqueued
     // bf16 wire format: the conv-weight AdamW reads a packed bucket straight from the averaged bf16 copy (no unpack pass; the fp32
     // arena keeps this rank's own gradients); only the few weights of a bucket that the flat pass updates (Linear heads:
     // bucket_flat_w) are unpacked.  bucket_packed[b]: bit 0 = conv-weight part still packed, bit 1 = flat part still packed.
@@ -978,6 +985,18 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
         HIPCHK(hipStreamWaitEvent(e->side, ev, 0));
         st = e->side; slabs = e->partial_tn; e->side_dirty = true;
     } else if ((size_t)sk * nw > e->partial_floats) sk = 1;
+    if (e->dw_chunks > 1 && (int)(&l - e->layers.data()) == e->dw_chunk_layer && sk == 1 && !side && l.k == 1 && l.cout % (128 * e->dw_chunks) == 0) {
+        const int rows = l.cout / e->dw_chunks;
+        for (int c = 0; c < e->dw_chunks; ++c) {
+            GemmTN q = p;
+            q.splitk = 1; q.N1 = rows;
+            q.A = (const char*)dy.p + (size_t)c * rows * e->esz;
+            q.out = G + (size_t)c * rows * l.cin;
+            if (launch_gemm_tn(e->dt, q, st)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s (rows %d..%d)", l.prefix.c_str(), c * rows, (c + 1) * rows);
+            if (e->dw_chunk_hook && e->dw_chunk_hook(c, e->dw_chunks, c * rows, (c + 1) * rows)) return fail(SGV_ERR_HIP, "weight-gradient chunk exchange failed for %s", l.prefix.c_str());
+        }
+        return 0;
+    }
     ScopedTimer tm(e, "gemm_tn", &l, p.M, p.N1, p.N2, p.taps, sk);
     if (sk == 1) {
         p.splitk = 1; p.out = G;
@@ -1956,6 +1975,7 @@ static int adamw_begin(sgv_engine* e);
 static int adamw_finish(sgv_engine* e);
 static int adamw_range(sgv_engine* e, float lr, int bucket_lo, int bucket_hi, int which, hipStream_t st);
 static int adamw_bucket_async(sgv_engine* e, float lr, int b, hipStream_t st);
+static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, bool from_lp);
 int sgv_adamw_step(sgv_engine* e, float lr);
 // fuse_lr >= 0: also run the optimizer, and start the AdamW of every conv-weight bucket on the side stream as soon as
 // that bucket's gradients are final, under the rest of backward (single-GPU path: no bucket callback registered)
@@ -1970,6 +1990,18 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     // have landed, under the rest of backward -- the data-parallel mirror of `early`
     const bool dearly = e->ddp_early && fuse && e->comm && !comm_is_single(e->comm) && !e->timing && ensure_opt(e);
     if (early || dearly) CHK(adamw_begin(e));
+    // chunked exchange of the last weight bucket: it must be exactly the first encoder layer's tiled weight
+    const int last_b = (int)e->buckets.size() - 2;
+    const int L0i = e->encA[0].st[0].layer;
+    bool last_chunked = false;
+    if (dearly && e->ddp_last_chunks > 1 && last_b >= 0) {
+        const Layer& L0 = e->layers[L0i];
+        const int rt6 = (L0.cout + 63) / 64, ct6 = (L0.cin + 63) / 64;
+        last_chunked = e->encA[0].st.size() == 1 && L0.k == 1 && L0.has_grad && layer_fused_adam(L0) && L0.cout % (128 * e->ddp_last_chunks) == 0 &&
+                       e->buckets[last_b].first == L0.gw && e->buckets[last_b].second == align_up((size_t)L0.nw(), 4) &&
+                       e->tile_off[last_b + 1] - e->tile_off[last_b] == rt6 * ct6 && e->flat_off[last_b + 1] == e->flat_off[last_b] &&
+                       2.0e-9 * (double)((long)e->batch * e->T) * L0.cout * L0.cin > 250.0;      // the big-GEMM regime: main stream, split-K 1
+    }
     const int B = e->batch, n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
     const float coefB = beta / (float)B;
@@ -2119,12 +2151,40 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             // release it BEFORE the first-layer weight-gradient GEMM so that its all-reduce (and, with it, the AdamW
             // of every other layer) does not queue behind the 390 MB first-layer bucket
             const std::function<void()> early = [&]() { flush_fin(true); fire_at(small_bucket); };
-            CHK(block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early, nullptr, nullptr, a_ready));
+            if (last_chunked) {
+                e->dw_chunks = e->ddp_last_chunks; e->dw_chunk_layer = L0i;
+                e->dw_chunk_hook = [&](int c, int n_c, int co0, int co1) -> int {
+                    const Layer& L0 = e->layers[L0i];
+                    const size_t off = L0.gw + (size_t)co0 * L0.cin, cnt = (size_t)(co1 - co0) * L0.cin;
+                    const hipStream_t cs = e->comm_stream;
+                    if (gather_on(cs)) return 1;                                  // the chunk's GEMM (main stream)
+                    const bool lp = e->payload_bf16 != 0;
+                    void* w = lp ? (void*)((char*)e->grads_lp + 2 * off) : (void*)(e->grads + off);
+                    if (lp) ew_pack_bf16(e->grads + off, w, (long)cnt, cs);
+                    if (g_rccl.AllReduce(w, w, cnt, lp ? kNcclBfloat16 : kNcclFloat32, kNcclAvg, e->comm, cs)) return 1;
+                    if (c == 0 && e->bucket_dots[last_b].second) {
+                        float* d = e->grads + e->bucket_dots[last_b].first;
+                        if (g_rccl.AllReduce(d, d, e->bucket_dots[last_b].second, kNcclFloat32, kNcclAvg, e->comm, cs)) return 1;
+                    }
+                    hipEvent_t ev = c == n_c - 1 ? e->bucket_done[last_b] : next_event(e);
+                    if (!ev || hipEventRecord(ev, cs) != hipSuccess || hipStreamWaitEvent(e->opt, ev, 0) != hipSuccess) return 1;
+                    if (lp && !e->lp_direct) ew_unpack_bf16(w, e->grads + off, (long)cnt, e->opt);
+                    const int ct6 = (L0.cin + 63) / 64, t0 = e->tile_off[last_b] + (co0 / 64) * ct6, t1 = e->tile_off[last_b] + (co1 / 64) * ct6;
+                    if (adamw_tiles(e, fuse_lr, t0, t1, e->opt, lp && e->lp_direct)) return 1;
+                    e->opt_dirty = true;
+                    if (c == n_c - 1) e->bucket_updated[last_b] = 1;
+                    return 0;
+                };
+            }
+            const int br = block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early, nullptr, nullptr, a_ready);
+            e->dw_chunks = 1; e->dw_chunk_layer = -1; e->dw_chunk_hook = nullptr;
+            CHK(br);
         } else {
             CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], &e->d_h[i - 1], B, nullptr, nullptr, nullptr, a_ready));
         }
     }
-    fire();   // first encoder block's weights
+    if (last_chunked && e->bucket_updated[last_b]) ++bucket;      // exchanged and updated chunk by chunk above
+    else fire();                                                   // first encoder block's weights
     if (early_err) return fail(SGV_ERR_HIP, "early AdamW launch failed");
     if (fuse) {
         const int nbk = (int)e->buckets.size();
@@ -2192,7 +2252,7 @@ static AdamCoef adam_coef(const sgv_engine* e) {
     const double b1 = 0.9, b2 = 0.999;
     return {(float)b1, (float)b2, (float)(1.0 - pow(b1, (double)e->step)), (float)sqrt(1.0 - pow(b2, (double)e->step))};
 }
-static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, bool from_lp = false) {
+static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, bool from_lp) {
     if (t1 <= t0) return 0;
     const AdamCoef c = adam_coef(e);
     if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, c.b1, c.b2, 1e-8f, 0.01f, c.bc1, c.bc2s, e->gnorm_part + e->n_items_adam_flat + t0, e->dt, st,

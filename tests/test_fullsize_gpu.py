@@ -162,3 +162,68 @@ def test_fullsize_fused_step_is_bitwise_equal_to_separate_calls(dtype):
     assert out[0][0] == out[1][0], (out[0][0], out[1][0])
     for k in names:
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
+
+
+@pytest.mark.parametrize("payload", ["f32", "bf16"])
+def test_fullsize_engine_issued_data_parallel_step(monkeypatch, payload):
+    """The data-parallel step at full size through REAL RCCL calls on a one-rank group (SGV_FORCE_COLLECTIVE=1: every bucket packed,
+    all-reduced, updated as with more ranks), engine-issued path: weight buckets averaged together with their <G,W> scalars and
+    updated on the optimizer stream under backward, the last bucket (first encoder layer, 97 M gradients) produced, exchanged and
+    updated in two row chunks of its weight-gradient GEMM (batch 8: that GEMM is in the big-GEMM regime).  AVG over one rank is the
+    identity, so with the fp32 wire format two steps must leave BITWISE the state of the plain step; with the bf16 wire format the
+    weight gradients are rounded once to bf16 on the way (gradient norm within 1e-3, the big weights within 3e-3 rel-L2 of the
+    plain step after two AdamW steps)."""
+    import torch.distributed as dist
+    from modules.train import NativeAllReduce
+    monkeypatch.setenv("SGV_FORCE_COLLECTIVE", "1")
+    monkeypatch.setenv("SGV_GRAD_PAYLOAD", payload)
+    cfg = VAEConfig(32, 8, ENC, ENC[::-1], N, T, "MSE", True)
+    state = init_state(cfg, 7, reference_init=True)
+    Bs = 8
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand((Bs, N, T), generator=g, device="cuda") * 1.4 - 0.7
+    dec = cfg.num_filter_dec
+    eps = [torch.randn((Bs, cfg.latent_dim), generator=g, device="cuda")] + \
+          [torch.randn((Bs, dec[i + 1], T), generator=g, device="cuda") for i in range(len(dec) - 2)]
+    names = BIG + ["encoder.encoder_blocks.0.module_list.0._seq.0.weight_u", "encoder.encoder_blocks.0.module_list.0._seq.0.bias",
+                   "encoder.xs_linear.1.weight_orig", "decoder.recon.1.bias"]
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        out = []
+        for mode in ("plain", "ddp"):
+            eng = E.Engine(cfg, max_batch=Bs, compute_dtype="bf16")
+            eng.load_state(state)
+            ar = NativeAllReduce(eng) if mode == "ddp" else None
+            assert ar is None or not ar.single
+            rec = []
+            for step in range(2):
+                eng.set_input(x)
+                eng.set_eps([e.contiguous() for e in eps])
+                sc = eng.forward(train=True)
+                if ar is not None:
+                    ar.backward_step(eng, ALPHA, BETA, 1e-3)
+                else:
+                    eng.backward_step(ALPHA, BETA, 1e-3)
+                rec.append((sc["recon"], tuple(sc["kls"]), eng.last_grad_norm()))
+            sd = eng.state_dict()
+            out.append((rec, {k: sd[k] for k in names}))
+            if ar is not None:
+                ar.close()
+            eng.close()
+        (ra, sa), (rb, sb) = out
+        if payload == "f32":
+            assert ra == rb, (ra, rb)
+            for k in names:
+                assert np.array_equal(sa[k], sb[k]), k
+        else:
+            assert ra[0][:2] == rb[0][:2]                       # the first forward saw the same weights
+            for (_, _, na), (_, _, nb) in zip(ra, rb):
+                assert abs(na - nb) <= 1e-3 * na
+            for k in BIG[:4]:       # two AdamW steps move an element by <= 2e-3; a once-more-rounded gradient re-draws the sign of the near-zero ones
+                assert rel_l2(sb[k], sa[k]) <= 3e-3, k
+    finally:
+        if created:
+            dist.destroy_process_group()
