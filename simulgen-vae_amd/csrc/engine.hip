@@ -1994,6 +1994,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     const int last_b = (int)e->buckets.size() - 2;
     const int L0i = e->encA[0].st[0].layer;
     bool last_chunked = false;
+    std::vector<hipEvent_t> chunk_done;
     if (dearly && e->ddp_last_chunks > 1 && last_b >= 0) {
         const Layer& L0 = e->layers[L0i];
         const int rt6 = (L0.cout + 63) / 64, ct6 = (L0.cin + 63) / 64;
@@ -2167,18 +2168,28 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
                         if (g_rccl.AllReduce(d, d, e->bucket_dots[last_b].second, kNcclFloat32, kNcclAvg, e->comm, cs)) return 1;
                     }
                     hipEvent_t ev = c == n_c - 1 ? e->bucket_done[last_b] : next_event(e);
-                    if (!ev || hipEventRecord(ev, cs) != hipSuccess || hipStreamWaitEvent(e->opt, ev, 0) != hipSuccess) return 1;
-                    if (lp && !e->lp_direct) ew_unpack_bf16(w, e->grads + off, (long)cnt, e->opt);
-                    const int ct6 = (L0.cin + 63) / 64, t0 = e->tile_off[last_b] + (co0 / 64) * ct6, t1 = e->tile_off[last_b] + (co1 / 64) * ct6;
-                    if (adamw_tiles(e, fuse_lr, t0, t1, e->opt, lp && e->lp_direct)) return 1;
-                    e->opt_dirty = true;
-                    if (c == n_c - 1) e->bucket_updated[last_b] = 1;
+                    if (!ev || hipEventRecord(ev, cs) != hipSuccess) return 1;
+                    chunk_done.push_back(ev);
                     return 0;
                 };
             }
             const int br = block_bwd(e, e->encA[0], x_prev, e->enc_a_dummy[0], nullptr, B, &early, nullptr, nullptr, a_ready);
             e->dw_chunks = 1; e->dw_chunk_layer = -1; e->dw_chunk_hook = nullptr;
             CHK(br);
+            if (last_chunked && (int)chunk_done.size() == e->ddp_last_chunks) {
+                // the chunks' updates go to the MAIN stream, behind the last GEMM chunk: it has nothing else left to do, and chunk c's
+                // AdamW then runs beside chunk c + 1's exchange instead of in front of it on the communication stream's queue
+                const Layer& L0 = e->layers[L0i];
+                const int n_c = e->ddp_last_chunks, rows = L0.cout / n_c, ct6 = (L0.cin + 63) / 64;
+                const bool lp = e->payload_bf16 != 0;
+                for (int c = 0; c < n_c; ++c) {
+                    const size_t off = L0.gw + (size_t)c * rows * L0.cin, cnt = (size_t)rows * L0.cin;
+                    HIPCHK(hipStreamWaitEvent(e->stream, chunk_done[c], 0));
+                    if (lp && !e->lp_direct) ew_unpack_bf16((const char*)e->grads_lp + 2 * off, e->grads + off, (long)cnt, e->stream);
+                    CHK(adamw_tiles(e, fuse_lr, e->tile_off[last_b] + (c * rows / 64) * ct6, e->tile_off[last_b] + ((c + 1) * rows / 64) * ct6, e->stream, lp && e->lp_direct));
+                }
+                e->bucket_updated[last_b] = 1;
+            }
         } else {
             CHK(block_bwd(e, e->encA[i], x_prev, e->enc_a_dummy[i], &e->d_h[i - 1], B, nullptr, nullptr, nullptr, a_ready));
         }
