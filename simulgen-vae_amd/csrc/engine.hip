@@ -1664,17 +1664,28 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
         ew_linear_expand_fwd(e->dt, e->zlat, e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->sbuf.p, B, l.cin, l.cout, e->stream);
     }
     CHK(block_fwd(e, e->decS, e->sbuf, B));
+    static const int hoist = getenv("SGV_LANE_HOIST") ? atoi(getenv("SGV_LANE_HOIST")) : 1;
     for (int i = 0; i < n_st; ++i) {
-        CHK(block_fwd(e, e->decU[i], e->zs[i], B));
-        CHK(block_fwd(e, e->decD[i], e->decU[i].st.back().a, B));
-        if (i == n_st - 1) break;
-        const int C = e->dec[i + 1];
-        {   // posterior branch (xs lift -> condition_xz) on the second lane, beside the prior branch below
-            Lane2 lane(e);
+        const bool post = i < n_st - 1;
+        auto xs_lift = [&]() -> int {       // xs lift of the posterior branch: depends on the encoder only
             const Layer& l = e->layers[e->xs_exp[i]];
             const int lvl = n - 2 - i;
             ew_linear_expand_fwd(e->dt, e->xs_raw[lvl], e->params + l.w, e->params + l.b, e->sn_sigma + 2 * l.sn + 1, e->xl[i].p, B, l.cin, l.cout, e->stream);
-            CHK(block_fwd(e, e->decX[i], e->xl[i], B));
+            return block_fwd(e, e->decX[i], e->xl[i], B);
+        };
+        if (post && hoist) {
+            // hoisted onto the second lane beside this stage's up-sampling and residual blocks: the lane's chain (lift, condition_xz) was
+            // twice as long as the prior branch it ran beside, and the main stream waited for it at the join
+            Lane2 lane(e);
+            CHK(xs_lift());
+        }
+        CHK(block_fwd(e, e->decU[i], e->zs[i], B));
+        CHK(block_fwd(e, e->decD[i], e->decU[i].st.back().a, B));
+        if (!post) break;
+        const int C = e->dec[i + 1];
+        {   // posterior branch (xs lift -> condition_xz) on the second lane, beside the prior branch below
+            Lane2 lane(e);
+            if (!hoist) CHK(xs_lift());
             CHK(block_fwd(e, e->decQ1[i], e->cat[i], B));
             CHK(block_fwd(e, e->decQ2[i], e->decQ1[i].st.back().a, B));
         }
@@ -2093,6 +2104,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         fire();
     }
     // ---- decoder stages ----
+    static const int hoist_b = getenv("SGV_LANE_HOIST") ? atoi(getenv("SGV_LANE_HOIST")) : 1;
     for (int i = n_st - 1; i >= 0; --i) {
         const int C = e->dec[i + 1];
         if (i < n_st - 1) {
@@ -2100,25 +2112,37 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
                          e->gp[i].p, e->gq[i].p, (int)M, C, coefB, e->stream);
             Tensor d_xs = e->dcat[i]; d_xs.C = C;
             Tensor d_oq = e->dcat[i]; d_oq.C = C; d_oq.p = (char*)d_oq.p + (size_t)C * e->esz;
+            auto xs_lift_bwd = [&]() -> int {
+                const int r = block_bwd(e, e->decX[i], e->xl[i], d_xs, &e->d_xl[i], B);
+                if (r) return r;
+                const Layer& l = e->layers[e->xs_exp[i]];
+                const int lvl = n - 2 - i;
+                ew_linear_expand_bwd(e->dt, e->d_xl[i].p, e->xs_raw[lvl], e->params + l.w, e->sn_sigma + 2 * l.sn + 1, e->d_xs_raw[lvl],
+                                     e->grads + l.gw, e->grads + l.gb, B, l.cin, l.cout, e->stream);
+                return 0;
+            };
             {   // posterior branch on the second lane, beside the prior branch below (they meet in the add3 after the join)
                 Lane2 lane(e);
                 bool q_ready = false;      // condition_xz: the output convolution's input gradient went straight into the residual block's GroupNorm backward
                 CHK(block_bwd(e, e->decQ2[i], e->decQ1[i].st.back().a, e->gq[i], &e->d_qres[i], B, nullptr, &e->decQ1[i].st.back(), &q_ready, false, 0.1f));
                 CHK(block_bwd(e, e->decQ1[i], e->cat[i], e->d_qres[i], &e->dcat[i], B, nullptr, nullptr, nullptr, q_ready));
-                CHK(block_bwd(e, e->decX[i], e->xl[i], d_xs, &e->d_xl[i], B));
-                const Layer& l = e->layers[e->xs_exp[i]];
-                const int lvl = n - 2 - i;
-                ew_linear_expand_bwd(e->dt, e->d_xl[i].p, e->xs_raw[lvl], e->params + l.w, e->sn_sigma + 2 * l.sn + 1, e->d_xs_raw[lvl],
-                                     e->grads + l.gw, e->grads + l.gb, B, l.cin, l.cout, e->stream);
+                if (!hoist_b) CHK(xs_lift_bwd());
             }
             bool p_ready = false;
             CHK(block_bwd(e, e->decP2[i], e->decP1[i].st.back().a, e->gp[i], &e->d_pres[i], B, nullptr, &e->decP1[i].st.back(), &p_ready, false, 0.1f));
             CHK(block_bwd(e, e->decP1[i], e->dec_out[i], e->d_pres[i], &e->d_outp[i], B, nullptr, nullptr, nullptr, p_ready));
             lane2_join(e);
             ew_add3(e->dt, e->d_outp[i].p, e->d_outp[i].ld, e->dzs[i + 1].p, e->dzs[i + 1].ld, d_oq.p, d_oq.ld, e->d_out[i].p, e->d_out[i].ld, (int)M, C, e->stream);
+            if (hoist_b) {
+                // the xs lift's backward needs d_xs only: deferred onto the lane beside the residual / up-sampling blocks' backward
+                // below (the mirror of the forward hoist); joined before the stage's bucket is released
+                Lane2 lane(e);
+                CHK(xs_lift_bwd());
+            }
         }
         CHK(block_bwd(e, e->decD[i], e->decU[i].st.back().a, e->d_out[i], &e->d_u[i], B));
         CHK(block_bwd(e, e->decU[i], e->zs[i], e->d_u[i], &e->dzs[i], B));
+        if (i < n_st - 1 && hoist_b) lane2_join(e);
         if (i == 0) {
             CHK(block_bwd(e, e->decS, e->sbuf, e->dzs[0], &e->d_sbuf, B));
             const Layer& l = e->layers[e->start_lin];
