@@ -426,7 +426,7 @@ def test_two_rank_data_parallel_steps(tmp_path, payload, ahead):
         assert np.array_equal(a, w) and np.array_equal(b, w), k
 
 
-@pytest.mark.parametrize("path,payload", [("torch", "f32"), ("torch", "bf16"), ("native", "f32"), ("native", "bf16")])
+@pytest.mark.parametrize("path,payload", [("torch", "f32"), ("torch", "bf16"), ("native", "f32"), ("native", "bf16"), ("torch-wire", "bf16")])
 def test_one_rank_forced_collectives_through_rccl(monkeypatch, path, payload):
     """One-GPU rehearsal of the N > 1 step with REAL RCCL calls (SGV_FORCE_COLLECTIVE=1: a one-rank group normally issues no
     collective at all, so nothing else on a one-GPU box runs ncclAllReduce(ncclAvg) on the fp32 arena / the bf16 wire copy,
@@ -441,6 +441,9 @@ def test_one_rank_forced_collectives_through_rccl(monkeypatch, path, payload):
     from tests.gpu_common import G1
     monkeypatch.setenv("SGV_FORCE_COLLECTIVE", "1")
     monkeypatch.setenv("SGV_GRAD_PAYLOAD", payload)
+    if path == "torch-wire":      # released buckets gathered and packed on the engine's wire stream, collectives issued from there
+        monkeypatch.setenv("SGV_DDP_WIRE", "1")
+        path = "torch"
     cfg = make_cfg(G1)
     B = 4
     x = torch.from_numpy(synthetic_samples(5, range(B), cfg.num_node, cfg.num_time)).cuda()
@@ -460,6 +463,7 @@ def test_one_rank_forced_collectives_through_rccl(monkeypatch, path, payload):
             if mode == "torch":
                 ar = GradAllReduce(eng)
                 assert not ar.single and (ar.flat_lp is not None) == (payload == "bf16")
+                assert (ar.wire is not None) == (os.environ.get("SGV_DDP_WIRE") == "1")
             elif mode == "native":
                 ar = NativeAllReduce(eng)
                 assert not ar.single
