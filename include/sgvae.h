@@ -304,6 +304,10 @@ int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias
                         int K, int taps, int Tlen, int splitk, int out_f32, int mode, int Cg, double* sums, int* plan_kind, void* stream);
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,
                      int Tlen, int splitk, int use_tr /* 2: force the 128x256 two-blocks-per-CU kernel */, void* stream);
+/* Test hook for the stream placement: *overlaps = 1 if kernels of the engine's auxiliary stream `which` (0 second lane, 1 weight-
+ * gradient side stream, 2 optimizer stream, 3 the engine's communication stream; 2 and 3 are created by the call if need be) can run
+ * while a kernel of the engine stream is running, i.e. the two do not share a hardware queue; -1 if the engine has no such stream. */
+int sgv_test_stream_overlap(sgv_engine* e, int which, int* overlaps);
 
 #ifdef __cplusplus
 }

@@ -2687,6 +2687,15 @@ int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias
     return SGV_OK;
 }
 
+int sgv_test_stream_overlap(sgv_engine* e, int which, int* overlaps) {
+    if (!e || !overlaps) return fail(SGV_ERR_ARG, "null argument");
+    hipStream_t s = which == 0 ? e->lane2 : which == 1 ? e->side : which == 2 ? ensure_opt(e) : which == 3 ? ensure_comm_own(e) : nullptr;
+    if (which < 0 || which > 3) return fail(SGV_ERR_ARG, "which must be 0..3");
+    if (!s) { *overlaps = -1; return SGV_OK; }
+    HIPCHK(hipStreamSynchronize(e->stream));
+    *overlaps = streams_overlap(e->stream, s) ? 1 : 0;
+    return SGV_OK;
+}
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps, int Tlen, int splitk,
                      int use_tr, void* stream) {
     GemmTN p; memset(&p, 0, sizeof(p));

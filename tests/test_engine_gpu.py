@@ -264,3 +264,26 @@ def test_schedule_and_fused_stage_options_agree():
     assert abs(nb - nu) <= 1e-2 * nu
     for k in gb:
         assert rel_l2(gb[k], gu[k]) < 2e-2, (k, rel_l2(gb[k], gu[k]))
+
+
+def test_auxiliary_streams_do_not_share_the_main_streams_hardware_queue():
+    """The HIP runtime maps streams onto four hardware queues and kernels of two streams on one queue never overlap; which
+    queue a new stream gets depends on how many streams the process created before (this pytest process: torch's, earlier
+    engines').  The engine probes every auxiliary stream at creation and rejects candidates that cannot run beside the main
+    stream: second lane, side stream, optimizer stream and the engine's own communication stream must all
+    report that their kernels overlap a running main-stream kernel -- for three engines created one after the other."""
+    import ctypes as C
+    from simulgen_vae_amd.engine import Engine
+    from tests.gpu_common import G1, make_cfg
+    lib = E.load_library()
+    lib.sgv_test_stream_overlap.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    engines = [Engine(make_cfg(G1), max_batch=2, compute_dtype="bf16") for _ in range(3)]
+    try:
+        for eng in engines:
+            for which in range(4):
+                o = C.c_int(-2)
+                assert lib.sgv_test_stream_overlap(eng.h, which, C.byref(o)) == 0, lib.sgv_last_error()
+                assert o.value == 1, (which, o.value)
+    finally:
+        for eng in engines:
+            eng.close()
