@@ -1247,22 +1247,25 @@ static bool streams_overlap(hipStream_t a, hipStream_t b) {
     (void)hipGetLastError();
     return overlap;
 }
-// A new auxiliary stream that shares its hardware queue with none of `avoid` (up to 6 candidates: the runtime hands queues out
-// round-robin, so the next stream lands elsewhere; the rejected ones are destroyed afterwards so that the keeper holds its place).
+// A new auxiliary stream that shares its hardware queue with none of `avoid`.  The runtime gives a new stream the least-loaded
+// queue (round-robin in a fresh process; in a process that has created and destroyed many streams the main stream's queue can be the
+// emptiest for many creations in a row), so the rejected candidates stay alive until a keeper is found -- every reject loads the
+// queue it sits on and steers the next candidate elsewhere -- and up to 32 candidates are tried (0.3 ms each per stream to avoid).
 // SGV_STREAM_PROBE=0: take the first.  If every candidate collides the last one is kept.
 static hipError_t make_aux_stream(hipStream_t* out, const char* env, int level, std::initializer_list<hipStream_t> avoid) {
     static const int probe = getenv("SGV_STREAM_PROBE") ? atoi(getenv("SGV_STREAM_PROBE")) : 1;
     std::vector<hipStream_t> rejected;
     hipStream_t s = nullptr;
     hipError_t rc = hipSuccess;
-    for (int attempt = 0; attempt < 6; ++attempt) {
+    constexpr int kAttempts = 32;
+    for (int attempt = 0; attempt < kAttempts; ++attempt) {
         s = nullptr;
         rc = make_stream(&s, env, level);
         if (rc != hipSuccess || !probe) break;
         bool ok = true;
         for (hipStream_t a : avoid) if (a != s && !streams_overlap(a, s)) { ok = false; break; }      // a == nullptr is the null stream: probed too
         if (getenv("SGV_STREAM_LOG")) fprintf(stderr, "[sgvae] %s: candidate %d %s\n", env, attempt, ok ? "kept" : "shares a hardware queue with a stream it must not, rejected");
-        if (ok || attempt == 5) break;
+        if (ok || attempt == kAttempts - 1) break;
         rejected.push_back(s);
     }
     for (hipStream_t r : rejected) hipStreamDestroy(r);
