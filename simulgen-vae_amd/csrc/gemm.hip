@@ -1016,17 +1016,26 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int tiles_1 = (p.N1 + 127) >> 7, tiles_2 = (p.N2 + 255) >> 8;
     const int ntiles = tiles_1 * tiles_2;
-    const int logical = xcd_remap(blockIdx.x, ntiles * p.taps * p.splitk);
-    const int tz = logical / ntiles;
-    const int tile = logical - tz * ntiles;
-    int t1, t2;
-    grouped_raster(tile, tiles_1, tiles_2, t1, t2);
-    const int i0 = t1 << 7, j0 = t2 << 8;
-    const int tap = tz / p.splitk, z = tz - tap * p.splitk;
-    const int dt = C2D ? 0 : tap - p.pad;
+    const int nitems = ntiles * p.taps * p.splitk;
+    // ---- schedule.  order 0: one work item per block, XCD-chunked, (tap, slice) slowest, grouped raster (round 1).
+    // order 1 (persistent): the grid is 2 blocks per CU; XCD x owns the x-th contiguous chunk of the item list and its block j
+    // walks items chunk_lo + j, + nbx, ...: all blocks start together and do equal work per item, so the ~64 items an XCD has in
+    // flight stay in step and form one patch of the list.  The list is cut into patches of pt1 x pt2 tiles x all taps (tap
+    // fastest: the taps of a tile read the same dY panel and the same X panel, shifted by a row), so the blocks in flight share
+    // pt1 dY panels and pt2 X panels in the XCD's L2.
+    int item, item_end, item_step;
+    if (p.order == 1) {
+        const int xcd = blockIdx.x & 7, jb = blockIdx.x >> 3;
+        const int q8 = nitems >> 3, r8 = nitems & 7;
+        const int it_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
+        item_end = it_lo + (xcd < r8 ? q8 + 1 : q8);
+        item_step = ((int)gridDim.x - xcd + 7) >> 3;
+        item = it_lo + jb;
+    } else {
+        item = xcd_remap(blockIdx.x, nitems);
+        item_end = item + 1; item_step = 1;
+    }
     const int ksteps = (p.M + KR - 1) / KR;
-    const int s_begin = (int)((long)ksteps * z / p.splitk);
-    const int s_end = (int)((long)ksteps * (z + 1) / p.splitk);
 
     const __amdgpu_buffer_rsrc_t rsA = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.A), 0, (int)p.a_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rsX = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.B), 0, (int)p.b_bytes, 0x00020000);
@@ -1039,44 +1048,30 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
     //    landed (SGV_T2_FIX), only in the stages that contain a sample boundary.
     const int la_row = lane >> 4;
     const int la_chunk = (lane & 15) ^ (la_row << 2);
-    const uint32_t a_col = (i0 + la_chunk * 8) < p.N1 ? (uint32_t)((i0 + la_chunk * 8) * ESZ) : OOB_OFF;
     const int lx_row = lane >> 5;
     const int lx_chunk0 = (lane & 31) ^ (lx_row << 2);
     const int lx_chunk1 = (lane & 31) ^ ((2 + lx_row) << 2);
-    uint32_t x_col0 = (j0 + lx_chunk0 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk0 * 8) * ESZ) : OOB_OFF;
-    uint32_t x_col1 = (j0 + lx_chunk1 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk1 * 8) * ESZ) : OOB_OFF;
-    // C2D: window offsets (minus the padding) of the lane's two chunk columns; state of the lane's first row of the next stage
-    int dh0 = 0, dw0 = 0, dh1 = 0, dw1 = 0;
-    uint32_t x_im = 0u;
-    int x_oh = 0, x_ow = 0;
     const uint32_t img_b = C2D ? (uint32_t)p.cv_H * (uint32_t)p.cv_W * (uint32_t)ldx_b : 0u;
-    if constexpr (C2D) {
-        const int vc0 = j0 + lx_chunk0 * 8, vc1 = j0 + lx_chunk1 * 8;
-        const int t0_ = vc0 / p.cv_C, t1_ = vc1 / p.cv_C;
-        const int kh0_ = t0_ / p.cv_kw, kh1_ = t1_ / p.cv_kw;
-        dh0 = kh0_ - p.cv_P; dw0 = t0_ - kh0_ * p.cv_kw - p.cv_P;
-        dh1 = kh1_ - p.cv_P; dw1 = t1_ - kh1_ * p.cv_kw - p.cv_P;
-        if (vc0 < p.N2) x_col0 = (uint32_t)((vc0 - t0_ * p.cv_C) * ESZ);
-        if (vc1 < p.N2) x_col1 = (uint32_t)((vc1 - t1_ * p.cv_C) * ESZ);
-        const int m_ = s_begin * KR + wave * 8 + lx_row;
-        const int hw_ = p.cv_Ho * p.cv_Wo;
-        const int b_ = m_ / hw_, q_ = m_ - b_ * hw_;
-        x_oh = q_ / p.cv_Wo; x_ow = q_ - x_oh * p.cv_Wo; x_im = (uint32_t)b_ * img_b;
-    }
-    uint32_t aoffs[2], xoffs[4];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) aoffs[q] = (uint32_t)(wave * 8 + q * 4 + la_row) * (uint32_t)lda_b + a_col;
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        xoffs[q] = (uint32_t)(wave * 8 + q * 2 + lx_row + dt) * (uint32_t)ldx_b + ((q & 1) ? x_col1 : x_col0);
     unsigned char* const dmaA = smem + wave * 8 * ROWA;
     unsigned char* const dmaX = smem + TILEA + wave * 8 * ROWX;
-    uint32_t ld_a = (uint32_t)(s_begin * KR) * (uint32_t)lda_b;
-    uint32_t ld_x = (uint32_t)(s_begin * KR) * (uint32_t)ldx_b;
-    int rd_t = (s_begin * KR) % p.Tlen;
     const uint32_t zero_base = (uint32_t)(uintptr_t)(lds_void*)smem + TILEA + (tid & 31) * 16;
     typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
     const u32x4_t zero4 = {0u, 0u, 0u, 0u};
+
+    const int lr = lane & 31, lh = lane >> 5;
+    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int rowpart = 8 * (g >> 1) + qq;
+    const uint32_t smem_b = (uint32_t)(uintptr_t)(lds_void*)smem;
+    const uint32_t a_base = smem_b + rowpart * ROWA + 32 * (g & 1) + 8 * pp;
+    const uint32_t fa0 = a_base + ((0 ^ qq) << 6), fa1 = a_base + ((1 ^ qq) << 6);
+    const uint32_t fa2 = a_base + ((2 ^ qq) << 6), fa3 = a_base + ((3 ^ qq) << 6);
+    const int xc0 = (8 * wave + 0 + 2 * (g & 1) + (pp >> 1)) ^ (qq << 2);
+    const int xc1 = (8 * wave + 4 + 2 * (g & 1) + (pp >> 1)) ^ (qq << 2);
+    const uint32_t fx0 = smem_b + TILEA + rowpart * ROWX + xc0 * 16 + 8 * (pp & 1);
+    const uint32_t fx1 = smem_b + TILEA + rowpart * ROWX + xc1 * 16 + 8 * (pp & 1);
+    typedef long tr64_t;
+    typedef long tr64x2_t __attribute__((ext_vector_type(2)));
+
 #define SGV_T2_A(Q, STAGE)                                                                                    \
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsA, (lds_void*)(dmaA + (STAGE) + (Q) * 1024), 16,      \
                                              aoffs[Q] + ld_a, 0, 0, 0);
@@ -1128,30 +1123,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
         }                                                                                                     \
         rd_t += KR; if (rd_t >= p.Tlen) rd_t -= p.Tlen;                                                       \
     }
-
-    f32x16 acc[4][2];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-
-    const int lr = lane & 31, lh = lane >> 5;
-    const int g = lane >> 4, qq = (lane >> 2) & 3, pp = lane & 3;
-    const int rowpart = 8 * (g >> 1) + qq;
-    const uint32_t smem_b = (uint32_t)(uintptr_t)(lds_void*)smem;
-    const uint32_t a_base = smem_b + rowpart * ROWA + 32 * (g & 1) + 8 * pp;
-    const uint32_t fa0 = a_base + ((0 ^ qq) << 6), fa1 = a_base + ((1 ^ qq) << 6);
-    const uint32_t fa2 = a_base + ((2 ^ qq) << 6), fa3 = a_base + ((3 ^ qq) << 6);
-    const int xc0 = (8 * wave + 0 + 2 * (g & 1) + (pp >> 1)) ^ (qq << 2);
-    const int xc1 = (8 * wave + 4 + 2 * (g & 1) + (pp >> 1)) ^ (qq << 2);
-    const uint32_t fx0 = smem_b + TILEA + rowpart * ROWX + xc0 * 16 + 8 * (pp & 1);
-    const uint32_t fx1 = smem_b + TILEA + rowpart * ROWX + xc1 * 16 + 8 * (pp & 1);
-    typedef long tr64_t;
-    typedef long tr64x2_t __attribute__((ext_vector_type(2)));
-    bf16x8 fA0, fA1, fA2, fA3, fB0, fB1;
-    bf16x8 gA0, gA1, gA2, gA3, gB0, gB1;
 #define SGV_T2_TR(DST, ADDR, IMM, PITCH)                                                                      \
     {                                                                                                         \
         tr64_t lo_, hi_;                                                                                      \
@@ -1187,36 +1158,126 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
         acc[3][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(X##A3, X##B1, acc[3][1], 0, 0, 0);                \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
-    const int nst = s_end - s_begin;
-    if (nst > 0) {
-        SGV_T2_ISSUE(0);
-        if (nst > 1) SGV_T2_ISSUE(STAGEB);
-        if (nst > 2) SGV_T2_ISSUE(2 * STAGEB);
-        if (nst > 2) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
-        else if (nst > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-        SGV_T2_FIX(0)
-        int cur = 0;                                // byte offset of the stage being consumed
-        for (int i = 0; i < nst; ++i) {
-            const uint32_t aa0 = fa0 + cur, aa1 = fa1 + cur, aa2 = fa2 + cur, aa3 = fa3 + cur;
-            const uint32_t ax0 = fx0 + cur, ax1 = fx1 + cur;
-            // both sub-steps' fragments are requested up front; the other block on the CU covers the latency
-            SGV_T2_LOAD(f, 0) SGV_T2_LOAD(g, 1)
-            SGV_T2_WAIT(f, 12) SGV_T2_MMA(f)
-            SGV_T2_WAIT(g, 0) SGV_T2_MMA(g)
-            if (i + 1 < nst) {
-                // my reads of `cur` have retired (lgkmcnt(0) above): wait for my part of the next stage, publish, refill
-                // `cur` with stage i + 3, patch the next stage's tap-boundary rows
-                const int nxt = cur == 2 * STAGEB ? 0 : cur + STAGEB;
-                if (i + 3 < nst) {
-                    asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
-                    SGV_T2_ISSUE(cur);
-                } else {
-                    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+
+    for (; item < item_end; item += item_step) {
+        // ---- decode the work item ----
+        int t1, t2, tap, z;
+        if (p.order == 1) {
+            const int per_z = ntiles * p.taps;
+            z = item / per_z;
+            const int r0_ = item - z * per_z;
+            const int band_full = p.pt1 * tiles_2 * p.taps;
+            const int band = r0_ / band_full, r1_ = r0_ - band * band_full;
+            const int first1 = band * p.pt1, g1 = min(p.pt1, tiles_1 - first1);
+            const int grp_full = g1 * p.pt2 * p.taps;
+            const int grp = r1_ / grp_full, r2_ = r1_ - grp * grp_full;
+            const int r3_ = r2_ / p.taps;
+            tap = r2_ - r3_ * p.taps;
+            const int c_ = r3_ / g1;
+            t1 = first1 + (r3_ - c_ * g1);
+            t2 = grp * p.pt2 + c_;
+        } else {
+            const int tz = item / ntiles;
+            grouped_raster(item - tz * ntiles, tiles_1, tiles_2, t1, t2);
+            tap = tz / p.splitk; z = tz - tap * p.splitk;
+        }
+        t1 = __builtin_amdgcn_readfirstlane(t1); t2 = __builtin_amdgcn_readfirstlane(t2);
+        tap = __builtin_amdgcn_readfirstlane(tap); z = __builtin_amdgcn_readfirstlane(z);
+        const int i0 = t1 << 7, j0 = t2 << 8;
+        const int dt = C2D ? 0 : tap - p.pad;
+        const int s_begin = (int)((long)ksteps * z / p.splitk);
+        const int s_end = (int)((long)ksteps * (z + 1) / p.splitk);
+
+        const uint32_t a_col = (i0 + la_chunk * 8) < p.N1 ? (uint32_t)((i0 + la_chunk * 8) * ESZ) : OOB_OFF;
+        uint32_t x_col0 = (j0 + lx_chunk0 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk0 * 8) * ESZ) : OOB_OFF;
+        uint32_t x_col1 = (j0 + lx_chunk1 * 8) < p.N2 ? (uint32_t)((j0 + lx_chunk1 * 8) * ESZ) : OOB_OFF;
+        // C2D: window offsets (minus the padding) of the lane's two chunk columns; state of the lane's first row of the next stage
+        int dh0 = 0, dw0 = 0, dh1 = 0, dw1 = 0;
+        uint32_t x_im = 0u;
+        int x_oh = 0, x_ow = 0;
+        if constexpr (C2D) {
+            const int vc0 = j0 + lx_chunk0 * 8, vc1 = j0 + lx_chunk1 * 8;
+            const int t0_ = vc0 / p.cv_C, t1_ = vc1 / p.cv_C;
+            const int kh0_ = t0_ / p.cv_kw, kh1_ = t1_ / p.cv_kw;
+            dh0 = kh0_ - p.cv_P; dw0 = t0_ - kh0_ * p.cv_kw - p.cv_P;
+            dh1 = kh1_ - p.cv_P; dw1 = t1_ - kh1_ * p.cv_kw - p.cv_P;
+            if (vc0 < p.N2) x_col0 = (uint32_t)((vc0 - t0_ * p.cv_C) * ESZ);
+            if (vc1 < p.N2) x_col1 = (uint32_t)((vc1 - t1_ * p.cv_C) * ESZ);
+            const int m_ = s_begin * KR + wave * 8 + lx_row;
+            const int hw_ = p.cv_Ho * p.cv_Wo;
+            const int b_ = m_ / hw_, q_ = m_ - b_ * hw_;
+            x_oh = q_ / p.cv_Wo; x_ow = q_ - x_oh * p.cv_Wo; x_im = (uint32_t)b_ * img_b;
+        }
+        uint32_t aoffs[2], xoffs[4];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) aoffs[q] = (uint32_t)(wave * 8 + q * 4 + la_row) * (uint32_t)lda_b + a_col;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            xoffs[q] = (uint32_t)(wave * 8 + q * 2 + lx_row + dt) * (uint32_t)ldx_b + ((q & 1) ? x_col1 : x_col0);
+        uint32_t ld_a = (uint32_t)(s_begin * KR) * (uint32_t)lda_b;
+        uint32_t ld_x = (uint32_t)(s_begin * KR) * (uint32_t)ldx_b;
+        int rd_t = (s_begin * KR) % p.Tlen;
+
+        f32x16 acc[4][2];
+#pragma unroll
+        for (int a = 0; a < 4; ++a)
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        bf16x8 fA0, fA1, fA2, fA3, fB0, fB1;
+        bf16x8 gA0, gA1, gA2, gA3, gB0, gB1;
+
+        const int nst = s_end - s_begin;
+        if (nst > 0) {
+            SGV_T2_ISSUE(0);
+            if (nst > 1) SGV_T2_ISSUE(STAGEB);
+            if (nst > 2) SGV_T2_ISSUE(2 * STAGEB);
+            if (nst > 2) asm volatile("s_waitcnt vmcnt(12)\n\ts_barrier" ::: "memory");
+            else if (nst > 1) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+            SGV_T2_FIX(0)
+            int cur = 0;                                // byte offset of the stage being consumed
+            for (int i = 0; i < nst; ++i) {
+                const uint32_t aa0 = fa0 + cur, aa1 = fa1 + cur, aa2 = fa2 + cur, aa3 = fa3 + cur;
+                const uint32_t ax0 = fx0 + cur, ax1 = fx1 + cur;
+                // both sub-steps' fragments are requested up front; the other block on the CU covers the latency
+                SGV_T2_LOAD(f, 0) SGV_T2_LOAD(g, 1)
+                SGV_T2_WAIT(f, 12) SGV_T2_MMA(f)
+                SGV_T2_WAIT(g, 0) SGV_T2_MMA(g)
+                if (i + 1 < nst) {
+                    // my reads of `cur` have retired (lgkmcnt(0) above): wait for my part of the next stage, publish, refill
+                    // `cur` with stage i + 3, patch the next stage's tap-boundary rows
+                    const int nxt = cur == 2 * STAGEB ? 0 : cur + STAGEB;
+                    if (i + 3 < nst) {
+                        asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+                        SGV_T2_ISSUE(cur);
+                    } else {
+                        asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+                    }
+                    asm volatile("" ::: "memory");
+                    SGV_T2_FIX(nxt)
+                    cur = nxt;
                 }
-                asm volatile("" ::: "memory");
-                SGV_T2_FIX(nxt)
-                cur = nxt;
+            }
+        }
+        // every wave's LDS reads of this item have retired (lgkmcnt(0) before its last MFMAs): after this barrier the next item's
+        // first stages may overwrite the ring
+        if (item + item_step < item_end) asm volatile("s_barrier" ::: "memory");
+
+        float* outp = p.out + (long)z * p.out_slab_stride + (long)tap * p.out_tap_stride;
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                const int col = j0 + wave * 64 + b * 32 + lr;
+                if (col >= p.N2) continue;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int row = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                    if (row >= p.N1) continue;
+                    outp[(long)row * p.ldo + col] = acc[a][b][r];
+                }
             }
         }
     }
@@ -1229,22 +1290,6 @@ __global__ __launch_bounds__(256, 2) void gemm_tn_w2_kernel(const GemmTN p) {
 #undef SGV_T2_LOAD
 #undef SGV_T2_WAIT
 #undef SGV_T2_MMA
-
-    float* outp = p.out + (long)z * p.out_slab_stride + (long)tap * p.out_tap_stride;
-#pragma unroll
-    for (int a = 0; a < 4; ++a) {
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = j0 + wave * 64 + b * 32 + lr;
-            if (col >= p.N2) continue;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = i0 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                if (row >= p.N1) continue;
-                outp[(long)row * p.ldo + col] = acc[a][b][r];
-            }
-        }
-    }
 }
 
 // =========================================================================================
@@ -1394,6 +1439,35 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
+// Schedule of gemm_tn_w2_kernel (returns the grid).  Persistent form: 512 blocks = two per CU walk an XCD-chunked item list cut
+// into patches of pt1 x pt2 tiles x all taps.  The ~64 items an XCD has in flight then read pt1 dY panels (256-byte rows) and
+// pt2 X panels (512-byte rows): pick the patch that minimises (pt1 + 2 pt2) / (pt1 pt2) with pt1 pt2 taps <= 64.
+// Measured (round 3, tests/micro/order_ab.sh, FETCH_SIZE per launch / time): 5120 x 5120 x 5 taps 2.04 -> 1.15 GB, 829 -> 814 us;
+// 2560 x 2560 x 5 taps 0.44 -> 0.19 GB, 212 -> 217 us; the one-tap 95 008-wide gradients do NOT gain (recon head 2.52 -> 2.79 GB,
+// 652 -> 719 us; first encoder layer 1.33 -> 1.30 GB, 657 -> 668 us): there the fetches are the 6.5 MB operand falling out of
+// the 4 MiB L2 (Infinity-Cache hits), not missed panel sharing.  So: persistent for multi-tap launches with at least four rounds
+// of items (SGV_TN_PERSIST=0 / 1 forces one item per block / the persistent walk everywhere).
+static int tn_w2_schedule(GemmTN& q, int tiles_1, int tiles_2, int taps) {
+    static const int persist_env = getenv("SGV_TN_PERSIST") ? atoi(getenv("SGV_TN_PERSIST")) : -1;
+    const bool persist = q.force_w2 == 2 || (persist_env >= 0 ? persist_env != 0 : (taps > 1 && (long)tiles_1 * tiles_2 * taps * q.splitk >= 2048));
+    static const int f1 = getenv("SGV_TN_PT1") ? atoi(getenv("SGV_TN_PT1")) : 0;
+    static const int f2 = getenv("SGV_TN_PT2") ? atoi(getenv("SGV_TN_PT2")) : 0;
+    static const int slots = getenv("SGV_TN_SLOTS") ? atoi(getenv("SGV_TN_SLOTS")) : 512;
+    const int nitems = tiles_1 * tiles_2 * taps * q.splitk;
+    q.order = persist ? 1 : 0; q.pt1 = 1; q.pt2 = 1;
+    if (!persist) return nitems;
+    const int cap = slots / 8;
+    double best = 1e30;
+    for (int a = 1; a <= tiles_1 && a <= cap; ++a)
+        for (int b = 1; b <= tiles_2 && a * b * taps <= cap; ++b) {
+            const double c = (double)(a + 2 * b) / ((double)a * b);
+            if (c < best - 1e-9) { best = c; q.pt1 = a; q.pt2 = b; }
+        }
+    if (f1 > 0) q.pt1 = f1 < tiles_1 ? f1 : tiles_1;
+    if (f2 > 0) q.pt2 = f2 < tiles_2 ? f2 : tiles_2;
+    return nitems < slots ? nitems : slots;
+}
+
 int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
     if (p.M <= 0 || p.N1 <= 0 || p.N2 <= 0) return 0;
     const int epc = dtype == 1 ? 8 : 4;
@@ -1412,7 +1486,7 @@ int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
     }
     if (q.a_bytes >= 0x7FFFFFF0L || q.b_bytes >= 0x7FFFFFF0L) return -1;
     if (c2d && p.use_tr && (gemm_tn_uses_w2(dtype, p.M, p.N1, p.N2, p.M) || (p.force_w2 && gemm_tn_w2_eligible(dtype, p.M, p.N1, p.N2, p.M)))) {
-        dim3 gridw(cdiv(p.N1, 128) * cdiv(p.N2, 256) * p.splitk);
+        dim3 gridw(tn_w2_schedule(q, cdiv(p.N1, 128), cdiv(p.N2, 256), 1));
         hipLaunchKernelGGL(gemm_tn_w2_kernel<true>, gridw, dim3(256), 0, s, q);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
@@ -1423,7 +1497,7 @@ int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }
     if (p.use_tr && (gemm_tn_uses_w2(dtype, p.M, p.N1, p.N2, p.Tlen) || (p.force_w2 && gemm_tn_w2_eligible(dtype, p.M, p.N1, p.N2, p.Tlen)))) {
-        dim3 gridw(cdiv(p.N1, 128) * cdiv(p.N2, 256) * p.taps * p.splitk);
+        dim3 gridw(tn_w2_schedule(q, cdiv(p.N1, 128), cdiv(p.N2, 256), p.taps));
         hipLaunchKernelGGL(gemm_tn_w2_kernel<false>, gridw, dim3(256), 0, s, q);
         return hipGetLastError() == hipSuccess ? 0 : -2;
     }

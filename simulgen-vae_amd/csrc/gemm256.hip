@@ -58,6 +58,9 @@ constexpr uint32_t T256_OOB = 0x7FFFFFF0u;
 #ifndef T256_SETPRIO
 #define T256_SETPRIO 1
 #endif
+#ifndef T256_STRM_DEFAULT
+#define T256_STRM_DEFAULT 0   // stream policy of the banded launches (see STRM): measured, not assumed
+#endif
 
 // one 16-byte bf16 chunk from two packed halves
 __device__ __forceinline__ uint32_t t256_pack2(float a, float b) {
@@ -71,7 +74,10 @@ __device__ __forceinline__ float t256_hi(uint32_t v) { return __builtin_bit_cast
 // OUT: 0 = bf16 output (scale, bias, addend, optional statistics), 1 = fp32 (split-K slab: raw sums; or final fp32 output)
 // MT:  the layer has more than one tap (per-row tap windows are tested when a DMA is issued)
 // C2D: 2-D taps (GemmNT::cv_*, needs MT): rows are output pixels of a channels-last image batch, tap = (kh, kw)
-template <int OUT, bool MT, bool C2D = false>
+// STRM: cache policy of the two streams of a launch whose activation tiles should stay in the XCD's L2 (the recon head: every
+//       weight panel is read once per XCD and 608 MB of output flow through the same 4 MiB): bit 0 = the weight stream is
+//       loaded non-temporally, bit 1 = the bf16 output is stored with sc1 (the line leaves the L2 once written)
+template <int OUT, bool MT, bool C2D = false, int STRM = 0>
 __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     constexpr int ESZ = 2;
     constexpr int NST = (OUT == 0 ? 16 : 32) + 1;     // buffer stores per wave and epilogue + the next item's bias load
@@ -158,11 +164,26 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
         }                                                                                                     \
         IM = mk_;                                                                                             \
     }
+    // item -> (slice z, row tile tm, column tile tn).  p.band == 0: column-panel-major (the tiles_m row tiles of a weight panel are
+    // neighbours).  p.band > 0: the row tiles are cut into bands of p.band; band-major, then column tile, row tile fastest -- an
+    // XCD then works on one band (its activation tiles stay in L2) and streams the weight panels past it.
+#define T256_TILE_OF(IT, Z, TM, TN)                                                                           \
+    {                                                                                                         \
+        Z = T256_UNI((IT) / ntile);                                                                           \
+        const int rem_ = (IT) - Z * ntile;                                                                    \
+        if (p.band > 0) {                                                                                     \
+            const int bf_ = p.band * tiles_n;                                                                 \
+            const int b_ = T256_UNI(rem_ / bf_), r1_ = rem_ - b_ * bf_;                                       \
+            const int first_ = b_ * p.band, g_ = min(p.band, tiles_m - first_);                               \
+            TN = T256_UNI(r1_ / g_); TM = first_ + (r1_ - TN * g_);                                           \
+        } else {                                                                                              \
+            TN = T256_UNI(rem_ / tiles_m); TM = rem_ - TN * tiles_m;                                          \
+        }                                                                                                     \
+    }
 #define T256_SETUP_ITEM()                                                                                     \
     {                                                                                                         \
-        const int z_ = T256_UNI(li / ntile);                                                                  \
-        const int rem_ = li - z_ * ntile;                                                                     \
-        const int tn_ = T256_UNI(rem_ / tiles_m), tm_ = rem_ - tn_ * tiles_m;                                 \
+        int z_, tm_, tn_;                                                                                     \
+        T256_TILE_OF(li, z_, tm_, tn_)                                                                        \
         const int m0_ = tm_ << 8, n0_ = tn_ << 8;                                                             \
         l_kt = T256_UNI((int)((long)total_kt * z_ / p.splitk));                                               \
         l_kt_end = T256_UNI((int)((long)total_kt * (z_ + 1) / p.splitk));                                     \
@@ -199,6 +220,9 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
 #else
 #define T256_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (t256_lds_t*)(DST), 16, (VOFF), (SOFF), 0, 0);
 #endif
+#define T256_DMAW(VOFF, DST)                                                                                  \
+    if constexpr ((STRM & 1) != 0) { __builtin_amdgcn_raw_ptr_buffer_load_lds(rsW, (t256_lds_t*)(DST), 16, (VOFF), sW, 0, 2); } \
+    else { T256_DMA(rsW, VOFF, sW, DST) }
     // quarter issues: F = 1 fast path (cursor active, no K tail), F = 0 general; PB = byte offset of the parity buffer filled
 #define T256_ISSUE_A0(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
@@ -212,13 +236,13 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     }
 #define T256_ISSUE_B0(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
-        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsW, vW0, sW, ldsB0 + (PB)) T256_DMA(rsW, vW1, sW, ldsB0 + (PB) + 1024) } \
-        else { T256_DMA(rsW, T256_KT(vW0, dc0), sW, ldsB0 + (PB)) T256_DMA(rsW, T256_KT(vW1, dc1), sW, ldsB0 + (PB) + 1024) } \
+        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMAW(vW0, ldsB0 + (PB)) T256_DMAW(vW1, ldsB0 + (PB) + 1024) } \
+        else { T256_DMAW(T256_KT(vW0, dc0), ldsB0 + (PB)) T256_DMAW(T256_KT(vW1, dc1), ldsB0 + (PB) + 1024) } \
     }
 #define T256_ISSUE_B1(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
-        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsW, vW2, sW, ldsB1 + (PB)) T256_DMA(rsW, vW3, sW, ldsB1 + (PB) + 1024) } \
-        else { T256_DMA(rsW, T256_KT(vW2, dc0), sW, ldsB1 + (PB)) T256_DMA(rsW, T256_KT(vW3, dc1), sW, ldsB1 + (PB) + 1024) } \
+        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMAW(vW2, ldsB1 + (PB)) T256_DMAW(vW3, ldsB1 + (PB) + 1024) } \
+        else { T256_DMAW(T256_KT(vW2, dc0), ldsB1 + (PB)) T256_DMAW(T256_KT(vW3, dc1), ldsB1 + (PB) + 1024) } \
     }
     // move the load cursor to the next K-tile of the stream
 #define T256_ADVANCE(F)                                                                                       \
@@ -401,13 +425,12 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
 
     // ---------------- compute cursor ----------------
     int ci = it_lo + jb;
-    int c_z, c_m0, c_n0, c_nkt;
+    int c_z, c_m0, c_n0, c_nkt, c_tile;
 #define T256_DECODE_C()                                                                                       \
     {                                                                                                         \
-        c_z = T256_UNI(ci / ntile);                                                                           \
-        const int rem_ = ci - c_z * ntile;                                                                    \
-        const int tn_ = T256_UNI(rem_ / tiles_m), tm_ = rem_ - tn_ * tiles_m;                                 \
-        c_m0 = tm_ << 8; c_n0 = tn_ << 8;                                                                     \
+        int tm_, tn_;                                                                                         \
+        T256_TILE_OF(ci, c_z, tm_, tn_)                                                                       \
+        c_m0 = tm_ << 8; c_n0 = tn_ << 8; c_tile = tn_ * tiles_m + tm_;                                       \
         c_nkt = T256_UNI((int)((long)total_kt * (c_z + 1) / p.splitk) - (int)((long)total_kt * c_z / p.splitk)); \
     }
     T256_DECODE_C()
@@ -530,7 +553,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
 #ifdef T256_ABL_CONTIG      // timing only: every store instruction writes 1 KiB of consecutive bytes
                         __builtin_amdgcn_raw_buffer_store_b128(ch, rsC, (uint32_t)((((long)mw * p.ldc + nw) * 2 & ~1023L) + ((i * 2 + pr) * 8 + wave) * 1024 + lane * 16), 0, 0);
 #else
-                        if (!T256_ABL_NOSTORE_) __builtin_amdgcn_raw_buffer_store_b128(ch, rsC, ok ? (uint32_t)(((long)row * p.ldc + col) * 2) : T256_OOB, 0, 0);
+                        if (!T256_ABL_NOSTORE_) __builtin_amdgcn_raw_buffer_store_b128(ch, rsC, ok ? (uint32_t)(((long)row * p.ldc + col) * 2) : T256_OOB, 0, (STRM & 2) ? 16 : 0);
 #endif
                         if (st) {
                             // the chunk's two 4-column halves may lie in different groups (Cg % 4 == 0)
@@ -560,7 +583,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
                         vals[k] = x;
                     }
                     if (lane == 0) {
-                        float* dst = p.gn_part + ((long)ci * 8 + wave) * 8;
+                        float* dst = p.gn_part + ((long)c_tile * 8 + wave) * 8;    // statistics need split-K 1: one item per tile
                         *reinterpret_cast<t256_f4*>(dst) = (t256_f4){vals[0], vals[1], vals[2], vals[3]};
                         *reinterpret_cast<t256_f4*>(dst + 4) = (t256_f4){vals[4], vals[5], vals[6], vals[7]};
                     }
@@ -712,6 +735,29 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
     q.a_bytes = ((arows - 1) * p.lda + p.K) * 2;
     q.w_bytes = ((long)(p.taps - 1) * p.w_tap_stride + (long)(p.N - 1) * p.ldw + p.K) * 2;
     if (q.a_bytes >= 0x7FFFFFF0L || q.w_bytes >= 0x7FFFFFF0L) return -1;
+    // item order and stream policy (see T256_TILE_OF, STRM).  A one-tap product with a short K and many column panels (the recon
+    // head: K = 1024, N = 95 008) streams every weight panel once per XCD and 608 MB of output through the XCD's 4 MiB L2; its
+    // activation matrix (M x K, 6.5 MB) does not survive there, so the XCDs each take a band of row tiles (<= 3.5 MiB of
+    // activations).  SGV_T256_BAND / SGV_T256_STRM override (A/B runs); GemmNT::band / strm < 0 switch either off (tests).
+    static const int band_env = getenv("SGV_T256_BAND") ? atoi(getenv("SGV_T256_BAND")) : -1;
+    static const int strm_env = getenv("SGV_T256_STRM") ? atoi(getenv("SGV_T256_STRM")) : -1;
+    {
+        const int tm_all = t256_cdiv(p.M, 256), tn_all = t256_cdiv(p.N, 256);
+        const long a_tile_bytes = 256L * p.K * 2 * p.taps;
+        int band = p.band, strm = p.strm;                                // 0: chosen here; < 0: off (tests)
+        if (band == 0 && strm == 0 && !p.cv_kw && p.taps == 1 && p.splitk == 1 && tn_all >= 64 && (long)tm_all * a_tile_bytes > (7L << 19)) {
+            band = (int)((7L << 19) / a_tile_bytes);                     // row tiles whose activations fit 3.5 MiB
+            if (band < 1) band = 1;
+            const int nb = t256_cdiv(tm_all, band);
+            band = t256_cdiv(tm_all, nb);                                // equal bands
+            strm = T256_STRM_DEFAULT;
+        }
+        if (band_env >= 0 && p.band == 0) band = band_env;
+        if (strm_env >= 0 && p.strm == 0) strm = strm_env;
+        if (band < 0 || band >= tm_all) band = 0;
+        if (strm < 0) strm = 0;
+        q.band = band; q.strm = (!p.cv_kw && p.taps == 1 && !(p.splitk > 1 || p.out_f32)) ? (strm & 3) : 0;
+    }
     const int nitems = t256_cdiv(p.M, 256) * t256_cdiv(p.N, 256) * p.splitk;
     int grid = ((nitems + 7) / 8) * 8;
     if (grid > 256) grid = 256;
@@ -727,6 +773,9 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
         else hipLaunchKernelGGL((gemm_nt_t256_kernel<0, true>), dim3(grid), dim3(512), 0, s, q);
     } else {
         if (f32) hipLaunchKernelGGL((gemm_nt_t256_kernel<1, false>), dim3(grid), dim3(512), 0, s, q);
+        else if (q.strm == 1) hipLaunchKernelGGL((gemm_nt_t256_kernel<0, false, false, 1>), dim3(grid), dim3(512), 0, s, q);
+        else if (q.strm == 2) hipLaunchKernelGGL((gemm_nt_t256_kernel<0, false, false, 2>), dim3(grid), dim3(512), 0, s, q);
+        else if (q.strm == 3) hipLaunchKernelGGL((gemm_nt_t256_kernel<0, false, false, 3>), dim3(grid), dim3(512), 0, s, q);
         else hipLaunchKernelGGL((gemm_nt_t256_kernel<0, false>), dim3(grid), dim3(512), 0, s, q);
     }
     if (p.splitk > 1) {

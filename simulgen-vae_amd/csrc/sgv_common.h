@@ -161,6 +161,9 @@ struct GemmNT {
     // half-resolution batch [B][ceil(add_H/2)][ceil(add_W/2)][ldadd] that is added at the even pixels only -- the input gradient
     // of a stride-2 1x1 convolution folded into the GEMM that produces the other branch's input gradient
     int add_H, add_W;
+    // gemm256.hip item order, filled by launch_gemm_nt256: band > 0 = row tiles in bands of `band` (band-major list);
+    // strm = cache policy of the weight / output streams (bit 0: non-temporal weight loads, bit 1: sc1 output stores)
+    int band, strm;
 };
 // gemm256.hip
 bool gemm_nt256_eligible(int dtype, const GemmNT& p);
@@ -186,13 +189,16 @@ struct GemmTN {
     long out_tap_stride;
     long out_slab_stride;
     int M, N1, N2, taps, pad, Tlen, splitk, use_tr;
-    int force_w2;                   // tests: take gemm_tn_w2_kernel whenever the shape is eligible (ignores SGV_TN_W2)
+    int force_w2;                   // tests: take gemm_tn_w2_kernel whenever the shape is eligible (ignores SGV_TN_W2); 2: and its persistent walk
     long a_bytes, b_bytes;          // filled by launch_gemm_tn
     // virtual im2col operand (cv_kw > 0; weight gradient of a 2-D convolution without the im2col matrix): B is a channels-
     // last image batch [nb][cv_H][cv_W][ldb] with cv_C channels, reduction row m = output pixel (b, oh, ow) of a
     // [nb][cv_Ho][cv_Wo] grid, column n2 = (kh*cv_kw + kw)*cv_C + c reads B[b][oh*cv_S - cv_P + kh][ow*cv_S - cv_P + kw][c]
     // (zero outside the image); N2 = KH*cv_kw*cv_C, taps = 1, pad / Tlen are not used.
     int cv_kw, cv_H, cv_W, cv_S, cv_P, cv_Ho, cv_Wo, cv_C;
+    // gemm_tn_w2_kernel schedule, filled by launch_gemm_tn: order 1 = persistent walk over an XCD-chunked item list cut into
+    // patches of pt1 x pt2 tiles x all taps (see the kernel); 0 = one item per block (round 1's raster)
+    int order, pt1, pt2;
 };
 
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s);

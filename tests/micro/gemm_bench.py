@@ -17,9 +17,12 @@ if kind in ("nt", "nt256"):
     W = (torch.randn(taps, N, K, device="cuda") * 0.05).to(torch.bfloat16)
     C = torch.empty(M, N, device="cuda", dtype=torch.bfloat16)
     sk = int(os.environ.get("SPLITK", "1"))
+    stats = int(os.environ.get("STATS", "0"))      # 1: GroupNorm(8) statistics from the epilogue (the recon head's launch: all row tiles, split-K 1)
+    sums = torch.zeros(M // T * 8 * 2, device="cuda", dtype=torch.float64) if stats else None
     def run():
         if kind == "nt256":     # the planner's choice for the shape (256x256 persistent kernel + 128-row tail); the call allocates its workspaces
-            rc = lib.sgv_test_gemm_nt256(A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, 1, 0, None, None, None)
+            rc = lib.sgv_test_gemm_nt256(A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, 1,
+                                         N // 8 if stats else 0, sums.data_ptr() if stats else None, None, None)
         else:
             rc = lib.sgv_test_gemm_nt(1, A.data_ptr(), W.data_ptr(), C.data_ptr(), None, None, None, M, N, K, taps, T, sk, 0, None)
         assert rc == 0, lib.sgv_last_error()

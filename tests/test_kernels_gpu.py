@@ -177,6 +177,10 @@ NT256_CASES = [
     (3200, 1024, 1280, 5, 200, 0, 1),     # planned: 256 kernel (all rows, or 12 row tiles + 128 tail rows on the 128-row kernel)
     (3200, 2560, 1280, 5, 200, 0, 1),     # planned: 12 x 10 tiles x 2 slices on the 256 kernel + the 128-row tail
     (3200, 1024, 512, 1, 200, 0, 1),      # planned: below the size threshold -> 128-row kernels only
+    (3200, 4104, 512, 1, 200, 1, 0 | (5 << 8) | (1 << 16)),   # row tiles in bands of 5 (5 + 5 + 3), non-temporal weight stream, ragged N
+    (3100, 2048, 512, 1, 200, 1, 0 | (7 << 8) | (2 << 16)),   # bands of 7 + 6, ragged last row tile, sc1 output stores
+    (3200, 1280, 320, 3, 200, 2, 0 | (4 << 8)),               # bands with taps and split-K slices
+    (3200, 16640, 512, 1, 200, 1, 0),                         # the launcher's own choice for a one-tap product with >= 64 column panels
 ]
 
 
@@ -196,10 +200,11 @@ def test_gemm_nt256(case):
     dbias, dscale = torch.from_numpy(bias).cuda(), torch.tensor([0.37], device="cuda")
     kind = C.c_int(-1)
     ref = ref_conv_nt(A, W, bias, 0.37, None, taps, Tlen)
-    if mode == 0:       # fp32 output: final (split-K 1) or slabs + combine
+    base = mode & 0xff  # bits 8+: work-item order / weight-stream policy (include/sgvae.h)
+    if base == 0:       # fp32 output: final (split-K 1) or slabs + combine
         out = torch.full((M, N), float("nan"), dtype=torch.float32, device="cuda")
         rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), dbias.data_ptr(), dscale.data_ptr(), None, M, N, K,
-                                     taps, Tlen, splitk, 1, 0, 0, None, C.byref(kind), None)
+                                     taps, Tlen, splitk, 1, mode, 0, None, C.byref(kind), None)
         assert rc == 0, lib.sgv_last_error()
         got = out.cpu().numpy()
         assert np.isfinite(got).all()
@@ -208,7 +213,7 @@ def test_gemm_nt256(case):
     rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out2.data_ptr(), dbias.data_ptr(), dscale.data_ptr(), dadd.data_ptr(), M, N, K,
                                  taps, Tlen, splitk, 0, mode, 0, None, C.byref(kind), None)
     assert rc == 0, lib.sgv_last_error()
-    if mode == 1:
+    if base == 1:
         assert (kind.value in (1, 2)) if N * K * taps >= 1024 * 1280 * 5 else kind.value == 0, kind.value
     want = _bf16_round(ref.astype(np.float32)).astype(np.float64) + add        # the kernels round before adding the addend
     got2 = out2.float().cpu().numpy()
@@ -222,6 +227,8 @@ NT256_STATS_CASES = [
     (600, 1056, 512, 3, 200, 132),       # 132 = 4 * 33: group boundaries inside 64-column blocks and inside 8-column chunks
     (520, 1360, 520, 1, 130, 68),        # ragged M / N, Cg just above the 64-column limit, K tail
     (3200, 2048, 512, 1, 200, 256),      # several items per workgroup
+    (3200, 2048, 512, 1, 200, 256, 4),   # the same with the row tiles in bands of 4: the statistics partials are indexed by tile, not by list position
+    (3000, 4224, 512, 1, 200, 132, 6),   # bands of 6 + 6, ragged last row tile, groups inside column blocks
 ]
 
 
@@ -231,7 +238,8 @@ def test_gemm_nt256_stats_epilogue(case):
     == per-(sample, group) sum / sum of squares of the bf16 output the kernel stored (fp64), and bitwise equal between runs."""
     import torch
     lib = E.load_library()
-    M, N, K, taps, Tlen, Cg = case
+    M, N, K, taps, Tlen, Cg = case[:6]
+    order = (case[6] << 8) | (3 << 16) if len(case) > 6 else 0     # bands + non-temporal weights + sc1 output
     rng = np.random.default_rng(37)
     A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
     W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.1)
@@ -244,7 +252,7 @@ def test_gemm_nt256_stats_epilogue(case):
         out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
         sums = torch.full((B, G, 2), float("nan"), dtype=torch.float64, device="cuda")      # the finalize overwrites: no zero-fill needed
         rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), dbias.data_ptr(), None, None, M, N, K, taps, Tlen, 1, 0,
-                                     0, Cg, sums.data_ptr(), None, None)
+                                     order, Cg, sums.data_ptr(), None, None)
         assert rc == 0, lib.sgv_last_error()
         y = out.float().cpu().numpy().astype(np.float64)
         assert np.abs(y - ref).max() / np.abs(ref).max() < 8e-3
@@ -313,13 +321,18 @@ TN_W2_CASES = [
     (1360, 200, 512, 3, 34, 1),
     (288, 64, 256, 5, 48, 1),         # 9 stages
     (400, 128, 95008, 1, 200, 1),     # the first encoder layer's width on the input side (95008 = 371 * 256 + 32)
-    (400, 95008, 256, 1, 200, 1),     # the recon head's width on the output side (95008 = 742 * 128 + 32)
+    (400, 95008, 256, 1, 200, 1),     # the recon head's width on the output side (95008 = 742 * 128 + 32): 743 items on 512 persistent blocks
+    (640, 1408, 2560, 5, 64, 1),      # 11 x 10 tiles x 5 taps = 550 items: patches of tiles x taps, several items per block
+    (1280, 1288, 1288, 3, 128, 4),    # 11 x 6 tiles x 3 taps x 4 slices = 792 items, ragged tiles
 ]
 
 
+@pytest.mark.parametrize("persistent", [0, 1])
 @pytest.mark.parametrize("case", TN_W2_CASES)
-def test_gemm_tn_w2(case):
-    """gemm_tn_w2_kernel (128x256 tile, 32-row stages, two blocks per CU) vs numpy on bf16-exact inputs, 8x per shape."""
+def test_gemm_tn_w2(case, persistent):
+    """gemm_tn_w2_kernel (128x256 tile, 32-row stages, two blocks per CU) vs numpy on bf16-exact inputs, 8x per shape, with one
+    work item per block and with the persistent walk over patches of tiles x taps (what the launcher picks for the big multi-tap
+    gradients); both orders must give bitwise the same matrix."""
     import torch
     lib = E.load_library()
     M, N1, N2, taps, Tlen, splitk = case
@@ -331,13 +344,17 @@ def test_gemm_tn_w2(case):
     scale = np.abs(ref).max()
     for rep in range(8):
         out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
-        # use_tr = 2: force the two-blocks-per-CU kernel for every eligible shape (whatever SGV_TN_W2 says)
-        rc = lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk, 2, None)
+        # use_tr = 2: force the two-blocks-per-CU kernel for every eligible shape (whatever SGV_TN_W2 says); 3: and its persistent walk
+        rc = lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk, 2 + persistent, None)
         assert rc == 0, lib.sgv_last_error()
         got = out.cpu().numpy()
         assert np.isfinite(got).all(), (case, rep)
         err = np.abs(got - ref).max() / scale
         assert err < 2e-5, (case, rep, err)
+    if persistent:
+        other = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+        assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), other.data_ptr(), M, N1, N2, taps, Tlen, splitk, 2, None) == 0
+        assert torch.equal(out, other)          # the item order changes which block computes a tile, not a single sum
 
 
 @pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1),
