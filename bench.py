@@ -61,11 +61,11 @@ def load_traffic():
     return t
 
 
-def cpu_baseline(sample_batch, cores, small=True):
+def cpu_baseline(sample_batch, cores, small=True, timed=2):
     """oracle/torch_port.py (PyTorch-CPU restatement of the reference step: same ATen conv/GroupNorm
-    kernels the reference's CPU path runs) timed on this box's host cores on a bounded sample: full
-    node/time/filter sizes, reduced batch; 2 untimed steps (lazy optimizer state, warm-up), then the mean of 3 timed full
-    training steps (fwd + bwd + grad-norm + AdamW)."""
+    kernels the reference's CPU path runs) timed on this box's host cores at the stated batch (batch 16,
+    full node/time/filter sizes): 1 untimed step (lazy optimizer state, allocator warm-up; its losses are the parity sample),
+    then the mean of `timed` full training steps (fwd + bwd + grad-norm + AdamW)."""
     import torch
     from simulgen_vae_amd.init import init_state, synthetic_eps, synthetic_samples
     from simulgen_vae_amd.spec import VAEConfig
@@ -75,12 +75,11 @@ def cpu_baseline(sample_batch, cores, small=True):
     m = TorchPortVAE(cfg, init_state(cfg, 7, reference_init=True))
     x = synthetic_samples(20251003, range(sample_batch), N_NODE, N_TIME)
     eps = synthetic_eps(1234, 0, cfg, sample_batch)
-    r0 = m.train_step(x, eps, ALPHA, 1e-4, LR)      # untimed: lazy optimizer state; its losses are the parity sample
-    m.train_step(x, eps, ALPHA, 1e-4, LR)           # warm-up
+    r0 = m.train_step(x, eps, ALPHA, 1e-4, LR)      # untimed: lazy optimizer state, warm-up; its losses are the parity sample
     t0 = time.time()
-    for _ in range(3):
+    for _ in range(timed):
         m.train_step(x, eps, ALPHA, 1e-4, LR)
-    dt = (time.time() - t0) / 3.0
+    dt = (time.time() - t0) / timed
     return sample_batch / dt, dt, r0, (x, eps)
 
 
@@ -209,7 +208,8 @@ def main():
                          "activations stay resident in the 288 GB HBM, so no recompute is needed)")
     ap.add_argument("--dataset", type=int, default=484, help="synthetic samples resident in HBM per rank")
     ap.add_argument("--cpu-baseline", default="auto", choices=["auto", "skip"])
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--cpu-sample-batch", type=int, default=16, help="batch of the timed CPU steps (BASELINE.md section 3 states 16)")
+    ap.add_argument("--cpu-timed-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--layer-times", action="store_true", help="print a per-layer GEMM table (stderr) after the run")
@@ -246,10 +246,11 @@ def main():
     t_init = time.time()
     eng.load_state(init_state(cfg, 7, reference_init=True))   # same seed on every rank -> identical replicas
     eng.set_option("write_xhat", 0)   # train.py:142 discards the reconstruction (`_`)
-    eng.seed(1234 + rank)
-    # synthetic dataset, generated on the device, converted to the engine's resident layout
+    eng.seed(1234)                     # ONE noise seed for the job; the draws are keyed by the global sample row (sgv_set_shard)
+    eng.set_shard(rank, world)
+    # synthetic dataset, generated on the device, converted to the engine's resident layout (replicated: same samples on every rank)
     P = args.dataset
-    gen = torch.Generator(device="cuda").manual_seed(20251003 + rank)
+    gen = torch.Generator(device="cuda").manual_seed(20251003)
     esz = 2 if args.dtype == "bf16" else 4
     data = torch.empty(P * N_NODE * N_TIME * esz, dtype=torch.uint8, device="cuda")
     chunk = 8
@@ -266,27 +267,36 @@ def main():
     ddp = world > 1 or (os.environ.get("SGV_FORCE_DDP") == "1" and dist.is_initialized())   # forced: plumbing test at N=1
     # bucketed mean all-reduce over RCCL, overlapped with backward and with AdamW (modules/train.py GradAllReduce)
     allreduce = make_allreduce(eng) if ddp else None
+    ddp_info = allreduce.info() if allreduce is not None else {"ddp_path": None, "rccl_nranks": None, "torch_world": world,
+                                                                "grad_payload": None, "buckets": eng.bucket_count(), "collectives_issued": False}
+    # which of the engine's auxiliary streams really run beside the main stream (hardware-queue probe): the lane
+    # and the weight-gradient side stream always exist; the optimizer / communication streams only on the data-parallel path
+    if ddp:
+        ddp_info["aux_streams_overlap"] = eng.stream_overlaps()
+    else:
+        so = eng.stream_overlaps_existing()
+        ddp_info["aux_streams_overlap"] = so
 
-    rng = random.Random(99 + rank)
-    nprng = np.random.RandomState(5 + rank)
+    rng = random.Random(99)              # the same stream on every rank: the GLOBAL batch is drawn, rank r keeps rows r::world
+    nprng = np.random.RandomState(5)
     epochs_beta = 1e-4   # WarmupKLLoss initial beta (train.py:75-81)
 
     def one_step(step_idx):
         # AugmentedDataset decisions (augmentation.py:58-84) drawn on the host, applied on the device
-        idx = [rng.randrange(P) for _ in range(B)]
-        seeds, scale, mix, lam = [], [], [], []
-        for b in range(B):
-            seeds.append(rng.getrandbits(63) | 1 if rng.random() < 0.5 else 0)
-            scale.append(0.9 + rng.random() * 0.2 if rng.random() < 0.5 else 1.0)
+        idx, seeds, scale, mix, lam = [], [], [], [], []
+        for g in range(B * world):
+            i_ = rng.randrange(P)
+            sd_ = rng.getrandbits(63) | 1 if rng.random() < 0.5 else 0
+            sc_ = 0.9 + rng.random() * 0.2 if rng.random() < 0.5 else 1.0
             if rng.random() < 0.5 and P > 1:
                 o = rng.randrange(P)
-                while o == idx[b]:
+                while o == i_:
                     o = rng.randrange(P)
-                mix.append(o)
-                lam.append(max(0.1, min(float(nprng.beta(0.2, 0.2)), 0.9)))
+                m_, l_ = o, max(0.1, min(float(nprng.beta(0.2, 0.2)), 0.9))
             else:
-                mix.append(-1)
-                lam.append(1.0)
+                m_, l_ = -1, 1.0
+            if g % world == rank:
+                idx.append(i_); seeds.append(sd_); scale.append(sc_); mix.append(m_); lam.append(l_)
         eng.augment_collate(data, idx, seeds, scale, mix, lam)
         eng.forward(train=True, sync=False)
         if ddp:
@@ -334,6 +344,7 @@ def main():
                              "parallelism": f"dp{world}", "losses_finite": finite},
                   "step_tflops": round((fwd + dx + dw) / (ms * 1e-3) / 1e12, 2),
                   "roofline": roof}
+        result["config"].update(ddp_info)
     # per-kernel durations (hipEvents on the engine's stream around each GEMM's main kernel), outside the timed region
     if not args.no_kernel_timing:
         eng.kernel_time_reset(2)
@@ -415,16 +426,15 @@ def main():
             except Exception:
                 pass
             cores = min(cores, args.cpu_threads)   # a 1-GPU box's CPU share is 16 cores; 256 torch threads thrash
-            v, dt, r, (cx, ceps) = cpu_baseline(args.cpu_sample_batch, cores, args.size == "small")
+            v, dt, r, (cx, ceps) = cpu_baseline(args.cpu_sample_batch, cores, args.size == "small", args.cpu_timed_steps)
             # parity beside the timing: the engine's ELBO on the very batch / weights the CPU port just ran (first step)
             e_elbo = engine_elbo(args.dtype, args.size == "small", cx, ceps)
             result["elbo_rel_vs_cpu_port"] = float(abs(e_elbo - r["loss"]) / abs(r["loss"]))
             result["cpu_baseline"] = {"value": round(v, 4), "unit": "samples/s", "cores": cores, "kind": "port",
-                                      "sample": f"oracle/torch_port.py (PyTorch-CPU fp32 port of the reference step), 2 warm-up + mean of 3 timed "
-                                                f"full training steps (fwd+bwd+grad-norm+AdamW) at full N=95008/T=200/filters "
-                                                f"with batch {args.cpu_sample_batch} ({dt:.1f}s; weight-sized passes are not "
-                                                f"amortised at this batch); the reference itself measured in the survey "
-                                                f"container: 0.564 samples/s on 8 cores at batch 16"}
+                                      "sample": f"oracle/torch_port.py (PyTorch-CPU fp32 port of the reference step), 1 warm-up + mean of "
+                                                f"{args.cpu_timed_steps} timed full training steps (fwd+bwd+grad-norm+AdamW) at full "
+                                                f"N=95008/T=200/filters with batch {args.cpu_sample_batch} ({dt:.1f} s per step); the "
+                                                f"reference itself measured in the survey container: 0.564 samples/s on 8 cores at batch 16"}
         else:
             result["cpu_baseline"] = None
         print(json.dumps(result), flush=True)

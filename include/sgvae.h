@@ -102,6 +102,11 @@ int sgv_set_input(sgv_engine* e, const float* x_dev, int batch);
  * engine draws it from its Philox stream (sgv_seed). */
 int sgv_set_eps(sgv_engine* e, int site, const float* eps_dev, int batch);
 int sgv_seed(sgv_engine* e, uint64_t seed);
+/* Data-parallel noise ("Philox streams keyed by global sample index so results are world-size-invariant"): sample b
+ * of this engine's batch is sample b * world + rank of the global batch (shards are r::world of the shuffled index list).  The
+ * engine's own draws then take the Philox counters of that global row, so N ranks with the SAME seed and B / N samples each draw
+ * exactly the noise one rank draws for B samples.  Default (0, 1). */
+int sgv_set_shard(sgv_engine* e, int rank, int world);
 /* Engine switches: "write_xhat" (materialise the reconstruction in training forwards; default 1),
  * "use_tr" (weight-gradient GEMM reads LDS with ds_read_b64_tr_b16; default 1), "dw_side_stream" (small weight-gradient
  * GEMMs on a second stream; default 1), "vendor_gemm" (A/B comparator: plain one-tap bf16 GEMMs go to hipBLASLt when
@@ -162,6 +167,14 @@ int sgv_scale_grads(sgv_engine* e, float factor);
  *    sgv_adamw_step updates every layer whose bucket has arrived while the last (first-encoder-layer) bucket is in flight;
  *    sgv_backward_step = sgv_backward + that sgv_adamw_step.  Mutually exclusive with sgv_set_bucket_callback. */
 int sgv_rccl_unique_id(void* id128);
+/* Local checks a host runs BEFORE it enters any collective step of the set-up, so that every rank can agree (through its own
+ * process group) on the path it takes: sgv_rccl_probe resolves librccl and its entry points in this process (no communication);
+ * sgv_rccl_comm_count = ncclCommCount of a communicator made by sgv_rccl_comm_init (what the bench line reports as rccl_nranks). */
+int sgv_rccl_probe(void);
+int sgv_rccl_comm_count(void* comm, int* nranks);
+/* In-place mean all-reduce (ncclAvg) of `count` fp32 / bf16 elements on `stream`: the host's first collective on a new
+ * communicator (a bounded self-test before the first training step), and a building block for hosts without an RCCL binding. */
+int sgv_rccl_allreduce(void* comm, void* dev_buf, size_t count, int dtype, void* stream);
 int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank);
 int sgv_rccl_comm_destroy(void* comm);
 int sgv_allreduce_grads(sgv_engine* e, void* rccl_comm, void* comm_stream);
@@ -311,6 +324,12 @@ int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M,
  * gradient side stream, 2 optimizer stream, 3 the engine's communication stream; 2 and 3 are created by the call if need be) can run
  * while a kernel of the engine stream is running, i.e. the two do not share a hardware queue; -1 if the engine has no such stream. */
 int sgv_test_stream_overlap(sgv_engine* e, int which, int* overlaps);
+/* Test double for the collective of the engine-issued data-parallel step (sgv_set_rccl with any non-null communicator handle):
+ * k != 0 replaces ncclAllReduce by "multiply the range in place by k on the given stream" (fp32 and bf16 ranges; no RCCL is
+ * loaded or called), k == 0 restores the library.  With k a power of two a step through the double must leave bitwise the
+ * state of a plain step at (k alpha, k beta) if and only if every gradient element and every <G,W> slot went through exactly
+ * one collective.  *calls / *elems return (and reset) the number of collectives and of elements since the last call. */
+int sgv_test_fake_collective(float k, long* calls, long* elems);
 
 #ifdef __cplusplus
 }

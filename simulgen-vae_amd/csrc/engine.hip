@@ -161,6 +161,7 @@ struct sgv_engine {
     // the last chunk's exchange is exposed (engine-issued path; SGV_DDP_LAST_CHUNKS=1 turns it off).  Two chunks: 512 rows keep the
     // GEMM's 128 x 256 tiles at whole rounds of the chip, four chunks of 256 rows cost 27 % of the GEMM
     int ddp_last_chunks = getenv("SGV_DDP_LAST_CHUNKS") ? atoi(getenv("SGV_DDP_LAST_CHUNKS")) : 2;
+    double ddp_chunk_min_gf = getenv("SGV_DDP_CHUNK_MIN_GF") ? atof(getenv("SGV_DDP_CHUNK_MIN_GF")) : 250.0;   // tests lower it to chunk a small first layer
     int dw_chunks = 1, dw_chunk_layer = -1;
     std::function<int(int, int, int, int)> dw_chunk_hook;        // (chunk, chunks, first row, end row) after the chunk's GEMM is enqueued
     // bf16 wire format: the conv-weight AdamW reads a packed bucket straight from the averaged bf16 copy (no unpack pass; the fp32
@@ -212,6 +213,7 @@ struct sgv_engine {
     std::vector<FinDot> fin_dots; std::vector<FinAffine> fin_affine;
     int dot_counts[512];
     uint64_t seed = 0x5347564145ull, draw = 0;
+    int shard_rank = 0, shard_world = 1;        // sgv_set_shard: sample b of this engine's batch is sample b * world + rank of the global batch
     long step = 0;
     float scalars_host[SGV_MAX_SCALARS];
     sgv_bucket_cb cb = nullptr; void* cb_user = nullptr;
@@ -1640,6 +1642,12 @@ int sgv_set_eps(sgv_engine* e, int site, const float* eps_dev, int batch) {
     return SGV_OK;
 }
 
+int sgv_set_shard(sgv_engine* e, int rank, int world) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (world < 1 || rank < 0 || rank >= world) return fail(SGV_ERR_ARG, "bad shard %d of %d", rank, world);
+    e->shard_rank = rank; e->shard_world = world;
+    return SGV_OK;
+}
 int sgv_seed(sgv_engine* e, uint64_t seed) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
     e->seed = seed; e->draw = 0;
@@ -1687,7 +1695,7 @@ static int decoder_fwd(sgv_engine* e, int B, int train, int mode_fix) {
     const int n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;
     for (int s = 1; s < n_st; ++s) {
-        if (!e->eps_set[s]) ew_randn(e->eps[s], M * e->dec[s], e->seed, (e->draw++) * 8 + s, e->stream);
+        if (!e->eps_set[s]) ew_randn(e->eps[s], M * e->dec[s], e->seed, (e->draw++) * 8 + s, e->stream, (long)e->T * e->dec[s], e->shard_world, e->shard_rank);
     }
     {
         const Layer& l = e->layers[e->start_lin];
@@ -1771,7 +1779,7 @@ int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
     HIPCHK(hipMemsetAsync(e->scal, 0, 16 * 8, e->stream));
     CHK(run_sn(e, train));
     CHK(encoder_fwd(e, B, false));
-    if (!e->eps_set[0]) ew_randn(e->eps[0], (long)B * e->Z, e->seed, (e->draw++) * 8, e->stream);
+    if (!e->eps_set[0]) ew_randn(e->eps[0], (long)B * e->Z, e->seed, (e->draw++) * 8, e->stream, e->Z, e->shard_world, e->shard_rank);
     ew_latent_fwd(e->last, e->eps[0], e->zlat, B, e->Z, e->scal + 2, e->stream);
     CHK(decoder_fwd(e, B, train, mode_fix));
     e->have_fwd = true;
@@ -1846,6 +1854,14 @@ int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t coun
         return export_act(e, e->x_in, B, host);
     }
     if (!e->have_fwd) return fail(SGV_ERR_STATE, "no forward pass to read from");
+    if (s.rfind("eps", 0) == 0 && s.size() == 4) {      // the noise of the last forward: eps0 [B][latent], eps{i} [B*T][C_i] (channels-last rows)
+        const int site = s[3] - '0';
+        if (site < 0 || site >= e->n_st) return fail(SGV_ERR_NAME, "bad noise site");
+        const long want = site == 0 ? (long)B * e->Z : (long)B * e->T * e->dec[site];
+        if ((long)count != want) return fail(SGV_ERR_ARG, "size mismatch for activation '%s': got %zu expected %ld", name, count, want);
+        HIPCHK(hipMemcpy(host, e->eps[site], count * 4, hipMemcpyDeviceToHost));
+        return SGV_OK;
+    }
     auto chk = [&](long want) { return (long)count == want ? 0 : fail(SGV_ERR_ARG, "size mismatch for activation '%s': got %zu expected %ld", name, count, want); };
     auto idx = [&](const char* pre) { return atoi(s.c_str() + strlen(pre)); };
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1979,6 +1995,13 @@ int sgv_rccl_comm_init(void** comm_out, int nranks, const void* id128, int rank)
     if (!rc) g_comm_ranks[*comm_out] = nranks;
     return rc ? rccl_fail("ncclCommInitRank", rc) : SGV_OK;
 }
+int sgv_rccl_allreduce(void* comm, void* dev_buf, size_t count, int dtype, void* stream) {
+    if (!comm || !dev_buf) return fail(SGV_ERR_ARG, "null argument");
+    if (dtype != SGV_DTYPE_F32 && dtype != SGV_DTYPE_BF16) return fail(SGV_ERR_ARG, "bad dtype");
+    CHK(rccl_load());
+    const int rc = g_rccl.AllReduce(dev_buf, dev_buf, count, dtype == SGV_DTYPE_BF16 ? kNcclBfloat16 : kNcclFloat32, kNcclAvg, comm, (hipStream_t)stream);
+    return rc ? rccl_fail("ncclAllReduce", rc) : SGV_OK;
+}
 int sgv_rccl_comm_destroy(void* comm) {
     if (!comm) return SGV_OK;
     CHK(rccl_load());
@@ -2091,7 +2114,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
         last_chunked = e->encA[0].st.size() == 1 && L0.k == 1 && L0.has_grad && layer_fused_adam(L0) && L0.cout % (128 * e->ddp_last_chunks) == 0 &&
                        e->buckets[last_b].first == L0.gw && e->buckets[last_b].second == align_up((size_t)L0.nw(), 4) &&
                        e->tile_off[last_b + 1] - e->tile_off[last_b] == rt6 * ct6 && e->flat_off[last_b + 1] == e->flat_off[last_b] &&
-                       2.0e-9 * (double)((long)e->batch * e->T) * L0.cout * L0.cin > 250.0;      // the big-GEMM regime: main stream, split-K 1
+                       2.0e-9 * (double)((long)e->batch * e->T) * L0.cout * L0.cin > e->ddp_chunk_min_gf;      // the big-GEMM regime: main stream, split-K 1
     }
     const int B = e->batch, n = e->n, n_st = e->n_st;
     const long M = (long)B * e->T;

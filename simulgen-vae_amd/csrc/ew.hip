@@ -1327,22 +1327,28 @@ int ew_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int B
     return 0;
 }
 
-// standard normals into an fp32 buffer (Philox keyed by seed/stream; element i <- block i/4)
-__global__ __launch_bounds__(256) void randn_kernel(float* out, long n, uint64_t seed, uint64_t stream) {
+// standard normals into an fp32 buffer [rows][per_row] (Philox keyed by seed/stream).  Row b is sample b of this rank's batch =
+// sample b * world + rank of the GLOBAL batch (shards are r::world), and its elements take the counters
+// (global row) * per_row + j: a world of N ranks with B / N samples each draws exactly the noise one rank draws for B samples.
+// per_row % 4 == 0 (one Philox block makes 4 normals); world = 1, rank = 0: element i <- block i / 4 as before.
+__global__ __launch_bounds__(256) void randn_kernel(float* out, long n, long per_row, int world, int rank, uint64_t seed, uint64_t stream) {
     const long n4 = (n + 3) / 4;
     for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+        const long e0 = i * 4;
+        const long b = e0 / per_row, j = e0 - b * per_row;
         float r[4];
-        philox_normal4(seed, stream, (uint64_t)i, r);
+        philox_normal4(seed, stream, (uint64_t)(((b * world + rank) * per_row + j) >> 2), r);
 #pragma unroll
         for (int e = 0; e < 4; ++e)
-            if (i * 4 + e < n) out[i * 4 + e] = r[e];
+            if (e0 + e < n) out[e0 + e] = r[e];
     }
 }
-int ew_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t s) {
+int ew_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t s, long per_row, int world, int rank) {
+    if (per_row <= 0 || per_row % 4 || world < 1) { per_row = n > 0 ? ((n + 3) / 4) * 4 : 4; world = 1; rank = 0; }
     int blocks = cdiv_i((n + 3) / 4, 256);
     if (blocks > 4096) blocks = 4096;
     if (blocks < 1) blocks = 1;
-    hipLaunchKernelGGL(randn_kernel, dim3(blocks), dim3(256), 0, s, out, n, seed, stream);
+    hipLaunchKernelGGL(randn_kernel, dim3(blocks), dim3(256), 0, s, out, n, per_row, world, rank, seed, stream);
     return 0;
 }
 

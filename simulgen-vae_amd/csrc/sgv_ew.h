@@ -112,7 +112,7 @@ int ew_add3(int dtype, const void* a, long lda, const void* b, long ldb, const v
             int rows, int C, hipStream_t s);
 int ew_transpose(int src_dtype, int dst_dtype, const void* src, void* dst, int Bn, int I, int J, long lds_, long ldd,
                  long sbatch, long dbatch, hipStream_t s);
-int ew_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t s);
+int ew_randn(float* out, long n, uint64_t seed, uint64_t stream, hipStream_t s, long per_row = 0, int world = 1, int rank = 0);
 int ew_latent_fwd(const float* last, const float* eps, float* z, int B, int Z, double* kl_sum, hipStream_t s);
 int ew_latent_bwd(const float* last, const float* eps, const float* dz, float* dlast, int B, int Z, float coef, hipStream_t s);
 int ew_stage_fwd(int dtype, const float* pz, const float* qz, const float* eps, const void* dec_out, long ldd,

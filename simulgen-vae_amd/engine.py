@@ -24,13 +24,13 @@ DTYPES = {"f32": 0, "fp32": 0, "float32": 0, "bf16": 1, "bfloat16": 1}
 ABI_SYMBOLS = [
     "sgv_last_error", "sgv_create", "sgv_destroy", "sgv_param_count", "sgv_param_info", "sgv_load_state",
     "sgv_export_state", "sgv_export_grad", "sgv_export_adam", "sgv_prepare", "sgv_set_input", "sgv_set_eps",
-    "sgv_seed", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
+    "sgv_seed", "sgv_set_shard", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
     "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_wire_stream", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
-    "sgv_rccl_unique_id", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
-    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_lib", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap",
+    "sgv_rccl_unique_id", "sgv_rccl_probe", "sgv_rccl_comm_count", "sgv_rccl_allreduce", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
+    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_lib", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_fake_collective",
 ]
 
 
@@ -73,6 +73,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_set_input.argtypes = [vp, vp, i32]
     lib.sgv_set_eps.argtypes = [vp, i32, vp, i32]
     lib.sgv_seed.argtypes = [vp, C.c_uint64]
+    lib.sgv_set_shard.argtypes = [vp, i32, i32]
     lib.sgv_set_option.argtypes = [vp, C.c_char_p, i32]
     lib.sgv_forward.argtypes = [vp, i32, i32, vp]
     lib.sgv_encode.argtypes = [vp, vp, vp, vp]
@@ -99,6 +100,11 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_rccl_unique_id.argtypes = [vp]
     lib.sgv_rccl_comm_init.argtypes = [C.POINTER(vp), i32, vp, i32]
     lib.sgv_rccl_comm_destroy.argtypes = [vp]
+    lib.sgv_rccl_probe.argtypes = []
+    lib.sgv_rccl_comm_count.argtypes = [vp, C.POINTER(i32)]
+    lib.sgv_rccl_allreduce.argtypes = [vp, vp, C.c_size_t, i32, vp]
+    lib.sgv_test_fake_collective.argtypes = [f32, C.POINTER(C.c_long), C.POINTER(C.c_long)]
+    lib.sgv_test_stream_overlap.argtypes = [vp, i32, C.POINTER(i32)]
     lib.sgv_allreduce_grads.argtypes = [vp, vp, vp]
     lib.sgv_set_rccl.argtypes = [vp, vp, vp]
     lib.sgv_last_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
@@ -231,6 +237,11 @@ class Engine:
 
     def seed(self, seed: int):
         _check(self.lib, self.lib.sgv_seed(self.h, C.c_uint64(seed)), "sgv_seed")
+
+    def set_shard(self, rank: int, world: int):
+        """Sample b of this engine's batch is sample b * world + rank of the global batch: the engine's noise draws are keyed by
+        that global row (include/sgvae.h: sgv_set_shard), so the same seed on every rank gives world-size-invariant noise."""
+        _check(self.lib, self.lib.sgv_set_shard(self.h, int(rank), int(world)), "sgv_set_shard")
 
     def set_input(self, x):
         """x: torch float32 CUDA tensor [B, num_node, num_time] (reference layout)."""
@@ -393,6 +404,26 @@ class Engine:
         """Register an RCCL communicator (sgv_rccl_comm_init) + communication stream: backward() then issues the bucket
         all-reduces itself and adamw_step() / backward_step() wait for them bucket by bucket.  comm=None unregisters."""
         _check(self.lib, self.lib.sgv_set_rccl(self.h, C.c_void_p(comm), C.c_void_p(comm_stream) if comm else None), "sgv_set_rccl")
+
+    def stream_overlaps(self):
+        """Probe results for the engine's auxiliary streams (second lane, weight-gradient side stream, optimizer stream,
+        communication stream): 1 = its kernels run beside the main stream's, 0 = it shares the main stream's hardware queue (the
+        overlap it exists for is lost), -1 = the stream does not exist.  Creates the optimizer / communication streams."""
+        out = {}
+        for which, name in enumerate(("lane", "side", "opt", "comm")):
+            v = C.c_int(-2)
+            _check(self.lib, self.lib.sgv_test_stream_overlap(self.h, which, C.byref(v)), "sgv_test_stream_overlap")
+            out[name] = v.value
+        return out
+
+    def stream_overlaps_existing(self):
+        """stream_overlaps() for the streams a single-GPU engine has (lane, side) -- creates nothing."""
+        out = {}
+        for which, name in enumerate(("lane", "side")):
+            v = C.c_int(-2)
+            _check(self.lib, self.lib.sgv_test_stream_overlap(self.h, which, C.byref(v)), "sgv_test_stream_overlap")
+            out[name] = v.value
+        return out
 
     def allreduce_grads(self, comm, comm_stream=None):
         """Mean all-reduce of the whole gradient arena (stream-ordered, not overlapped)."""

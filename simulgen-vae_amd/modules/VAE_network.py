@@ -4,7 +4,7 @@
   VAE(latent_dim, hierarchical_dim, num_filter_enc, num_filter_dec, num_node, num_time,
       lossfun='MSE', batch_size=1, small=False, use_checkpointing=False)
   .forward(x) / __call__(x) -> (x_hat, recon_loss, [kl, kl2_0, ...], recon_loss_MSE)
-  .encoder(x) -> (mu, log_var, xs) ; .decoder(z, xs, mode="random"|"fix") -> (x_hat, kl_list)
+  .encoder(x) -> (mu, log_var, xs) ; .decoder(z, xs, mode="random"|"fix", freeze_level=-1) -> (x_hat, kl_list)
   .state_dict() / .load_state_dict() with the reference's key names, .train()/.eval(), .to(),
   .compile_model(mode) (no-op: there is no tracing compiler here), picklable.
 Differences a caller can observe: tensors returned are detached (gradients live inside the engine and
@@ -27,12 +27,15 @@ class VAE:
                              num_time, lossfun, bool(small))
         self.latent_dim = latent_dim
         self.lossfun = self.cfg.lossfun
-        # The reference accepts the flag and forces it to False (VAE_network.py:60,68: no recompute exists in its code).  False is
-        # accepted here; True is refused loudly rather than silently ignored: the engine keeps every activation resident
-        # (large model, batch 16, full size: see DESIGN.md section 12 for the measured bytes against the 288 GB of one MI355X)
+        # The reference accepts the flag and forces it to False (VAE_network.py:60,68: no recompute exists in its code), so a caller
+        # that passes True runs there without recompute.  Same here: accepted, forced to False, with a warning that says where
+        # the memory went instead (every activation of a step stays resident: large model, batch 16, full size = 14.3 GiB of the
+        # 288 GB of one MI355X)
         if use_checkpointing:
-            raise NotImplementedError("use_checkpointing=True: activation recompute is not implemented; all activations of a step stay "
-                                      "resident in HBM (Engine.memory_info() reports the bytes); pass use_checkpointing=False")
+            import warnings
+            warnings.warn("use_checkpointing=True is accepted and ignored, as in the reference (modules/VAE_network.py:68 forces it to "
+                          "False): the engine keeps every activation of a step resident in HBM; Engine.memory_info() reports the bytes",
+                          stacklevel=2)
         self.use_checkpointing = False
         self.batch_size = int(batch_size)
         self.compute_dtype = compute_dtype
@@ -81,7 +84,11 @@ class VAE:
         return self
 
     def parameters(self):
-        return iter(())
+        """nn.Module.parameters(): the trainable tensors (weight_orig / weight / bias entries of the state_dict, in its order) as
+        detached copies -- enough for the reference's uses that only count or inspect them (torchinfo-style summaries,
+        `sum(p.numel() for p in model.parameters())`); gradients and the optimizer live inside the engine."""
+        sd = self.state_dict()
+        return iter([v for k, v in sd.items() if not (k.endswith("weight_u") or k.endswith("weight_v"))])
 
     # ---- state ----
     def state_dict(self):
@@ -141,8 +148,22 @@ class VAE:
         return t(mu), t(lv), [t(v) for v in xs]
 
     def _decode(self, z, xs=None, mode="random", freeze_level=-1):
+        """Decoder.forward(z, xs, mode, freeze_level) (modules/decoder.py:170-216).  Two corners of that signature are refused
+        rather than silently computed differently:
+          * xs=None: the reference then never replaces z, so stage 1 adds the [B, latent] vector to a [B, C, T] map
+            (decoder.py:179) -- a broadcasting RuntimeError for every size the path is used at (latent 32, T 200); no caller
+            does it.  RuntimeError here too.
+          * freeze_level >= 1 with mode="fix": the reference re-uses latents it stored on the module in EARLIER calls
+            (decoder.py:202-207, `self.zs`, read at index i+1) -- state that survives across calls and batches; no caller passes
+            it (utils.py:499, latent_conditioner_e2e.py:371, reconstruction_evaluator.py:174 all use the default -1).
+            NotImplementedError instead of ignoring the argument.  freeze_level <= 0 is the plain path in the reference as well
+            (`i < freeze_level` is never true)."""
         if xs is None:
-            raise SgvError("decoder(z, xs=None) is not supported by the engine")
+            raise RuntimeError("decoder(z, xs=None): the reference adds the [B, latent] vector to a [B, C, T] map in this case "
+                               "(modules/decoder.py:179) and fails; pass the encoder's xs")
+        if mode == "fix" and freeze_level is not None and freeze_level >= 1:
+            raise NotImplementedError("decoder(..., mode='fix', freeze_level >= 1): the reference's cross-call latent cache "
+                                      "(modules/decoder.py:202-207) is not reproduced; use the default freeze_level=-1")
         eng = self._eng(z.shape[0])
         kls = eng.decode(self._prep(z), [self._prep(v) for v in xs], fix=(mode == "fix"))
         return eng.xhat(), [torch.tensor(k, device="cuda") for k in kls]

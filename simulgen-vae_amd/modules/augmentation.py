@@ -23,26 +23,31 @@ class AugmentedDataset(Dataset):
         }
         self.training = True
 
-    def plan(self, index):
+    def plan(self, index, key=None):
         """The random draws of AugmentedDataset._apply_augmentations (augmentation.py:58-84) in the
         reference's order: python `random` for decisions/scale, numpy for the mixup lambda.  Returns
-        (noise_seed, scale, mix_index, lam); noise itself is drawn on the device (Philox)."""
+        (noise_seed, scale, mix_index, lam); noise itself is drawn on the device (Philox).
+        key = None: the process-global streams, as the reference (single process).  key = an integer: generators of their own
+        seeded with it -- the data-parallel loaders pass (job seed, epoch, position in the global shuffled list), so a sample's
+        augmentation does not depend on how many ranks the list is dealt to."""
         cfg = self.augmentation_config
         if not cfg["enabled"] or not self.training:
             return 0, 1.0, -1, 1.0
-        seed = (random.getrandbits(62) | 1) if random.random() < cfg["noise_prob"] else 0
+        rnd = random if key is None else random.Random(key)
+        seed = (rnd.getrandbits(62) | 1) if rnd.random() < cfg["noise_prob"] else 0
         scale = 1.0
-        if random.random() < cfg["scaling_prob"]:
+        if rnd.random() < cfg["scaling_prob"]:
             lo, hi = cfg["scaling_range"]
-            scale = lo + random.random() * (hi - lo)
-        random.random()  # shift draw (probability 0)
+            scale = lo + rnd.random() * (hi - lo)
+        rnd.random()  # shift draw (probability 0)
         mix, lam = -1, 1.0
-        if random.random() < cfg["mixup_prob"] and len(self) > 1:
-            mix = random.randint(0, len(self) - 1)
+        if rnd.random() < cfg["mixup_prob"] and len(self) > 1:
+            mix = rnd.randint(0, len(self) - 1)
             while mix == index:
-                mix = random.randint(0, len(self) - 1)
-            lam = max(0.1, min(float(np.random.beta(cfg["mixup_alpha"], cfg["mixup_alpha"])), 0.9))
-        random.random()  # cutout draw (probability 0)
+                mix = rnd.randint(0, len(self) - 1)
+            beta = np.random.beta if key is None else np.random.RandomState(key & 0xFFFFFFFF).beta
+            lam = max(0.1, min(float(beta(cfg["mixup_alpha"], cfg["mixup_alpha"])), 0.9))
+        rnd.random()  # cutout draw (probability 0)
         return seed, scale, mix, lam
 
     def __getitem__(self, index):
@@ -99,11 +104,17 @@ class ResidentLoader:
 
     def batch_plans(self):
         idx = self._epoch_indices()
+        epoch = self.epoch - 1
         for i in range(0, len(idx), self.batch_size):
             b = idx[i:i + self.batch_size]
             was = self.dataset.augmentation_config["enabled"]
             self.dataset.augmentation_config["enabled"] = was and self.augment
-            plans = [self.dataset.plan(j) for j in b]
+            if self.shuffle_seed is not None:
+                # keyed by the position in the GLOBAL shuffled list (local position k of rank r is k * world + r): world-size-invariant
+                keys = [(self.shuffle_seed * 1000003 + epoch) * 2147483647 + (i + k) * self.world + self.rank for k in range(len(b))]
+                plans = [self.dataset.plan(j, key) for j, key in zip(b, keys)]
+            else:
+                plans = [self.dataset.plan(j) for j in b]
             self.dataset.augmentation_config["enabled"] = was
             yield b, [p[0] for p in plans], [p[1] for p in plans], [p[2] for p in plans], [p[3] for p in plans]
 

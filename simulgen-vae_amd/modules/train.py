@@ -147,6 +147,10 @@ class GradAllReduce:
         if not self.single:
             engine.set_bucket_callback(self._on_bucket)        # one rank: nothing to exchange, the engine keeps its single-GPU schedule
 
+    def info(self):
+        return {"ddp_path": "torch", "rccl_nranks": None, "torch_world": dist.get_world_size(self.group),
+                "grad_payload": "bf16" if self.flat_lp is not None else "f32", "buckets": self.nb, "collectives_issued": not self.single}
+
     def backward_step(self, engine, alpha, beta, lr):
         """backward + gradient exchange + AdamW.  One rank: the engine's fused step (optimizer overlapped under backward), exactly
         the single-GPU path; several ranks: backward with bucket callbacks, then the bucket-ordered optimizer."""
@@ -218,36 +222,125 @@ class GradAllReduce:
         self.pending.clear()
 
 
+class _Watchdog:
+    """Bounded wait around a blocking collective set-up step: if it has not been cancelled after `seconds`, print the reason and
+    end the PROCESS with status 3 (a fresh process may retry; a process that has touched the GPU is never re-executed).  The
+    launcher (torchrun) then takes the other ranks down, so a rank stuck inside ncclCommInitRank because a peer failed does not
+    hang the job."""
+
+    def __init__(self, seconds, what, rank):
+        import threading
+
+        def fire():
+            import sys
+            sys.stderr.write(f"[sgvae] rank {rank}: {what} did not finish within {seconds:.0f} s (SGV_DDP_INIT_TIMEOUT): a peer "
+                             f"failed or the fabric is unreachable; exiting with status 3\n")
+            sys.stderr.flush()
+            os._exit(3)
+        self.t = threading.Timer(seconds, fire)
+        self.t.daemon = True
+        self.t.start()
+
+    def cancel(self):
+        self.t.cancel()
+
+
+def ddp_init_timeout():
+    return float(os.environ.get("SGV_DDP_INIT_TIMEOUT", "180"))
+
+
 class NativeAllReduce:
     """The same data-parallel step with the collective issued by the engine itself (include/sgvae.h: sgv_set_rccl): an
     RCCL communicator of the library's own (unique id from rank 0, broadcast over the existing torch.distributed group),
     a dedicated communication stream, bucket all-reduces launched from inside sgv_backward without a host callback, and
-    sgv_adamw_step ordering the waits (first-encoder-layer bucket last).  Opt-in: SGV_DDP_NATIVE=1."""
+    sgv_adamw_step ordering the waits (first-encoder-layer bucket last).  The default on an RCCL group (make_allreduce);
+    SGV_DDP_NATIVE=0 / 1 forces the torch.distributed path / this one.
 
-    def __init__(self, engine, group=None):
-        import ctypes as C
-        self.engine, lib = engine, engine.lib
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
-        ident = (C.c_char * 128)()
-        if rank == 0:
-            if lib.sgv_rccl_unique_id(ident) != 0:
-                raise RuntimeError(lib.sgv_last_error().decode())
-        t = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8).clone()
-        dev = t.cuda() if dist.get_backend(group) == "nccl" else t
-        dist.broadcast(dev, src=0, group=group)
-        ident = (C.c_char * 128).from_buffer_copy(bytes(dev.cpu().numpy().tobytes()))
-        comm = C.c_void_p()
-        if lib.sgv_rccl_comm_init(C.byref(comm), world, ident, rank) != 0:
-            raise RuntimeError(lib.sgv_last_error().decode())
-        self.comm = comm.value
+    Set-up is `NativeAllReduce.create`: every step that could leave the ranks in different collectives is preceded by an
+    agreement over the torch.distributed group, so either all ranks end up with a communicator or all fall back together:
+      1. local probe (sgv_rccl_probe: dlopen + dlsym, no communication) -> MIN all-reduce of the flag;
+      2. rank 0 draws the unique id and broadcasts a status byte WITH it (a failure on rank 0 reaches every rank);
+      3. ncclCommInitRank + one 8-element mean all-reduce on the new communicator under a watchdog (_Watchdog: a rank whose
+         peer failed inside the collective init cannot agree on anything any more -- it exits non-zero after the timeout);
+      4. MIN all-reduce of the local result."""
+
+    def __init__(self, engine, comm, world, group=None):
+        self.engine, self.comm, self.world = engine, comm, world
         forced = os.environ.get("SGV_FORCE_COLLECTIVE") == "1"     # one-GPU rehearsal of the N > 1 path (see GradAllReduce)
         self.single = world == 1 and not forced
+        self.payload = "f32"
         if not self.single and grad_payload_dtype(engine) == "bf16":
             engine.set_grad_payload("bf16")      # the engine packs, all-reduces the bf16 copy and unpacks by itself
+            self.payload = "bf16"
         # the engine's own communication stream: probed so that it never shares a hardware queue with the main stream
         self.stream = torch.cuda.ExternalStream(engine.comm_stream())
         if not self.single:
             engine.set_rccl(self.comm, self.stream.cuda_stream)      # one rank: nothing to exchange, single-GPU schedule
+
+    @classmethod
+    def create(cls, engine, group=None):
+        """(NativeAllReduce, None) on every rank, or (None, reason) on every rank."""
+        import ctypes as C
+        lib = engine.lib
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        cuda = dist.get_backend(group) == "nccl"
+        dev = "cuda" if cuda else "cpu"
+
+        def agree(ok):
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+            return int(t.item()) == 1
+        # 1. can every rank resolve RCCL at all?
+        local = lib.sgv_rccl_probe() == 0
+        why = None if local else lib.sgv_last_error().decode()
+        if not agree(local):
+            return None, why or "librccl could not be resolved on another rank"
+        # 2. unique id + status byte from rank 0
+        msg = torch.zeros(129, dtype=torch.uint8)
+        if rank == 0:
+            ident = (C.c_char * 128)()
+            if lib.sgv_rccl_unique_id(ident) == 0:
+                msg[0] = 1
+                msg[1:] = torch.frombuffer(bytearray(ident.raw), dtype=torch.uint8)
+            else:
+                why = lib.sgv_last_error().decode()
+        msg = msg.to(dev)
+        dist.broadcast(msg, src=0, group=group)
+        msg = msg.cpu()
+        if int(msg[0]) != 1:
+            return None, why or "rank 0 could not create the RCCL unique id"
+        ident = (C.c_char * 128).from_buffer_copy(bytes(msg[1:].numpy().tobytes()))
+        # 3. collective init + first collective, bounded
+        comm = C.c_void_p()
+        dog = _Watchdog(ddp_init_timeout(), "ncclCommInitRank / the first all-reduce of the engine's communicator", rank)
+        ok = lib.sgv_rccl_comm_init(C.byref(comm), world, ident, rank) == 0
+        if not ok:
+            why = lib.sgv_last_error().decode()
+        else:
+            probe = torch.full((8,), float(rank + 1), dtype=torch.float32, device="cuda")
+            st = torch.cuda.current_stream()
+            ok = lib.sgv_rccl_allreduce(comm, C.c_void_p(probe.data_ptr()), 8, 0, C.c_void_p(st.cuda_stream)) == 0
+            if ok:
+                st.synchronize()
+                ok = bool(torch.allclose(probe.cpu(), torch.full((8,), (world + 1) / 2.0)))
+                if not ok:
+                    why = f"the first all-reduce returned {probe.cpu().tolist()[:2]}, expected {(world + 1) / 2.0}"
+            else:
+                why = lib.sgv_last_error().decode()
+        dog.cancel()
+        # 4. agree on the result
+        if not agree(ok):
+            if comm.value:
+                lib.sgv_rccl_comm_destroy(comm)
+            return None, why or "communicator set-up failed on another rank"
+        return cls(engine, comm.value, world, group), None
+
+    def info(self):
+        import ctypes as C
+        n = C.c_int(-1)
+        self.engine.lib.sgv_rccl_comm_count(C.c_void_p(self.comm), C.byref(n))
+        return {"ddp_path": "native", "rccl_nranks": int(n.value), "torch_world": self.world, "grad_payload": self.payload,
+                "buckets": self.engine.bucket_count(), "collectives_issued": not self.single}
 
     def backward_step(self, engine, alpha, beta, lr):
         # one rank: the single-GPU schedule.  Several: sgv_backward_step on a registered communicator -- the engine averages every
@@ -293,26 +386,18 @@ def broadcast_replica_state(engine, group=None, src=0):
 def make_allreduce(engine, group=None):
     """The data-parallel step's gradient exchange.  On an RCCL (`nccl`) group the engine issues the collectives itself
     (NativeAllReduce: its own communicator on a communication stream it placed on a hardware queue away from the main stream's,
-    every bucket updated on that queue right behind its all-reduce); if ANY rank fails to set that up, every rank falls back
-    to GradAllReduce (torch.distributed issues the bucket collectives from the engine's callbacks), which is also what other
-    backends get.  SGV_DDP_NATIVE=1 / 0 forces one or the other."""
+    every bucket updated on that queue right behind its all-reduce); if the set-up fails in a way the ranks can still agree on
+    (NativeAllReduce.create), every rank falls back to GradAllReduce (torch.distributed issues the bucket collectives from the
+    engine's callbacks), which is also what other backends get.  SGV_DDP_NATIVE=1 / 0 forces one or the other."""
     want = os.environ.get("SGV_DDP_NATIVE", "")
     if want == "0" or (want != "1" and dist.get_backend(group) != "nccl"):
         return GradAllReduce(engine, group)
-    if want == "1":
-        return NativeAllReduce(engine, group)
-    ar, err = None, None
-    try:
-        ar = NativeAllReduce(engine, group)
-    except Exception as ex:       # noqa: BLE001 -- whatever went wrong, all ranks must agree on the path they take
-        err = ex
-    ok = torch.tensor([0 if ar is None else 1], dtype=torch.int32, device="cuda")
-    dist.all_reduce(ok, op=dist.ReduceOp.MIN, group=group)
-    if int(ok.item()) == 1:
-        return ar
+    ar, why = NativeAllReduce.create(engine, group)
     if ar is not None:
-        ar.close()
-    logging.warning("engine-issued RCCL path unavailable on some rank (%s): torch.distributed issues the bucket collectives", err)
+        return ar
+    if want == "1":
+        raise RuntimeError(f"SGV_DDP_NATIVE=1 but the engine-issued RCCL path is unavailable: {why}")
+    logging.warning("engine-issued RCCL path unavailable (%s): torch.distributed issues the bucket collectives on every rank", why)
     return GradAllReduce(engine, group)
 
 
@@ -334,7 +419,10 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
     warmup_kl = WarmupKLLoss(epochs, 1e-4, int(epochs * 0.3), int(epochs * 0.8), 1)   # init_beta hard-coded
     allreduce = make_allreduce(eng) if world > 1 else None
     if world > 1:
-        eng.seed(broadcast_replica_state(eng) + rank)      # identical replicas, rank-distinct reparameterisation / noise streams
+        # identical replicas, ONE noise seed for the job: the engine keys its draws by the global sample row (sgv_set_shard), so
+        # 8 x 16 samples see the noise 1 x 128 would
+        eng.seed(broadcast_replica_state(eng))
+        eng.set_shard(rank, world)
     fused = hasattr(train_dataloader, "batch_plans")
     data = train_dataloader.resident(eng) if fused else None
 

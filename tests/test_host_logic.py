@@ -292,11 +292,58 @@ def test_e2e_cosine_schedule_and_latent_scaler(tmp_path):
         latent_conditioner_scaler(np.zeros((0, 4)), str(tmp_path / "c.pkl"))
 
 
-def test_use_checkpointing_true_is_refused_loudly():
-    """The reference forces use_checkpointing to False (VAE_network.py:60,68); the mirror accepts False and refuses True instead
-    of silently ignoring it (no recompute path exists: every activation stays resident)."""
+def test_use_checkpointing_true_is_accepted_and_forced_off_like_the_reference():
+    """The reference accepts use_checkpointing and forces it to False (VAE_network.py:60,68); the mirror does the same and says
+    so (no recompute path exists: every activation stays resident)."""
     from simulgen_vae_amd.modules.VAE_network import VAE
     enc = [32, 16, 8, 8]
-    VAE(32, 8, enc, enc[::-1], 72, 10, use_checkpointing=False)
-    with pytest.raises(NotImplementedError, match="recompute"):
-        VAE(32, 8, enc, enc[::-1], 72, 10, use_checkpointing=True)
+    assert VAE(32, 8, enc, enc[::-1], 72, 10, use_checkpointing=False).use_checkpointing is False
+    with pytest.warns(UserWarning, match="accepted and ignored"):
+        m = VAE(32, 8, enc, enc[::-1], 72, 10, use_checkpointing=True)
+    assert m.use_checkpointing is False
+    # nn.Module.parameters(): the trainable tensors (no spectral-norm u / v buffers), e.g. for a parameter count
+    n = sum(p.numel() for p in m.parameters())
+    sd = m.state_dict()
+    assert n == sum(v.numel() for k, v in sd.items() if not k.endswith(("weight_u", "weight_v"))) and n > 0
+
+
+def test_decoder_signature_corners_are_refused_not_ignored():
+    """decoder(z, xs=None) fails in the reference (broadcast of [B, latent] onto [B, C, T], decoder.py:179) and raises here;
+    freeze_level >= 1 with mode='fix' (a cross-call latent cache, decoder.py:202-207) raises NotImplementedError instead of being
+    dropped; neither needs a GPU to be refused."""
+    import torch
+    from simulgen_vae_amd.modules.VAE_network import VAE
+    enc = [32, 16, 8, 8]
+    m = VAE(32, 8, enc, enc[::-1], 72, 10)
+    z = torch.zeros(2, 32)
+    with pytest.raises(RuntimeError, match="xs=None"):
+        m.decoder(z, None)
+    with pytest.raises(NotImplementedError, match="freeze_level"):
+        m.decoder(z, [torch.zeros(2, 8)] * 3, mode="fix", freeze_level=1)
+
+
+def test_keyed_augmentation_plans_do_not_depend_on_the_world_size():
+    """SURVEY 8(e): augmentation keyed by the position in the global shuffled list.  Two ranks' loaders (r::2 shards) must plan,
+    for every global position, exactly what a one-rank loader with the same job seed plans -- sample index, noise seed, scale,
+    mixup partner and lambda -- whatever the process-global random streams hold."""
+    import random
+    from simulgen_vae_amd.modules.augmentation import AugmentedDataset, ResidentLoader
+    x = np.zeros((40, 6, 4), np.float32)
+    idx = list(range(37))
+    def plans(rank, world, bs, seed_global):
+        random.seed(seed_global); np.random.seed(seed_global)
+        ld = ResidentLoader(AugmentedDataset(x, False), idx, bs, shuffle=True, augment=True, rank=rank, world=world, shuffle_seed=4242)
+        out = []
+        for _ in range(2):
+            out.append([list(zip(*item)) for item in ld.batch_plans()])
+        return out
+    one = plans(0, 1, 8, 1)
+    r0, r1 = plans(0, 2, 4, 77), plans(1, 2, 4, 999)
+    for e in range(2):
+        flat1 = [p for batch in one[e] for p in batch]
+        f0 = [p for batch in r0[e] for p in batch]
+        f1 = [p for batch in r1[e] for p in batch]
+        assert len(f0) == len(f1) == 18               # 37 // 2 per rank (drop-last to equal shards)
+        for k in range(18):
+            assert f0[k] == flat1[2 * k] and f1[k] == flat1[2 * k + 1], (e, k)
+        assert any(p[1] for p in f0) and any(p[3] >= 0 for p in f0)      # noise seeds and mixup partners do occur

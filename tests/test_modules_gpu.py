@@ -270,7 +270,7 @@ def test_native_rccl_path_equals_plain_step():
             eng = Engine(cfg, max_batch=B, compute_dtype="f32")
             eng.load_state(state)
             eng.seed(99)
-            ar = NativeAllReduce(eng) if mode != "plain" else None
+            ar = NativeAllReduce.create(eng)[0] if mode != "plain" else None
             if ar is not None:
                 # a one-rank NativeAllReduce leaves the engine on its single-GPU schedule (nothing to exchange); register the
                 # communicator by hand so that the engine's own bucket / event / wait plumbing is what runs here
@@ -465,7 +465,7 @@ def test_one_rank_forced_collectives_through_rccl(monkeypatch, path, payload):
                 assert not ar.single and (ar.flat_lp is not None) == (payload == "bf16")
                 assert (ar.wire is not None) == (os.environ.get("SGV_DDP_WIRE") == "1")
             elif mode == "native":
-                ar = NativeAllReduce(eng)
+                ar = NativeAllReduce.create(eng)[0]
                 assert not ar.single
             ranges = []
             if mode == "expect":
@@ -528,6 +528,8 @@ def test_make_allreduce_picks_the_engine_issued_path_and_falls_back_together(mon
         x = torch.from_numpy(synthetic_samples(5, range(2), cfg.num_node, cfg.num_time)).cuda()
         ar = T.make_allreduce(eng)
         assert isinstance(ar, T.NativeAllReduce) and ar.stream.cuda_stream == eng.comm_stream()
+        info = ar.info()
+        assert info["ddp_path"] == "native" and info["rccl_nranks"] == 1 and info["torch_world"] == 1 and info["buckets"] == eng.bucket_count()
         eng.set_input(x); eng.forward(train=True); ar.backward_step(eng, 1e6, 1e-4, 1e-3)
         assert np.isfinite(eng.last_grad_norm())
         ar.close()
@@ -535,18 +537,87 @@ def test_make_allreduce_picks_the_engine_issued_path_and_falls_back_together(mon
         assert isinstance(T.make_allreduce(eng), T.GradAllReduce)
         monkeypatch.delenv("SGV_DDP_NATIVE")
 
-        class Broken:
-            def __init__(self, *a, **k):
-                raise RuntimeError("no RCCL here")
-        monkeypatch.setattr(T, "NativeAllReduce", Broken)
+        # the set-up failing in a way the ranks agree on (NativeAllReduce.create returns (None, reason) everywhere)
+        monkeypatch.setattr(T.NativeAllReduce, "create", classmethod(lambda cls, e, g=None: (None, "no RCCL here")))
         ar = T.make_allreduce(eng)
         assert isinstance(ar, T.GradAllReduce)
+        assert ar.info()["ddp_path"] == "torch"
+        monkeypatch.setenv("SGV_DDP_NATIVE", "1")
+        with pytest.raises(RuntimeError, match="no RCCL here"):
+            T.make_allreduce(eng)
+        monkeypatch.delenv("SGV_DDP_NATIVE")
         eng.set_input(x); eng.forward(train=True); ar.backward_step(eng, 1e6, 1e-4, 1e-3)
         assert np.isfinite(eng.last_grad_norm())
         eng.close()
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("chunks", [2, 1])
+@pytest.mark.parametrize("early", [1, 0])
+@pytest.mark.parametrize("payload", ["f32", "bf16"])
+def test_engine_issued_collectives_cover_every_gradient_exactly_once(payload, early, chunks, monkeypatch):
+    """N > 1 correctness of the engine-issued data-parallel step without a second GPU.  A one-rank ncclAvg is the identity, so a
+    range that is never reduced -- or reduced twice -- cannot show in any one-rank run.  Here ncclAllReduce is replaced by a test
+    double that multiplies the range it is handed by k in place (sgv_test_fake_collective; fp32 and bf16 ranges): with k = 2 a step
+    at (alpha, beta) must leave BITWISE the state of a step with k = 1 at (2 alpha, 2 beta) -- backward is linear in (alpha, beta)
+    and a factor of two is exact in fp32 and bf16 -- iff every gradient element, every <G,W> slot and the small zone went through
+    exactly one collective before the update that reads it.  All modes of the path: fp32 / bf16 wire format, per-bucket updates
+    under backward on / off, the first layer's bucket exchanged in chunks of its weight-gradient GEMM / in one piece (preset
+    widths, N = 4096: the chunked exchange needs 1024 output channels)."""
+    import ctypes as C
+    from simulgen_vae_amd.engine import Engine, load_library
+    from simulgen_vae_amd.init import init_state
+    lib = load_library()
+    G2 = dict(latent_dim=32, hierarchical_dim=8, enc=[1024, 512, 256, 128], num_node=4096, num_time=32)     # preset widths (fixture g2's shape)
+    monkeypatch.setenv("SGV_GRAD_PAYLOAD", payload)
+    monkeypatch.setenv("SGV_DDP_LAST_CHUNKS", str(chunks))
+    monkeypatch.setenv("SGV_DDP_CHUNK_MIN_GF", "0")
+    cfg = make_cfg(G2)
+    B = 4
+    x = torch.from_numpy(synthetic_samples(5, range(B), cfg.num_node, cfg.num_time)).cuda()
+    state = init_state(cfg, 11, reference_init=True)
+    names = ["encoder.encoder_blocks.0.module_list.0._seq.0.weight_orig", "encoder.encoder_blocks.0.module_list.0._seq.0.bias",
+             "decoder.recon.0.weight_orig", "decoder.recon.1.weight", "decoder.decoder_residual_blocks.2.seq.3.weight_orig",
+             "decoder.decoder_residual_blocks.0.seq.0.weight_orig", "encoder.xs_linear.1.weight_orig", "encoder.encoder_blocks.2.module_list.0._seq.1.bias",
+             "decoder.condition_xz.0.2.weight_orig", "decoder.sequence_start.0.0.weight_orig"]
+    outs, counts = [], []
+    try:
+        for k, mult in ((2.0, 1.0), (1.0, 2.0)):
+            assert lib.sgv_test_fake_collective(k, None, None) == 0
+            eng = Engine(cfg, max_batch=B, compute_dtype="bf16")
+            eng.load_state(state)
+            eng.seed(99)
+            eng.set_option("ddp_early_adamw", early)
+            if payload == "bf16":
+                eng.set_grad_payload("bf16")
+            eng.set_rccl(0x5eed, eng.comm_stream())         # any non-null handle: the double never looks at it
+            norms = []
+            for step in range(2):
+                eng.set_input(x)
+                eng.forward(train=True)
+                eng.backward_step(1e6 * mult, 1e-4 * mult, 1e-3)
+                norms.append(eng.last_grad_norm())
+            torch.cuda.synchronize()
+            calls, elems = C.c_long(), C.c_long()
+            assert lib.sgv_test_fake_collective(k, C.byref(calls), C.byref(elems)) == 0
+            counts.append((calls.value, elems.value))
+            ptr, n = eng.grad_buffer()
+            sd = eng.state_dict()
+            outs.append((norms, {kk: sd[kk] for kk in sd if kk in names or kk.endswith("weight_u")}, n))
+            eng.set_rccl(None, None)
+            eng.close()
+    finally:
+        lib.sgv_test_fake_collective(0.0, None, None)
+    (na, sa, n_arena), (nb, sb, _) = outs
+    assert counts[0] == counts[1] and counts[0][0] > 0
+    # every arena element went into a collective exactly once per step (the arena is padded per bucket: >=)
+    assert counts[0][1] >= 2 * n_arena - 64 * 2 and counts[0][1] <= 2 * n_arena, (counts, n_arena)
+    assert na == nb, (na, nb)                       # gradient norm of (2 alpha, 2 beta) == norm of the doubled gradients, bitwise
+    assert set(names) <= set(sa)
+    for kk in sa:
+        assert np.array_equal(sa[kk], sb[kk]), kk
 
 
 def test_fused_backward_step_equals_separate_calls():
