@@ -109,8 +109,8 @@ int sgv_seed(sgv_engine* e, uint64_t seed);
 int sgv_set_shard(sgv_engine* e, int rank, int world);
 /* Engine switches: "write_xhat" (materialise the reconstruction in training forwards; default 1),
  * "use_tr" (weight-gradient GEMM reads LDS with ds_read_b64_tr_b16; default 1), "dw_side_stream" (small weight-gradient
- * GEMMs on a second stream; default 1), "vendor_gemm" (A/B comparator: plain one-tap bf16 GEMMs go to hipBLASLt when
- * libhipblaslt.so.1 can be loaded; default 0: every GEMM runs on the hand-written kernels), "deterministic" (default 1: no
+ * GEMMs on a second stream; default 1), "vendor_gemm" (removed in round 3: 0 is accepted, 1 is an error -- every GEMM
+ * runs on the hand-written kernels; the hipBLASLt comparator lives in tests/micro/vendor, outside this library), "deterministic" (default 1: no
  * floating-point atomics anywhere in the step), "lanes" (second compute lane for the posterior branch of a decoder stage and
  * the xs heads; schedule only, results are bitwise the same; default 1), "fused_stages" (small Conv1d -> GroupNorm -> GELU
  * stages in one launch, csrc/convgn.hip; default 1, 0: GEMM + split-K combine + GroupNorm kernels). */
@@ -282,11 +282,6 @@ int sgv_kernel_time_tag(sgv_engine* e, int index, char* name, size_t cap, float*
 int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const float* bias, const float* scale,
                      const void* addend, int M, int N, int K, int taps, int Tlen, int splitk, int out_f32,
                      void* stream);
-/* The hipBLASLt path of plain one-tap bf16 GEMMs (csrc/vendor.hip): C[M][N] = (*scale or 1) * A[M][K] W[N][K]^T + bias
- * (+ addend[M][N], bf16), bf16 out.  SGV_ERR_ARG for shapes the engine would not hand to the library, SGV_ERR_STATE when
- * libhipblaslt.so.1 cannot be loaded. */
-int sgv_test_gemm_nt_lib(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
-                         int K, void* stream);
 /* bf16 128x128 kernel with the GroupNorm-statistics epilogue: sums[(m / Tlen) * (N / Cg) + n / Cg][2] += (sum, sum of squares)
  * of the stored outputs; sums must be zeroed by the caller.  Rejected unless Tlen >= 128, Cg >= 128 and the shape runs on the
  * 128x128 kernel (fewer than 64 K-steps of 32, or N < 256). */

@@ -1350,37 +1350,10 @@ int sgv_op_gemm_nt(int dtype, const void* A, const void* W, void* C, const float
     p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N;
     p.addend = addend; p.ldadd = N; p.bias = bias; p.scale = scale;
     p.M = M; p.N = N; p.K = K; p.taps = 1; p.pad = 0; p.Tlen = M; p.splitk = 1; p.out_f32 = out_f32;
-    // library path (csrc/vendor.hip) for the shapes it wins; its device-side scale is a vector: N copies of *scale in a
-    // per-stream scratch buffer, written by one small kernel in front of the GEMM
-    static const int lib_on = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 0;   // comparator only (tests/micro)
-    if (lib_on && dtype == 1 && !out_f32) {
-        p.vendor = 1;
-        if (scale) {
-            static std::mutex mu;
-            static std::map<hipStream_t, std::pair<float*, int>> scratch;
-            std::lock_guard<std::mutex> lk(mu);
-            auto& sc = scratch[ST(stream)];
-            if (sc.second < N) {
-                if (sc.first) hipFree(sc.first);
-                sc.second = 0;
-                if (hipMalloc((void**)&sc.first, sizeof(float) * (size_t)std::max(N, 4096)) == hipSuccess) sc.second = std::max(N, 4096);
-            }
-            if (sc.second >= N) p.scale_vec = sc.first;
-        }
-        if (gemm_nt_vendor_eligible(dtype, p)) {
-            if (p.scale_vec) ew_fill_from_scalar(const_cast<float*>(p.scale_vec), scale, N, ST(stream));
-        } else {
-            p.vendor = 0; p.scale_vec = nullptr;
-        }
-    }
-    int r;
-    if (p.vendor) r = launch_gemm_nt(dtype, p, ST(stream));
-    else {
-        // the engine's kernel choice (gemm256.hip): 256x256 persistent kernel for the big products, 128-row kernels otherwise;
-        // this stateless entry point has no split-K workspace, so every plan is split-K 1
-        const GemmPlan pl = gemm_nt_plan(dtype, p, 0, 0);
-        r = launch_gemm_nt_planned(dtype, p, pl, ST(stream));
-    }
+    // the engine's kernel choice (gemm256.hip): 256x256 persistent kernel for the big products, 128-row kernels otherwise;
+    // this stateless entry point has no split-K workspace, so every plan is split-K 1
+    const GemmPlan pl = gemm_nt_plan(dtype, p, 0, 0);
+    const int r = launch_gemm_nt_planned(dtype, p, pl, ST(stream));
     if (r) return sgv_set_error(-1, "sgv_op_gemm_nt: launch rejected (%d) for M=%d N=%d K=%d", r, M, N, K);
     return 0;
 }

@@ -67,7 +67,6 @@ struct Layer {
     size_t w = NPOS, b = NPOS, u = NPOS, v = NPOS;  // param arena (floats)
     size_t gw = NPOS, gb = NPOS, gdot = NPOS;       // grad arena (floats); gdot: <G,W_eff> scalar (small zone)
     size_t wc = NPOS, wct = NPOS;                   // compute-copy arena (elements)
-    size_t alpha = NPOS;                            // [max(cin, cout)] copies of 1/sigma for the library GEMM path (one-tap bf16 layers)
     int sn = -1;
     int splitk_tn = 1;
     size_t dot_part = NPOS;                         // per-block <G,W_eff> partials of the layer's dY kernel (e->red arena)
@@ -130,7 +129,6 @@ struct sgv_engine {
     std::vector<int> dot_off, fin_lin_off;           // [bucket] -> first Linear <G,W> work item / first fin_lin_dots entry (tables sorted by bucket)
     double* gnorm_part = nullptr; int n_gnorm_part = 0;   // per-work-item sums of squared gradients of the AdamW passes
     float* sn_sigma = nullptr;
-    float* sn_alpha = nullptr; size_t n_sn_alpha = 0;   // per-layer vectors of 1/sigma (Layer::alpha)
     float* sn_dot_dummy = nullptr;
     double* scal = nullptr;        // device doubles: [0..1] loss sums, [2] kl, [3..] kl2, [15] grad norm^2
     float* partial = nullptr; size_t partial_floats = 0;
@@ -195,7 +193,6 @@ struct sgv_engine {
     float *last = nullptr, *d_last = nullptr, *zlat = nullptr, *d_z = nullptr;
     int batch = 0;
     bool have_fwd = false, fwd_train = false, write_xhat = true, copies_fresh = false;
-    int vendor_gemm = getenv("SGV_VENDOR_GEMM") ? atoi(getenv("SGV_VENDOR_GEMM")) : 0;   // 1: plain one-tap GEMMs go to hipBLASLt (vendor.hip) -- comparator for tests/micro only; option "vendor_gemm"
     int deterministic = getenv("SGV_DETERMINISTIC") ? atoi(getenv("SGV_DETERMINISTIC")) : 1;   // 1: no float-atomic accumulation anywhere in the step; option "deterministic"
     float* gn_part = nullptr; size_t gn_part_floats = 0;   // per-(tile, wave) GroupNorm partial sums of the 256x256 GEMM epilogue
     // deterministic reductions: block partials that nobody needs before the optimizer (GroupNorm affine / bias gradients,
@@ -646,10 +643,6 @@ static int build_tables(sgv_engine* e) {
         if (l.need_wct) { l.wct = nc; nc = align_up(nc + (size_t)l.nw(), 8); }
     }
     e->n_copies = nc;
-    size_t na = 0;
-    for (auto& l : e->layers)
-        if (l.used && l.op != OP_LINEAR && l.k == 1 && e->dt == SGV_DTYPE_BF16) { l.alpha = na; na += align_up((size_t)std::max(l.cin, l.cout), 4); }
-    e->n_sn_alpha = na;
     // SN scratch
     size_t nt = 0;
     int si = 0;
@@ -694,7 +687,6 @@ static int upload_tables(sgv_engine* e) {
         d.dot = l.has_grad ? e->grads + l.gdot : e->sn_dot_dummy;
         d.G = l.has_grad ? e->grads + l.gw : nullptr;
         d.wc = (e->dt == SGV_DTYPE_BF16 && l.wc != NPOS && l.cin % 8 == 0) ? (const void*)(e->copies + l.wc * e->esz) : nullptr;
-        d.alpha_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr; d.alpha_n = l.alpha != NPOS ? std::max(l.cin, l.cout) : 0;
         d.taps = l.k; d.rows = l.cout; d.cols = l.cin; d.active = l.used ? 1 : 0;
         e->sn_host[i] = d;
         if (l.used) {
@@ -859,8 +851,6 @@ static void conv_fwd_params(sgv_engine* e, const Layer& l, const Tensor& x, cons
     p.bias = e->params + l.b;
     p.scale = e->sn_sigma + 2 * l.sn + 1;
     p.M = (int)M; p.N = l.cout; p.K = l.cin; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
-    p.vendor = e->vendor_gemm;
-    p.scale_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr;
     p.partial = e->partial;
 }
 // 0: separate statistics pass; 1: 128x128 kernel epilogue (fp64 atomics); 2: 256x256 kernel (deterministic)
@@ -868,7 +858,6 @@ static int conv_fwd_stats_mode(sgv_engine* e, const Layer& l, const Tensor& x, c
     if (y.f32 || e->dt != SGV_DTYPE_BF16) return 0;
     GemmNT q; conv_fwd_params(e, l, x, y, M, q);
     q.gn_Cg = Cg; q.gn_G = G;
-    if (q.vendor && l.alpha != NPOS && gemm_nt_vendor_eligible(e->dt, q)) return 0;   // library GEMM + a statistics pass
     const GemmPlan pl = gemm_nt_plan(e->dt, q, e->partial_floats, 1);
     if (pl.kind == 1 && pl.fuse_stats && gemm_nt256_part_floats((int)M, l.cout, 1) <= e->gn_part_floats) return 2;
     if (pl.kind == 0 && !e->deterministic && gemm_nt_can_fuse_stats(e->dt, (int)M, l.cout, l.cin, l.k, e->T, Cg)) return 1;
@@ -883,14 +872,6 @@ static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor
     const int smode = gn_sums ? conv_fwd_stats_mode(e, l, x, y, M, gn_Cg, gn_G) : 0;
     if (gn_sums && !smode) return fail(SGV_ERR_STATE, "conv_fwd: statistics requested from a GEMM that cannot produce them (%s)", l.prefix.c_str());
     p.gn_Cg = gn_Cg; p.gn_G = gn_G;
-    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
-    if (lib) {
-        p.splitk = 1;
-        ScopedTimer tm(e, "gemm_nt_lib", &l, p.M, p.N, p.K, p.taps, 1);
-        if (launch_gemm_nt(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "library gemm launch failed for %s", l.prefix.c_str());
-        return 0;
-    }
-    p.vendor = 0;
     GemmPlan pl = gemm_nt_plan(e->dt, p, e->partial_floats, smode == 2);
     if (smode == 2) { p.gn_sums = gn_sums; p.gn_part = e->gn_part; }
     else if (smode == 1) { p.gn_sums = gn_sums; }
@@ -908,17 +889,7 @@ static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     if (addend) { p.addend = addend->p; p.ldadd = addend->ld; }
     p.scale = e->sn_sigma + 2 * l.sn + 1;
     p.M = (int)M; p.N = l.cin; p.K = l.cout; p.taps = l.k; p.pad = (l.k - 1) / 2; p.Tlen = e->T;
-    p.vendor = e->vendor_gemm;
-    p.scale_vec = l.alpha != NPOS ? e->sn_alpha + l.alpha : nullptr;
     p.partial = e->partial;
-    const bool lib = p.vendor && gemm_nt_vendor_eligible(e->dt, p);
-    if (lib) {
-        p.splitk = 1;
-        ScopedTimer tm(e, "gemm_nt_lib", &l, p.M, p.N, p.K, p.taps, 1);
-        if (launch_gemm_nt(e->dt, p, e->stream)) return fail(SGV_ERR_ARG, "library gemm(dX) launch failed for %s", l.prefix.c_str());
-        return 0;
-    }
-    p.vendor = 0;
     const GemmPlan pl = gemm_nt_plan(e->dt, p, e->partial_floats, 0);
     ScopedTimer tm(e, pl.kind ? "gemm_nt_t256" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, pl.sk_main);
     int r = launch_gemm_nt_planned(e->dt, p, pl, e->stream);
@@ -1385,7 +1356,6 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     ALLOC(e->stats, e->n_stats * 8);
     ALLOC(e->sn_tmp, e->n_sn_tmp * 4);
     ALLOC(e->sn_sigma, e->layers.size() * 2 * 4);
-    ALLOC(e->sn_alpha, std::max<size_t>(e->n_sn_alpha, 4) * 4);
     ALLOC(e->sn_dot_dummy, SGV_DOT_SLOTS * sizeof(float));
     ALLOC(e->scal, 32 * 8);
     ALLOC(e->partial, e->partial_floats * 4);
@@ -1426,15 +1396,15 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
 int sgv_destroy(sgv_engine* e) {
     if (!e) return SGV_OK;
     hipStreamSynchronize(e->stream);
-    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_alpha, e->sn_dot_dummy,
+    void* ptrs[] = {e->params, e->grads, e->adam_m, e->adam_v, e->copies, e->act, e->stats, e->sn_tmp, e->sn_sigma, e->sn_dot_dummy,
                     e->scal, e->partial, e->partial_tn, e->partial2, e->colpart2, e->gn_part2, e->gn_part, e->red, e->xpose_tmp, e->colpart, e->sn_dev, e->adam_dev, e->items_sn, e->items_dot, e->items_adam, e->items_copy, e->items_wct,
                     e->items_sn_unf, e->items_adam_flat, e->items_adam_2d, e->items_ts, e->items_ss, e->lin_dot_part, e->gnorm_part};
     for (void* p : ptrs) if (p) hipFree(p);
-    if (e->side) { hipStreamSynchronize(e->side); gemm_nt_vendor_release_stream(e->side); hipStreamDestroy(e->side); }
+    if (e->side) { hipStreamSynchronize(e->side); hipStreamDestroy(e->side); }
     if (e->opt) { hipStreamSynchronize(e->opt); hipStreamDestroy(e->opt); }
     if (e->wire) { hipStreamSynchronize(e->wire); hipStreamDestroy(e->wire); }
     if (e->comm_own) { hipStreamSynchronize(e->comm_own); hipStreamDestroy(e->comm_own); }
-    if (e->lane2) { hipStreamSynchronize(e->lane2); gemm_nt_vendor_release_stream(e->lane2); hipStreamDestroy(e->lane2); }
+    if (e->lane2) { hipStreamSynchronize(e->lane2); hipStreamDestroy(e->lane2); }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
     if (e->lane_join) hipEventDestroy(e->lane_join);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
@@ -1661,7 +1631,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     else if (!strcmp(key, "dw_side_stream")) e->use_side = value != 0 && e->side != nullptr;
     else if (!strcmp(key, "ddp_early_adamw")) e->ddp_early = value != 0;
     else if (!strcmp(key, "wire_stream")) e->use_wire = value != 0 && ensure_wire(e) != nullptr;
-    else if (!strcmp(key, "vendor_gemm")) e->vendor_gemm = value != 0;
+    else if (!strcmp(key, "vendor_gemm")) { if (value) return fail(SGV_ERR_ARG, "vendor_gemm: the library GEMM back end was removed from libsgvae.so (comparator: tests/micro/vendor)"); }
     else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
     else if (!strcmp(key, "lanes")) e->use_lanes = value != 0 && e->lane2 != nullptr;          // second compute lane (schedule only: results are bitwise the same)
     else if (!strcmp(key, "fused_stages")) e->use_convgn = value != 0;                          // csrc/convgn.hip kernels for the small Conv -> GroupNorm -> GELU stages
@@ -2686,28 +2656,6 @@ int sgv_test_gemm_nt(int dtype, const void* A, const void* W, void* C, const flo
     if (partial) hipFree(partial);
     if (r) return fail(SGV_ERR_ARG, "launch_gemm_nt rejected the arguments (%d)", r);
     if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm_nt failed: %s", hipGetErrorString(se));
-    return SGV_OK;
-}
-
-int sgv_test_gemm_nt_lib(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
-                         int K, void* stream) {
-    GemmNT p; memset(&p, 0, sizeof(p));
-    p.A = A; p.lda = K; p.W = W; p.ldw = K; p.w_tap_stride = (long)N * K; p.C = C; p.ldc = N; p.bias = bias; p.scale = scale;
-    p.addend = addend; p.ldadd = N;
-    p.M = M; p.N = N; p.K = K; p.taps = 1; p.Tlen = M; p.splitk = 1; p.vendor = 1;
-    float* vec = nullptr;
-    if (scale) {
-        HIPCHK(hipMalloc((void**)&vec, sizeof(float) * (size_t)N));
-        ew_fill_from_scalar(vec, scale, N, (hipStream_t)stream);
-        p.scale_vec = vec;
-    }
-    if (!gemm_nt_vendor_eligible(SGV_DTYPE_BF16, p)) { if (vec) hipFree(vec); return fail(SGV_ERR_ARG, "shape is not one the library path takes"); }
-    const int r = launch_gemm_nt_vendor(p, (hipStream_t)stream);
-    hipError_t se = hipStreamSynchronize((hipStream_t)stream);
-    if (vec) hipFree(vec);
-    if (r > 0) return fail(SGV_ERR_STATE, "hipBLASLt is not available (dlopen libhipblaslt.so.1) or has no algorithm for this shape");
-    if (r < 0) return fail(SGV_ERR_HIP, "hipblasLtMatmul failed");
-    if (se != hipSuccess) return fail(SGV_ERR_HIP, "gemm failed: %s", hipGetErrorString(se));
     return SGV_OK;
 }
 

@@ -1381,7 +1381,7 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
     const int Mr = p.M - p.row0;                                           // rows this launch computes
     const bool c2d = p.cv_kw > 0;
     // strided addend (add_W > 0): the staged bf16 epilogue of gemm_nt_kernel only
-    if (p.add_W > 0 && (!p.addend || dtype != 1 || p.splitk != 1 || p.out_f32 || p.add_H < 1 || p.M % (p.add_H * p.add_W) || p.vendor ||
+    if (p.add_W > 0 && (!p.addend || dtype != 1 || p.splitk != 1 || p.out_f32 || p.add_H < 1 || p.M % (p.add_H * p.add_W) ||
                         (!c2d && gemm_nt_is_wide(dtype, p.N, (long)p.taps * cdiv(p.K, 32)))))
         return -1;
     if (c2d) {
@@ -1390,13 +1390,6 @@ int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s) {
         // every output pixel's window may start outside the image but must not reach past it by more than the padding
         if ((p.cv_Ho - 1) * p.cv_S - p.cv_P >= p.cv_H || (p.cv_Wo - 1) * p.cv_S - p.cv_P >= p.cv_W) return -1;
         if (p.gn_sums || p.row0) return -1;
-    }
-    if (!c2d && p.vendor && !p.row0 && gemm_nt_vendor_eligible(dtype, p)) {
-        const int vr = launch_gemm_nt_vendor(p, s);
-        if (vr <= 0) {
-            if (main_done) hipEventRecord(main_done, s);
-            return vr;
-        }                                            // 1: library not available -> own kernel below
     }
     const long total_steps = (long)p.taps * cdiv(p.K, dtype == 1 ? 32 : 16);
     if (p.gn_sums && (dtype != 1 || gemm_nt_is_wide(dtype, p.N, total_steps) || p.splitk != 1 || p.out_f32 || p.Tlen < 128 ||

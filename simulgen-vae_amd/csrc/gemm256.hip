@@ -847,7 +847,6 @@ int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipSt
         return launch_gemm_nt(dtype, q, s);
     }
     GemmNT q = p;
-    q.vendor = 0;
     q.splitk = pl.sk_main;
     if (!pl.fuse_stats) { q.gn_part = nullptr; q.gn_sums = nullptr; }
     if (pl.kind == 1) return launch_gemm_nt256(q, s);
@@ -855,7 +854,7 @@ int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipSt
     int r = launch_gemm_nt256(q, s);
     if (r) return r;
     GemmNT t = p;
-    t.vendor = 0; t.gn_part = nullptr; t.gn_sums = nullptr;
+    t.gn_part = nullptr; t.gn_sums = nullptr;
     t.row0 = pl.m_main; t.splitk = pl.sk_tail;
     return launch_gemm_nt(dtype, t, s);
 }

@@ -171,10 +171,6 @@ __global__ __launch_bounds__(1024) void sn_norm_u_kernel(const SNDesc* descs, in
         sigma = (float)tot;
     }
     if (threadIdx.x == 0) { d.sigma[0] = sigma; d.sigma[1] = 1.0f / sigma; }
-    if (d.alpha_vec) {
-        const float inv = 1.0f / sigma;
-        for (int i = threadIdx.x; i < d.alpha_n; i += 1024) d.alpha_vec[i] = inv;
-    }
 }
 
 int opt_sn_power_iteration(const SNDesc* descs_dev, const WorkItem* items1, int n1, const WorkItem* items3, int n3,

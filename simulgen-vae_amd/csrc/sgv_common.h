@@ -142,8 +142,6 @@ struct GemmNT {
     // bf16 output, Tlen >= 128, gn_Cg >= 128; see gemm_nt_can_fuse_stats): gn_sums[(m / Tlen) * gn_G + n / gn_Cg][2] +=
     // (sum, sum of squares) of the stored (bf16-rounded) values, fp64 atomics into a zeroed buffer
     double* gn_sums; int gn_Cg, gn_G;
-    int vendor;                     // 1: hand eligible plain GEMMs (gemm_nt_vendor_eligible) to hipBLASLt (vendor.hip)
-    const float* scale_vec;         // >= N copies of *scale on the device (the library takes a device alpha only as a vector)
     // gemm256.hip (256x256 persistent kernel): deterministic GroupNorm statistics.  gn_part != null: every (work item, wave)
     // writes 8 floats (sum / sum of squares of all, of the rows of the next sample, of the columns of the next group, of
     // both) to gn_part[(item * 8 + wave) * 8 ..]; t256_stats_finalize then produces gn_sums in a fixed order (no atomics).
@@ -178,9 +176,6 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s);
 struct GemmPlan { int kind, sk_main, sk_tail, m_main, fuse_stats; };
 GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int want_stats);
 int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s);
-bool gemm_nt_vendor_eligible(int dtype, const GemmNT& p);
-int launch_gemm_nt_vendor(const GemmNT& p, hipStream_t s);   // 0 launched, 1 unavailable, < 0 error
-void gemm_nt_vendor_release_stream(hipStream_t s);
 bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);
 struct GemmTN {
     const void* A; long lda;        // dY [M][lda], N1 columns used

@@ -157,8 +157,6 @@ struct SNDesc {
     float* dot;        // [SGV_DOT_SLOTS] partial <G, W_eff> (lives in the gradient arena's small zone: all-reduced with it)
     const float* G;    // gradient wrt W_eff (null if the layer gets no gradient)
     const void* wc;    // bf16 copy of W in the same [taps][rows][cols] order (bf16 engines), or null: W v reads it instead of W
-    float* alpha_vec;  // optional [alpha_n]: filled with 1/sigma (the library GEMM path takes its device-side scale as a vector)
-    int alpha_n;
     int taps, rows, cols;
     int active;        // participates in this forward
 };

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_wire_stream", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_rccl_unique_id", "sgv_rccl_probe", "sgv_rccl_comm_count", "sgv_rccl_allreduce", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
-    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_lib", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_fake_collective",
+    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_fake_collective",
 ]
 
 
@@ -122,7 +122,6 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_scale_convert.argtypes = [i32, vp, vp, vp, vp, C.c_long, i32, vp]
     lib.sgv_kernel_time_tag.argtypes = [vp, i32, C.c_char_p, C.c_size_t, C.POINTER(f32), C.POINTER(i32)]
     lib.sgv_test_gemm_nt.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
-    lib.sgv_test_gemm_nt_lib.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, vp]
     lib.sgv_test_gemm_nt_stats.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.sgv_test_gemm_nt256.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
     lib.sgv_test_gemm_tn.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]

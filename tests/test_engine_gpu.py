@@ -159,6 +159,55 @@ def test_philox_eps_statistics():
     eng.close()
 
 
+def test_engine_noise_is_keyed_by_the_global_sample_row():
+    """"Philox streams keyed by global sample index so results are world-size-invariant".  Two engines that stand for
+    the ranks of a 2-way data-parallel run (same seed, sgv_set_shard(r, 2), rows r::2 of the batch) must draw, row for row and
+    BITWISE, the noise one engine draws for the whole batch -- at every noise site, for two consecutive steps -- and the mean of
+    their gradients must be the whole-batch gradient (fp32 compute: rounding only; the sums run in a different order, so this
+    part cannot be bitwise)."""
+    import torch
+    cfg = make_cfg(G1)
+    B, T = 4, cfg.num_time
+    dec = cfg.num_filter_dec
+    x = synthetic_samples(20251003, range(B), cfg.num_node, cfg.num_time)
+    state = init_state(cfg, 7)
+    names = [e.name for e in param_spec(cfg) if e.kind in ("bias", "weight_orig", "gn_weight", "gn_bias")]
+
+    def run(rows, rank, world):
+        eng = E.Engine(cfg, max_batch=len(rows), compute_dtype="f32")
+        eng.load_state(state)
+        eng.seed(4711)
+        eng.set_shard(rank, world)
+        out = []
+        for step in range(2):
+            eng.set_input(torch.from_numpy(np.ascontiguousarray(x[rows])).cuda())
+            eng.forward(train=True)
+            n = len(rows)
+            eps = [eng.activation("eps0", (n, cfg.latent_dim))] + [eng.activation(f"eps{i}", (n, T, dec[i])) for i in (1, 2)]
+            eng.backward(1e6, 1e-4)
+            grads = {k: eng.grad(k) for k in names}
+            out.append((eps, grads))
+            eng.load_state(state)          # same weights (and power-iteration vectors) for the next step: only the draw counter moves
+        eng.close()
+        return out
+    whole = run([0, 1, 2, 3], 0, 1)
+    r0, r1 = run([0, 2], 0, 2), run([1, 3], 1, 2)
+    for step in range(2):
+        for site in range(3):
+            w = whole[step][0][site]
+            assert np.array_equal(r0[step][0][site], w[[0, 2]]), (step, site)
+            assert np.array_equal(r1[step][0][site], w[[1, 3]]), (step, site)
+            assert np.abs(w).max() > 1.0 and not np.array_equal(w[0], w[1])
+        assert not np.array_equal(whole[0][0][0], whole[1][0][0])             # a new draw every step
+        for k in names:
+            gw = whole[step][1][k]
+            if gw is None:
+                assert r0[step][1][k] is None
+                continue
+            mean = 0.5 * (r0[step][1][k].astype(np.float64) + r1[step][1][k].astype(np.float64))
+            assert relerr(mean, gw) < 5e-5, (step, k, relerr(mean, gw))
+
+
 def test_augment_collate_matches_oracle():
     """A13: the fused noise/scale/mixup + collate kernel on the HBM-resident dataset vs oracle.augment_sample
     (augmentation.py:86-124).  Scale and mixup are exact arithmetic on the stored sample; the Gaussian noise comes from

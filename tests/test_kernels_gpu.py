@@ -1,6 +1,7 @@
 """Kernel-level parity: the two MFMA GEMMs against numpy on bf16-exact inputs (so the only
 difference is fp32 accumulation order).  Called through the C ABI (sgv_test_gemm_*)."""
 import ctypes as C
+import os
 
 import numpy as np
 import pytest
@@ -385,9 +386,17 @@ def test_gemm_nt_wide_stress(case):
                                   (3200, 512, 2560, False, True, True), (1600, 2560, 512, False, False, False),
                                   (3200, 128, 256, True, True, False)])
 def test_gemm_nt_library_path(case):
-    """csrc/vendor.hip (hipBLASLt for plain one-tap GEMMs): scale from a device scalar (handed over as a vector), fp32 bias
-    along N, optional bf16 residual addend, bf16 output -- against numpy and against the hand-written kernel on the same
-    operands (one fp32 result rounded to bf16 on both sides: equal up to summation order, a few one-ulp flips)."""
+    """The hand-written NT kernels against hipBLASLt on the same operands.  The library is a COMPARATOR only (round 3 took its
+    dispatch out of libsgvae.so: tests/micro/vendor/libsgvcmp.so, built by __graft_entry__.build()): scale from a device scalar
+    (handed over as a vector), fp32 bias along N, optional bf16 residual addend, bf16 output -- both against numpy, and against
+    each other (one fp32 result rounded to bf16 on both sides: equal up to summation order, a few one-ulp flips)."""
+    import ctypes
+    cmp_path = os.path.join(os.path.dirname(__file__), "micro", "vendor", "libsgvcmp.so")
+    if not os.path.exists(cmp_path):
+        pytest.skip("comparator library not built (make -C tests/micro/vendor)")
+    cmp_lib = ctypes.CDLL(cmp_path)
+    vp_ = ctypes.c_void_p
+    cmp_lib.sgv_cmp_gemm_nt_lib.argtypes = [vp_, vp_, vp_, vp_, vp_, vp_, ctypes.c_int, ctypes.c_int, ctypes.c_int, vp_]
     import torch
     lib = E.load_library()
     M, N, K, use_bias, use_scale, use_add = case
@@ -401,8 +410,10 @@ def test_gemm_nt_library_path(case):
     dscale = torch.tensor([0.37], dtype=torch.float32, device="cuda") if use_scale else None
     args = (dbias.data_ptr() if use_bias else None, dscale.data_ptr() if use_scale else None, dadd.data_ptr() if use_add else None)
     out = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
-    rc = lib.sgv_test_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), *args, M, N, K, None)
-    assert rc == 0, lib.sgv_last_error()
+    rc = cmp_lib.sgv_cmp_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), *args, M, N, K, None)
+    if rc == 2:
+        pytest.skip("libhipblaslt.so.1 not loadable or no algorithm for this shape")
+    assert rc == 0, rc
     ref = ref_conv_nt(A, W, bias if use_bias else None, 0.37 if use_scale else 1.0, add if use_add else None, 1, M)
     got = out.float().cpu().numpy()
     assert np.abs(got - ref).max() / np.abs(ref).max() < 8e-3
@@ -414,8 +425,8 @@ def test_gemm_nt_library_path(case):
         assert d.max() / np.abs(ref).max() < 1.6e-2 and d.mean() / np.abs(ref).mean() < 3e-3
     else:
         assert d.max() / np.abs(ref).max() < 8e-3 and d.mean() / np.abs(ref).mean() < 1e-4
-    # shapes the engine keeps on its own kernels are refused by the hook
-    assert lib.sgv_test_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, None, 64, 64, 64, None) != 0
+    # shapes round 1 kept on its own kernels are refused by the comparator
+    assert cmp_lib.sgv_cmp_gemm_nt_lib(dA.data_ptr(), dW.data_ptr(), out.data_ptr(), None, None, None, 64, 64, 64, None) == 1
 
 
 CONV_GN_CASES = [
