@@ -58,8 +58,9 @@ def _run(tag, dtype):
 
 
 # (per-tensor gradient norm, sampled entry / scale) against the reference's gradients: measured worst case per fixture x 2-3
-GRAD_BOUNDS = {("g2_preset_4096", "f32"): (2e-4, 2e-4), ("g3_fullsize_b2", "f32"): (2e-4, 2e-4),
-               ("g2_preset_4096", "bf16"): (3e-2, 0.25), ("g3_fullsize_b2", "bf16"): (3e-2, 0.25)}
+# (round 3, MI355X: f32 6.4e-7 / 3.9e-6 and 4.1e-6 / 9.7e-6; bf16 4.3e-3 / 4.1e-2 and 3.7e-3 / 2.3e-2)
+GRAD_BOUNDS = {("g2_preset_4096", "f32"): (5e-6, 2e-5), ("g3_fullsize_b2", "f32"): (2e-5, 4e-5),
+               ("g2_preset_4096", "bf16"): (1e-2, 8e-2), ("g3_fullsize_b2", "bf16"): (1e-2, 6e-2)}
 
 
 @pytest.mark.parametrize("tag", ["g2_preset_4096", "g3_fullsize_b2"])
