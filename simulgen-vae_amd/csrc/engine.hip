@@ -2754,7 +2754,7 @@ int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M,
                      int use_tr, void* stream) {
     GemmTN p; memset(&p, 0, sizeof(p));
     p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
-    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_w2 = use_tr == 2 ? 1 : use_tr == 3 ? 2 : 0;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_w2 = use_tr == 2 ? 1 : use_tr == 3 ? 2 : use_tr == 4 ? 3 : use_tr == 5 ? -1 : 0;
     float* partial = nullptr;
     const long nw = (long)taps * N1 * N2;
     if (p.splitk > 1) {

@@ -12,6 +12,7 @@
 // sample-boundary taps are zero-filled at chunk granularity.
 #include <math.h>
 #include <stdlib.h>
+#include <string.h>
 #include "sgv_common.h"
 
 // minimum waves per SIMD asked of the register allocator for the GEMM kernels: 3 (168 VGPRs; a dozen
@@ -1351,6 +1352,11 @@ bool gemm_tn_uses_w2(int dtype, int M, int N1, int N2, int Tlen) {
     return use_w2 && gemm_tn_w2_eligible(dtype, M, N1, N2, Tlen);
 }
 int gemm_tn_pick_splitk(int M, int N1, int N2, int taps, int dtype, int Tlen) {
+    {   // the 256 x 256 kernel takes the product whole (its items fill the chip without slices)
+        GemmTN q; memset(&q, 0, sizeof(q));
+        q.M = M; q.N1 = N1; q.N2 = N2; q.taps = taps; q.Tlen = Tlen; q.lda = N1; q.ldb = N2; q.ldo = N2;
+        if (Tlen > 0 && gemm_tn_uses_t256(dtype, q)) return 1;
+    }
     if (gemm_tn_uses_w2(dtype, M, N1, N2, Tlen))     // 128x256 tiles, two blocks per CU, 32-row stages
         return pick_splitk((long)cdiv(N1, 128) * cdiv(N2, 256) * taps, cdiv(M, 32), (double)taps * N1 * N2 * 4.0, 12, 512.0);
     const int kr = dtype == 1 ? 32 : 16;
@@ -1478,6 +1484,11 @@ int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s) {
         q.b_bytes = (((long)(p.M / (p.cv_Ho * p.cv_Wo)) * p.cv_H * p.cv_W - 1) * p.ldb + p.cv_C) * esz;
     }
     if (q.a_bytes >= 0x7FFFFFF0L || q.b_bytes >= 0x7FFFFFF0L) return -1;
+    if (!c2d && dtype == 1 && p.use_tr && p.force_w2 >= 0 && p.force_w2 != 1 && p.force_w2 != 2 &&
+        (p.force_w2 == 3 ? gemm_tn256_eligible(dtype, p) : gemm_tn_uses_t256(dtype, p))) {
+        const int r = launch_gemm_tn256(p, s);
+        if (r != -1) return r;                       // -1: shape refused after all (offset ranges): the kernels below take it
+    }
     if (c2d && p.use_tr && (gemm_tn_uses_w2(dtype, p.M, p.N1, p.N2, p.M) || (p.force_w2 && gemm_tn_w2_eligible(dtype, p.M, p.N1, p.N2, p.M)))) {
         dim3 gridw(tn_w2_schedule(q, cdiv(p.N1, 128), cdiv(p.N2, 256), 1));
         hipLaunchKernelGGL(gemm_tn_w2_kernel<true>, gridw, dim3(256), 0, s, q);

@@ -184,7 +184,8 @@ struct GemmTN {
     long out_tap_stride;
     long out_slab_stride;
     int M, N1, N2, taps, pad, Tlen, splitk, use_tr;
-    int force_w2;                   // tests: take gemm_tn_w2_kernel whenever the shape is eligible (ignores SGV_TN_W2); 2: and its persistent walk
+    int force_w2;                   // tests: take gemm_tn_w2_kernel whenever the shape is eligible (ignores SGV_TN_W2); 2: and its persistent walk;
+                                    // 3: the 256 x 256 kernel (gemm256tn.hip) whenever eligible; -1: never the 256 x 256 kernel
     long a_bytes, b_bytes;          // filled by launch_gemm_tn
     // virtual im2col operand (cv_kw > 0; weight gradient of a 2-D convolution without the im2col matrix): B is a channels-
     // last image batch [nb][cv_H][cv_W][ldb] with cv_C channels, reduction row m = output pixel (b, oh, ow) of a
@@ -196,6 +197,10 @@ struct GemmTN {
     int order, pt1, pt2;
 };
 
+// gemm256tn.hip: 256 x 256 persistent weight-gradient kernel (bf16; same GemmTN contract, fp32 output / split-K slabs)
+bool gemm_tn256_eligible(int dtype, const GemmTN& p);
+bool gemm_tn_uses_t256(int dtype, const GemmTN& p);       // the launcher's choice: enough items to fill the chip, >= 150 GFLOP
+int launch_gemm_tn256(const GemmTN& p, hipStream_t s);
 int launch_gemm_nt(int dtype, const GemmNT& p, hipStream_t s);
 int launch_gemm_tn(int dtype, const GemmTN& p, hipStream_t s);
 int gemm_nt_pick_splitk(int M, int N, int K, int taps, int dtype);

@@ -358,6 +358,55 @@ def test_gemm_tn_w2(case, persistent):
         assert torch.equal(out, other)          # the item order changes which block computes a tile, not a single sum
 
 
+TN256_CASES = [
+    # M, N1, N2, taps, Tlen, splitk -- eligible for the 256 x 256 weight-gradient kernel (bf16, M % 64 == 0, M >= 1024, widths >= 256, Tlen >= 64)
+    (1024, 256, 256, 1, 128, 1),       # one tile, 16 K-tiles
+    (1280, 520, 776, 3, 64, 1),        # ragged tiles, three taps, sample boundaries on K-tile edges
+    (3200, 512, 768, 5, 200, 1),       # five taps, sample boundaries inside the K-tiles and inside the DMA pieces
+    (3200, 1024, 512, 1, 200, 2),      # split-K slabs (25 K-tiles each)
+    (1600, 256, 95008, 1, 200, 1),     # the first encoder layer's width: 372 items on 256 workgroups, item transitions
+    (1600, 95008, 256, 1, 200, 1),     # the recon head's width on the row side
+    (2048, 768, 1280, 5, 128, 2),      # taps x slices
+    (1280, 2560, 2816, 5, 64, 1),      # 10 x 11 tiles x 5 taps = 550 items: several items per workgroup with taps
+    (3264, 264, 328, 3, 96, 1),        # M = 34 samples of 96: windows that neither start nor end on a K-tile edge
+]
+
+
+@pytest.mark.parametrize("case", TN256_CASES)
+def test_gemm_tn256(case):
+    """gemm_tn_t256_kernel (csrc/gemm256tn.hip: 256 x 256 tiles, persistent, transposed LDS reads, taps as work items) vs numpy on
+    bf16-exact inputs, 4x per shape (the counted-vmcnt / barrier pipeline must not race), and bitwise equal between launches."""
+    import torch
+    lib = E.load_library()
+    M, N1, N2, taps, Tlen, splitk = case
+    rng = np.random.default_rng(23)
+    dY = _bf16_round(rng.standard_normal((M, N1)).astype(np.float32))
+    X = _bf16_round(rng.standard_normal((M, N2)).astype(np.float32))
+    ddY, dX = _dev(dY, 1), _dev(X, 1)
+    ref = ref_conv_tn(dY, X, taps, Tlen)
+    scale = np.abs(ref).max()
+    first = None
+    for rep in range(4):
+        out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+        rc = lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk, 4, None)   # 4: force the 256 x 256 kernel
+        assert rc == 0, lib.sgv_last_error()
+        got = out.cpu().numpy()
+        assert np.isfinite(got).all(), (case, rep)
+        err = np.abs(got - ref).max() / scale
+        assert err < 2e-5, (case, rep, err)
+        if first is None:
+            first = got
+        else:
+            assert np.array_equal(first, got), (case, rep)
+    # shapes the kernel does not take are refused by the forced hook's launcher and fall to the 128 x 256 kernel: still correct
+    if M % 128 == 0:
+        out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+        Mh = M - 32            # not a multiple of 64
+        assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), Mh, N1, N2, taps, Tlen, 1, 4, None) == 0
+        r2 = ref_conv_tn(dY[:Mh], X[:Mh], taps, Tlen)
+        assert np.abs(out.cpu().numpy() - r2).max() / np.abs(r2).max() < 2e-5
+
+
 @pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1),
                                   (300, 296, 9008, 1, 100, 2), (256, 512, 4160, 1, 64, 1)])
 def test_gemm_nt_wide_stress(case):
