@@ -398,7 +398,7 @@ def main():
             result["roofline_gemm_nt_wide"] = roof_obj(
                 "gemm_nt_wide", "gemm_nt_wide64p_kernel (128x256 tiles, LDS-DMA ring: mid-size layers and the 128-row tails)", "same accounting")
             result["roofline_gemm_nt_128"] = roof_obj("gemm_nt", "gemm_nt_kernel (128x128 tiles: N < 256 or short K)", "same accounting")
-            result["roofline_gemm_tn"] = roof_obj("gemm_tn", "gemm_tn_w2_kernel (weight-gradient GEMM: 128x256 tiles, two blocks per CU; layers with fewer than 256 input channels on the 128x128 gemm_tn_kernel)", "same accounting; traffic sums both kernels")
+            result["roofline_gemm_tn"] = roof_obj("gemm_tn", "gemm_tn_t256_kernel + gemm_tn_w2_kernel (weight-gradient GEMMs: the four big ones on the persistent 256x256 kernel with transposed LDS reads, the rest on 128x256 tiles with two blocks per CU; layers with fewer than 256 input channels on the 128x128 gemm_tn_kernel)", "same accounting; traffic sums the kernels of the class")
     if args.layer_times and rank == 0 and world == 1:      # extra step on one rank only: never with collectives in the step
         eng.kernel_time_reset(2)
         one_step(20_000)

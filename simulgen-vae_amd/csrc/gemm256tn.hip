@@ -12,16 +12,20 @@
 // per section, the two row halves half a section out of phase, a persistent walk over an XCD-chunked item list with the DMA
 // stream running ahead across item boundaries -- and changes what the TN contraction needs:
 //  * the reduction index is the ROW index m of both operands, so a K-tile is 64 rows x 512 B of dY and of X exactly as they
-//    lie in memory.  LDS image of a K-tile: 8 slabs per operand, slab s = columns [32 s, 32 s + 32) of the tile as 64 k-rows
-//    x 64 B.  A DMA piece (1 KiB) is 16 k-rows of one slab; a quarter is four slabs = 16 pieces, two per wave.
+//    lie in memory.  LDS image of a K-tile: 4 slabs per operand, slab s = columns [64 s, 64 s + 64) of the tile as 64 k-rows
+//    x 128 B.  A DMA piece (1 KiB) is 8 k-rows of one slab = 8 whole cache lines (a first version with 32-column slabs moved
+//    half lines: twice the L2 requests per byte); a quarter is two slabs = 16 pieces, two per wave.  The quarters are whole
+//    slabs because the waves' column tiles are dealt accordingly: wave (g, wq) owns dY columns g*128 + [0, 128) (slab 2g in the
+//    first half of a K-tile's sections, slab 2g+1 in the second) and X columns wq*32 + [0, 32) and 128 + wq*32 + [0, 32) (the
+//    first pair of tiles from slabs 0-1, the second from slabs 2-3).
 //  * MFMA operands come from ds_read_b64_tr_b16 (a 16-lane group reads 4 k-rows x 32 B and returns each lane its column's 4
-//    values): two reads per operand.  Row r stores its two 32-byte halves swapped when bit 3 of r is set (the DMA applies it
-//    on the source side), so the 8 rows a half-instruction touches (r0..r0+3 and r0+8..r0+11) cover all 64 banks.
+//    values): two reads per operand.  Row r stores its four 32-byte pairs XOR-permuted by (bit 1 of r) | (bit 3 of r) << 1 (the
+//    DMA applies it on the source side), so the 8 rows a half-instruction touches (r0..r0+3 and r0+8..r0+11) cover all 64 banks.
 //  * taps are work items (each tap has its own output), the tap shift is a row shift of X folded into the DMA's scalar offset,
 //    and an X row whose tap leaves its sample's window is pushed out of the buffer range per lane (a lane owns one k-row of a
 //    piece), so it lands as zeros: no patch pass over LDS.
 //  * the first MFMA operand is the X fragment: a lane ends with four consecutive n2 of one row n1 = 16 bytes of fp32 output.
-// Item order: (slice, tile, tap) with tap fastest -- the taps of a tile read the same two panels -- and the row-tile index
+// Item order: (slice, tile, tap) with tap fastest -- the taps of a tile read the same two panels -- and the column-tile index
 // fastest among tiles, XCD-chunked.  Deterministic: split-K slices (over m) go to slabs summed in slice order by the caller.
 #include <math.h>
 #include <stdlib.h>
@@ -66,22 +70,24 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         const_cast<char*>(reinterpret_cast<const char*>(p.B)) - x_shift, 0, (int)(p.b_bytes + x_shift), 0x00020000);
 
     // ---------------- DMA roles ----------------
-    // a quarter = 4 slabs x 64 k-rows x 64 B = 16 pieces of 1 KiB (16 k-rows of a slab); wave w moves pieces 2w, 2w+1: slab
-    // (w >> 1) of the quarter, k-rows (w & 1) * 32 + {0, 16} + (lane >> 2); LDS slot lane & 3 (16 B) of the row holds the
-    // source chunk of 32-byte half (slot >> 1) ^ bit 3 of the row.
-    const int dq = wave >> 1, kb = (wave & 1) * 32;
-    const int drow = lane >> 2, dslot = lane & 3;
-    const int dcol = (((dslot >> 1) ^ ((lane >> 5) & 1)) << 4) + ((dslot & 1) << 3);       // column of the chunk inside its slab
-    const int slabA0 = (dq >> 1) * 4 + (dq & 1), slabA1 = slabA0 + 2;                       // dY: rows g*128 + {0..63} / {64..127}
-    const int slabB0 = dq * 2, slabB1 = dq * 2 + 1;                                         // X: columns wq*64 + {0..31} / {32..63}
-    unsigned char* const ldsA0 = smem + slabA0 * 4096 + kb * 64;
-    unsigned char* const ldsA1 = smem + slabA1 * 4096 + kb * 64;
-    unsigned char* const ldsB0 = smem + 32768 + slabB0 * 4096 + kb * 64;
-    unsigned char* const ldsB1 = smem + 32768 + slabB1 * 4096 + kb * 64;
-    const uint32_t dA16 = (uint32_t)(16 * lda_b), dX16 = (uint32_t)(16 * ldx_b);
+    // a quarter = 2 slabs x 64 k-rows x 128 B = 16 pieces of 1 KiB (8 k-rows of a slab); wave w moves pieces 2w, 2w+1: slab
+    // (w >> 2) of the quarter, k-rows (w & 3) * 16 + {0, 8} + (lane >> 3); LDS slot lane & 7 (16 B) of row r holds the source
+    // chunk of pair (slot >> 1) ^ f(r), f(r) = (bit 1 of r) | (bit 3 of r) << 1: bit 3 is clear in the first piece, set in the second.
+    const int dq = wave >> 2, kb = (wave & 3) * 16;
+    const int drow = lane >> 3, dslot = lane & 7;
+    const int df = (drow >> 1) & 1;
+    const int dcol0 = ((((dslot >> 1) ^ df) << 4) + ((dslot & 1) << 3));                 // first piece: column of the chunk inside its slab
+    const int dcol1 = ((((dslot >> 1) ^ (df | 2)) << 4) + ((dslot & 1) << 3));           // second piece (rows + 8)
+    const int slabA0 = dq * 2, slabA1 = dq * 2 + 1;                                       // dY: columns g*128 + {0..63} / {64..127}, g = dq
+    const int slabB0 = dq, slabB1 = 2 + dq;                                               // X: columns {0..127} / {128..255}
+    unsigned char* const ldsA0 = smem + slabA0 * 8192 + kb * 128;
+    unsigned char* const ldsA1 = smem + slabA1 * 8192 + kb * 128;
+    unsigned char* const ldsB0 = smem + 32768 + slabB0 * 8192 + kb * 128;
+    unsigned char* const ldsB1 = smem + 32768 + slabB1 * 8192 + kb * 128;
+    const uint32_t dA8 = (uint32_t)(8 * lda_b), dX8 = (uint32_t)(8 * ldx_b);
 
     // per-item per-lane DMA state
-    uint32_t vA0, vA1, vB0, vB1;           // (kb + drow) * ld + column bytes of the four quarters' first piece, or out of range
+    uint32_t vA0, vA0b, vA1, vA1b, vB0, vB0b, vB1, vB1b;     // (kb + drow [+ 8]) * ld + column bytes of the quarters' two pieces, or out of range
     int t_lane = 0;                        // MT: time index of row l_kt * 64 + kb + drow inside its sample
     // load cursor (wave-uniform)
     int li = it_lo + jb;
@@ -91,14 +97,15 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     bool l_active = true;
 
 #define Q256_UNI(X) __builtin_amdgcn_readfirstlane(X)
-    // item -> (slice z, tap, row tile t1 of n1, column tile t2 of n2): tap fastest, then t1
+    // item -> (slice z, tap, row tile t1 of n1, column tile t2 of n2): tap fastest, then t2 (order 2, the default) or t1
 #define Q256_ITEM_OF(IT, Z, TAP, T1, T2)                                                                      \
     {                                                                                                         \
         Z = Q256_UNI((IT) / per_z);                                                                           \
         const int rem_ = (IT) - Z * per_z;                                                                    \
         const int tile_ = Q256_UNI(rem_ / p.taps);                                                            \
         TAP = rem_ - tile_ * p.taps;                                                                          \
-        T2 = Q256_UNI(tile_ / tiles_1); T1 = tile_ - T2 * tiles_1;                                            \
+        if (p.order == 2) { T1 = Q256_UNI(tile_ / tiles_2); T2 = tile_ - T1 * tiles_2; }                      \
+        else { T2 = Q256_UNI(tile_ / tiles_1); T1 = tile_ - T2 * tiles_1; }                                   \
     }
 #define Q256_SETUP_ITEM()                                                                                     \
     {                                                                                                         \
@@ -111,24 +118,26 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         sP = (uint32_t)(l_kt * 64) * (uint32_t)lda_b;                                                         \
         sQ = (uint32_t)(l_kt * 64 + tap_) * (uint32_t)ldx_b;                                                  \
         const uint32_t ra_ = (uint32_t)(kb + drow) * (uint32_t)lda_b, rx_ = (uint32_t)(kb + drow) * (uint32_t)ldx_b; \
-        const int ca0_ = i0_ + slabA0 * 32 + dcol, ca1_ = i0_ + slabA1 * 32 + dcol;                           \
-        const int cb0_ = j0_ + slabB0 * 32 + dcol, cb1_ = j0_ + slabB1 * 32 + dcol;                           \
-        vA0 = ca0_ < p.N1 ? ra_ + (uint32_t)(ca0_ * 2) : 0x80000000u;                                         \
-        vA1 = ca1_ < p.N1 ? ra_ + (uint32_t)(ca1_ * 2) : 0x80000000u;                                         \
-        vB0 = cb0_ < p.N2 ? rx_ + (uint32_t)(cb0_ * 2) : 0x80000000u;                                         \
-        vB1 = cb1_ < p.N2 ? rx_ + (uint32_t)(cb1_ * 2) : 0x80000000u;                                         \
+        const int ca0_ = i0_ + slabA0 * 64, ca1_ = i0_ + slabA1 * 64, cb0_ = j0_ + slabB0 * 64, cb1_ = j0_ + slabB1 * 64; \
+        vA0 = ca0_ + dcol0 < p.N1 ? ra_ + (uint32_t)((ca0_ + dcol0) * 2) : 0x80000000u;                       \
+        vA0b = ca0_ + dcol1 < p.N1 ? ra_ + dA8 + (uint32_t)((ca0_ + dcol1) * 2) : 0x80000000u;                \
+        vA1 = ca1_ + dcol0 < p.N1 ? ra_ + (uint32_t)((ca1_ + dcol0) * 2) : 0x80000000u;                       \
+        vA1b = ca1_ + dcol1 < p.N1 ? ra_ + dA8 + (uint32_t)((ca1_ + dcol1) * 2) : 0x80000000u;                \
+        vB0 = cb0_ + dcol0 < p.N2 ? rx_ + (uint32_t)((cb0_ + dcol0) * 2) : 0x80000000u;                       \
+        vB0b = cb0_ + dcol1 < p.N2 ? rx_ + dX8 + (uint32_t)((cb0_ + dcol1) * 2) : 0x80000000u;                \
+        vB1 = cb1_ + dcol0 < p.N2 ? rx_ + (uint32_t)((cb1_ + dcol0) * 2) : 0x80000000u;                       \
+        vB1b = cb1_ + dcol1 < p.N2 ? rx_ + dX8 + (uint32_t)((cb1_ + dcol1) * 2) : 0x80000000u;                \
         if (MT) t_lane = (l_kt * 64 + kb + drow) % p.Tlen;                                                    \
     }
-    // X offset of the lane's first / second piece row: pushed out of range when the tap leaves the row's sample window
-    // (offsets + scalar offsets stay below 2^31, so an invalid lane stays >= 2^31 after the add)
-#define Q256_VX(V, D16)                                                                                       \
-    (MT ? ((V) + (D16)) | ((unsigned)(((D16) ? (t_lane + 16 >= p.Tlen ? t_lane + 16 - p.Tlen : t_lane + 16) : t_lane) + l_dt) >= (unsigned)p.Tlen ? 0x80000000u : 0u) \
-        : (V) + (D16))
+    // X offset of the lane's piece row (SECOND: the piece 8 rows further): pushed out of range when the tap leaves the row's sample
+    // window (offsets + scalar offsets stay below 2^31, so an invalid lane stays >= 2^31 after the add)
+#define Q256_VX(V, SECOND)                                                                                    \
+    (MT ? (V) | ((unsigned)(((SECOND) ? (t_lane + 8 >= p.Tlen ? t_lane + 8 - p.Tlen : t_lane + 8) : t_lane) + l_dt) >= (unsigned)p.Tlen ? 0x80000000u : 0u) : (V))
 #define Q256_DMA(RS, VOFF, SOFF, DST) __builtin_amdgcn_raw_ptr_buffer_load_lds(RS, (q256_lds_t*)(DST), 16, (VOFF), (SOFF), 0, 0);
-#define Q256_ISSUE_A0(PB, F) if ((F) || l_active) { Q256_DMA(rsP, vA0, sP, ldsA0 + (PB)) Q256_DMA(rsP, vA0 + dA16, sP, ldsA0 + (PB) + 1024) }
-#define Q256_ISSUE_A1(PB, F) if ((F) || l_active) { Q256_DMA(rsP, vA1, sP, ldsA1 + (PB)) Q256_DMA(rsP, vA1 + dA16, sP, ldsA1 + (PB) + 1024) }
-#define Q256_ISSUE_B0(PB, F) if ((F) || l_active) { Q256_DMA(rsQ, Q256_VX(vB0, 0u), sQ, ldsB0 + (PB)) Q256_DMA(rsQ, Q256_VX(vB0, dX16), sQ, ldsB0 + (PB) + 1024) }
-#define Q256_ISSUE_B1(PB, F) if ((F) || l_active) { Q256_DMA(rsQ, Q256_VX(vB1, 0u), sQ, ldsB1 + (PB)) Q256_DMA(rsQ, Q256_VX(vB1, dX16), sQ, ldsB1 + (PB) + 1024) }
+#define Q256_ISSUE_A0(PB, F) if ((F) || l_active) { Q256_DMA(rsP, vA0, sP, ldsA0 + (PB)) Q256_DMA(rsP, vA0b, sP, ldsA0 + (PB) + 1024) }
+#define Q256_ISSUE_A1(PB, F) if ((F) || l_active) { Q256_DMA(rsP, vA1, sP, ldsA1 + (PB)) Q256_DMA(rsP, vA1b, sP, ldsA1 + (PB) + 1024) }
+#define Q256_ISSUE_B0(PB, F) if ((F) || l_active) { Q256_DMA(rsQ, Q256_VX(vB0, 0), sQ, ldsB0 + (PB)) Q256_DMA(rsQ, Q256_VX(vB0b, 1), sQ, ldsB0 + (PB) + 1024) }
+#define Q256_ISSUE_B1(PB, F) if ((F) || l_active) { Q256_DMA(rsQ, Q256_VX(vB1, 0), sQ, ldsB1 + (PB)) Q256_DMA(rsQ, Q256_VX(vB1b, 1), sQ, ldsB1 + (PB) + 1024) }
     // move the load cursor to the next K-tile of the stream
 #define Q256_ADVANCE(F)                                                                                       \
     if ((F) || l_active) {                                                                                    \
@@ -144,16 +153,19 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
 
     // ---------------- fragment addressing ----------------
     // lane = 16 q + 4 qq + pp: k-group q (k = 8q .. 8q+7 of a 32-wide sub-step), k-row qq of the group's first / second four,
-    // 8-byte segment pp of the tile's 32 bytes.  Tiles alternate between the two 32-byte halves of a slab row; the half is
-    // swapped in rows with bit 3 set = odd q.
+    // 8-byte segment pp of the tile's 32 bytes.  Tile pair P of a slab row sits at pair P ^ f, f = (bit 1 of qq) | (bit 0 of q) << 1.
     const int q = lane >> 4, lr = lane & 15;
     const int qq = lr >> 2, pp = lr & 3;
+    const int ff = ((qq >> 1) & 1) | ((q & 1) << 1);
     const uint32_t smem_b = (uint32_t)(uintptr_t)(q256_lds_t*)smem;
-    const uint32_t lane_e = (uint32_t)((8 * q + qq) * 64 + ((q & 1) << 5) + 8 * pp);
-    const uint32_t lane_o = (uint32_t)((8 * q + qq) * 64 + (((q & 1) ^ 1) << 5) + 8 * pp);
-    const uint32_t fPe = smem_b + g * 16384 + lane_e, fPo = smem_b + g * 16384 + lane_o;               // dY tiles (even / odd)
-    const uint32_t fQe = smem_b + 32768 + wq * 8192 + lane_e, fQo = smem_b + 32768 + wq * 8192 + lane_o;   // X tiles
-    const uint32_t fPen = fPe + 65536, fPon = fPo + 65536, fQen = fQe + 65536, fQon = fQo + 65536;
+    const uint32_t lrow = (uint32_t)((8 * q + qq) * 128 + 8 * pp);
+    // dY row tile i of the wave's half: slab 2g + (i >> 2), pair i & 3
+    const uint32_t fP0 = smem_b + g * 16384 + lrow + ((0 ^ ff) << 5), fP1 = smem_b + g * 16384 + lrow + ((1 ^ ff) << 5);
+    const uint32_t fP2 = smem_b + g * 16384 + lrow + ((2 ^ ff) << 5), fP3 = smem_b + g * 16384 + lrow + ((3 ^ ff) << 5);
+    // X column tile nt of the wave: slab (nt >> 1) * 2 + (wq >> 1), pair (wq & 1) * 2 + (nt & 1)
+    const uint32_t fQ0 = smem_b + 32768 + (wq >> 1) * 8192 + lrow + ((((wq & 1) * 2 + 0) ^ ff) << 5);
+    const uint32_t fQ1 = smem_b + 32768 + (wq >> 1) * 8192 + lrow + ((((wq & 1) * 2 + 1) ^ ff) << 5);
+    const uint32_t fP0n = fP0 + 65536, fP1n = fP1 + 65536, fP2n = fP2 + 65536, fP3n = fP3 + 65536, fQ0n = fQ0 + 65536, fQ1n = fQ1 + 65536;
 
     q256_f4 acc[8][4];
 #pragma unroll
@@ -164,28 +176,28 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     bf16x8 fb00, fb01, fb10, fb11;                             // X fragments, columns 0-31: [col tile][k sub-step]
     bf16x8 fc00, fc01, fc10, fc11;                             // X fragments, columns 32-63
 
-    // one operand = k-rows r..r+3 and r+4..r+7 of the lane's k-group: two transposed reads, 256 bytes (4 rows) apart
+    // one operand = k-rows r..r+3 and r+4..r+7 of the lane's k-group: two transposed reads, 512 bytes (4 rows) apart
 #define Q256_TR(DST, ADDR, IMM)                                                                               \
     {                                                                                                         \
         long lo_, hi_;                                                                                        \
         asm volatile("ds_read_b64_tr_b16 %0, %2 offset:%3\n\tds_read_b64_tr_b16 %1, %2 offset:%4"           \
-                     : "=&v"(lo_), "=&v"(hi_) : "v"(ADDR), "n"(IMM), "n"((IMM) + 256));                       \
+                     : "=&v"(lo_), "=&v"(hi_) : "v"(ADDR), "n"(IMM), "n"((IMM) + 512));                       \
         q256_l2 pr_; pr_[0] = lo_; pr_[1] = hi_;                                                              \
         DST = __builtin_bit_cast(bf16x8, pr_);                                                                \
     }
-    // dY row tiles R0..R0+3 of the wave's half (R0 = 0 or 4): slab (R0 >> 1) + {0, 1}, even / odd halves; k sub-step = +2048
-#define Q256_READ_A(PE, PO, R0)                                                                               \
+    // dY row tiles R0..R0+3 of the wave's half (R0 = 0 or 4): slab 2g + (R0 >> 2), pairs 0..3; k sub-step = +4096
+#define Q256_READ_A(P0, P1, P2, P3, R0)                                                                       \
     {                                                                                                         \
-        Q256_TR(fa00, PE, ((R0) >> 1) * 4096 + 0) Q256_TR(fa01, PE, ((R0) >> 1) * 4096 + 2048)                \
-        Q256_TR(fa10, PO, ((R0) >> 1) * 4096 + 0) Q256_TR(fa11, PO, ((R0) >> 1) * 4096 + 2048)                \
-        Q256_TR(fa20, PE, ((R0) >> 1) * 4096 + 4096) Q256_TR(fa21, PE, ((R0) >> 1) * 4096 + 4096 + 2048)      \
-        Q256_TR(fa30, PO, ((R0) >> 1) * 4096 + 4096) Q256_TR(fa31, PO, ((R0) >> 1) * 4096 + 4096 + 2048)      \
+        Q256_TR(fa00, P0, ((R0) >> 2) * 8192 + 0) Q256_TR(fa01, P0, ((R0) >> 2) * 8192 + 4096)                \
+        Q256_TR(fa10, P1, ((R0) >> 2) * 8192 + 0) Q256_TR(fa11, P1, ((R0) >> 2) * 8192 + 4096)                \
+        Q256_TR(fa20, P2, ((R0) >> 2) * 8192 + 0) Q256_TR(fa21, P2, ((R0) >> 2) * 8192 + 4096)                \
+        Q256_TR(fa30, P3, ((R0) >> 2) * 8192 + 0) Q256_TR(fa31, P3, ((R0) >> 2) * 8192 + 4096)                \
     }
-    // X column tiles C0, C0+1 of the wave's block (C0 = 0 or 2): slab C0 >> 1
-#define Q256_READ_B(X, QE, QO, C0)                                                                            \
+    // X column tiles C0, C0+1 of the wave (C0 = 0 or 2): slab (C0 >> 1) * 2 + (wq >> 1)
+#define Q256_READ_B(X, Q0, Q1, C0)                                                                            \
     {                                                                                                         \
-        Q256_TR(X##00, QE, ((C0) >> 1) * 4096 + 0) Q256_TR(X##01, QE, ((C0) >> 1) * 4096 + 2048)              \
-        Q256_TR(X##10, QO, ((C0) >> 1) * 4096 + 0) Q256_TR(X##11, QO, ((C0) >> 1) * 4096 + 2048)              \
+        Q256_TR(X##00, Q0, ((C0) >> 1) * 16384 + 0) Q256_TR(X##01, Q0, ((C0) >> 1) * 16384 + 4096)            \
+        Q256_TR(X##10, Q1, ((C0) >> 1) * 16384 + 0) Q256_TR(X##11, Q1, ((C0) >> 1) * 16384 + 4096)            \
     }
 #define Q256_WAIT_A() asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa00), "+v"(fa01), "+v"(fa10), "+v"(fa11), "+v"(fa20), "+v"(fa21), "+v"(fa30), "+v"(fa31));
 #define Q256_WAIT_B(X) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(X##00), "+v"(X##01), "+v"(X##10), "+v"(X##11));
@@ -224,11 +236,11 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
 #define Q256_W1(N, X) asm volatile("s_waitcnt lgkmcnt(" #N ")" : "+v"(X));
 #define Q256_MM2(R, C0, X, FA, S) Q256_MMA(R, C0 + 0, X, 0, FA, S) Q256_MMA(R, C0 + 1, X, 1, FA, S)
     // section 1: X tiles 0,1 + dY row tiles 0-3, k sub-step 0 first (24 reads)
-#define Q256_SEC1_READ(PE, PO, QE, QO)                                                                        \
-        Q256_TR(fb00, QE, 0) Q256_TR(fb10, QO, 0) Q256_TR(fa00, PE, 0) Q256_TR(fa10, PO, 0)                   \
-        Q256_TR(fa20, PE, 4096) Q256_TR(fa30, PO, 4096)                                                       \
-        Q256_TR(fb01, QE, 2048) Q256_TR(fb11, QO, 2048) Q256_TR(fa01, PE, 2048) Q256_TR(fa11, PO, 2048)       \
-        Q256_TR(fa21, PE, 4096 + 2048) Q256_TR(fa31, PO, 4096 + 2048)
+#define Q256_SEC1_READ(P0, P1, P2, P3, Q0, Q1)                                                                \
+        Q256_TR(fb00, Q0, 0) Q256_TR(fb10, Q1, 0) Q256_TR(fa00, P0, 0) Q256_TR(fa10, P1, 0)                   \
+        Q256_TR(fa20, P2, 0) Q256_TR(fa30, P3, 0)                                                             \
+        Q256_TR(fb01, Q0, 4096) Q256_TR(fb11, Q1, 4096) Q256_TR(fa01, P0, 4096) Q256_TR(fa11, P1, 4096)       \
+        Q256_TR(fa21, P2, 4096) Q256_TR(fa31, P3, 4096)
 #define Q256_SEC1_MMA()                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                        \
         Q256_W3(15, fb00, fb10, fa00) __builtin_amdgcn_sched_barrier(0); Q256_MM2(0, 0, fb, fa0, 0)           \
@@ -242,8 +254,8 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         __builtin_amdgcn_s_setprio(0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);
     // section 2: X tiles 2,3 (8 reads)
-#define Q256_SEC2_READ(QE, QO)                                                                                \
-        Q256_TR(fc00, QE, 4096) Q256_TR(fc10, QO, 4096) Q256_TR(fc01, QE, 4096 + 2048) Q256_TR(fc11, QO, 4096 + 2048)
+#define Q256_SEC2_READ(Q0, Q1)                                                                                \
+        Q256_TR(fc00, Q0, 16384) Q256_TR(fc10, Q1, 16384) Q256_TR(fc01, Q0, 16384 + 4096) Q256_TR(fc11, Q1, 16384 + 4096)
 #define Q256_SEC2_MMA()                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                        \
         Q256_W2(4, fc00, fc10) __builtin_amdgcn_sched_barrier(0);                                             \
@@ -253,9 +265,9 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         __builtin_amdgcn_s_setprio(0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);
     // section 3: dY row tiles 4-7 (16 reads)
-#define Q256_SEC3_READ(PE, PO)                                                                                \
-        Q256_TR(fa00, PE, 8192) Q256_TR(fa10, PO, 8192) Q256_TR(fa20, PE, 8192 + 4096) Q256_TR(fa30, PO, 8192 + 4096) \
-        Q256_TR(fa01, PE, 8192 + 2048) Q256_TR(fa11, PO, 8192 + 2048) Q256_TR(fa21, PE, 8192 + 4096 + 2048) Q256_TR(fa31, PO, 8192 + 4096 + 2048)
+#define Q256_SEC3_READ(P0, P1, P2, P3)                                                                        \
+        Q256_TR(fa00, P0, 8192) Q256_TR(fa10, P1, 8192) Q256_TR(fa20, P2, 8192) Q256_TR(fa30, P3, 8192)       \
+        Q256_TR(fa01, P0, 8192 + 4096) Q256_TR(fa11, P1, 8192 + 4096) Q256_TR(fa21, P2, 8192 + 4096) Q256_TR(fa31, P3, 8192 + 4096)
 #define Q256_SEC3_MMA()                                                                                       \
         __builtin_amdgcn_s_setprio(1);                                                                        \
         Q256_W1(14, fa00) __builtin_amdgcn_sched_barrier(0); Q256_MM2(4, 2, fc, fa0, 0)                       \
@@ -269,28 +281,28 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         __builtin_amdgcn_s_setprio(0);                                                                        \
         __builtin_amdgcn_sched_barrier(0);
 #else
-#define Q256_SEC1_READ(PE, PO, QE, QO) Q256_READ_A(PE, PO, 0) Q256_READ_B(fb, QE, QO, 0)
+#define Q256_SEC1_READ(P0, P1, P2, P3, Q0, Q1) Q256_READ_A(P0, P1, P2, P3, 0) Q256_READ_B(fb, Q0, Q1, 0)
 #define Q256_SEC1_MMA() Q256_WAIT_A() Q256_WAIT_B(fb) __builtin_amdgcn_sched_barrier(0); Q256_MMA16(0, 0, fb)
-#define Q256_SEC2_READ(QE, QO) Q256_READ_B(fc, QE, QO, 2)
+#define Q256_SEC2_READ(Q0, Q1) Q256_READ_B(fc, Q0, Q1, 2)
 #define Q256_SEC2_MMA() Q256_WAIT_B(fc) __builtin_amdgcn_sched_barrier(0); Q256_MMA16(0, 2, fc)
-#define Q256_SEC3_READ(PE, PO) Q256_READ_A(PE, PO, 4)
+#define Q256_SEC3_READ(P0, P1, P2, P3) Q256_READ_A(P0, P1, P2, P3, 4)
 #define Q256_SEC3_MMA() Q256_WAIT_A() __builtin_amdgcn_sched_barrier(0); Q256_MMA16(4, 2, fc)
 #endif
     // one K-tile (section structure and refill distances of gemm256.hip): parity buffer PB is consumed; quarters of the
     // stream's next K-tiles go into PN (B1, A1: the K-tile the cursor points at) and, after the cursor has moved, into PB (A0, B0)
-#define Q256_KTILE(PE, PO, QE, QO, PB, PN, F)                                                                 \
+#define Q256_KTILE(P0, P1, P2, P3, Q0, Q1, PB, PN, F)                                                         \
     {                                                                                                         \
-        Q256_SEC1_READ(PE, PO, QE, QO)                                                                        \
+        Q256_SEC1_READ(P0, P1, P2, P3, Q0, Q1)                                                                \
         Q256_ISSUE_B1(PN, F)                                                                                  \
         if (early) Q256_LEND(F)                                                                               \
         Q256_SEC1_MMA()                                                                                       \
         if (!early) Q256_LEND(F)                                                                              \
-        Q256_SEC2_READ(QE, QO)                                                                                \
+        Q256_SEC2_READ(Q0, Q1)                                                                                \
         Q256_ISSUE_A1(PN, F)                                                                                  \
         if (early) Q256_LEND(F)                                                                               \
         Q256_SEC2_MMA()                                                                                       \
         if (!early) Q256_LEND(F)                                                                              \
-        Q256_SEC3_READ(PE, PO)                                                                                \
+        Q256_SEC3_READ(P0, P1, P2, P3)                                                                        \
         Q256_ADVANCE(F)                                                                                       \
         if (!(F) && !l_active) wmode = 2;                                                                     \
         Q256_ISSUE_A0(PB, F)                                                                                  \
@@ -330,20 +342,20 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     for (;;) {
         // fast path: two K-tiles with compile-time parity while neither cursor meets a boundary
         while (pb == 0 && wmode == 0 && kt + 2 < c_nkt && l_kt + 2 < l_kt_end) {
-            Q256_KTILE(fPe, fPo, fQe, fQo, 0, 65536, 1)
-            Q256_KTILE(fPen, fPon, fQen, fQon, 65536, 0, 1)
+            Q256_KTILE(fP0, fP1, fP2, fP3, fQ0, fQ1, 0, 65536, 1)
+            Q256_KTILE(fP0n, fP1n, fP2n, fP3n, fQ0n, fQ1n, 65536, 0, 1)
             kt += 2;
         }
         {
             const uint32_t pn = pb ^ 65536u;
-            const uint32_t pe_ = fPe + pb, po_ = fPo + pb, qe_ = fQe + pb, qo_ = fQo + pb;
-            Q256_KTILE(pe_, po_, qe_, qo_, pb, pn, 0)
+            const uint32_t p0_ = fP0 + pb, p1_ = fP1 + pb, p2_ = fP2 + pb, p3_ = fP3 + pb, q0_ = fQ0 + pb, q1_ = fQ1 + pb;
+            Q256_KTILE(p0_, p1_, p2_, p3_, q0_, q1_, pb, pn, 0)
             ++kt;
             pb = pn;
         }
         if (kt == c_nkt) {
             // ================= epilogue of item ci: raw fp32 sums, 16 bytes per lane and tile =================
-            const int mw = c_i0 + g * 128, nw = c_j0 + wq * 64;
+            const int mw = c_i0 + g * 128, nw = c_j0 + wq * 32;          // column tiles 0,1 at nw, tiles 2,3 at nw + 128
             float* outp = p.out + (long)c_z * p.out_slab_stride + (long)c_tap * p.out_tap_stride;
             const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)(((long)(p.N1 - 1) * p.ldo + p.N2) * 4), 0x00020000);
 #pragma unroll
@@ -351,7 +363,7 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
                 const int row = mw + i * 16 + lr;
 #pragma unroll
                 for (int nt = 0; nt < 4; ++nt) {
-                    const int col = nw + nt * 16 + q * 4;
+                    const int col = nw + (nt >> 1) * 128 + (nt & 1) * 16 + q * 4;
                     const bool ok = row < p.N1 && col < p.N2;
                     const q256_f4 v = acc[i][nt];
                     acc[i][nt] = (q256_f4){0.f, 0.f, 0.f, 0.f};
@@ -400,6 +412,8 @@ int launch_gemm_tn256(const GemmTN& p, hipStream_t s) {
     if (q256_cdiv(p.M, 64) / p.splitk < 4) return -1;                 // every item keeps >= 4 K-tiles (prologue + counted waits)
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) || ((uintptr_t)p.out & 15)) return -1;
     GemmTN q = p;
+    static const int order_env = getenv("SGV_TN256_ORDER") ? atoi(getenv("SGV_TN256_ORDER")) : -1;
+    q.order = order_env >= 0 ? order_env : 2;        // measured (one box, order 0 / 2): 665 / 650, 652 / 620, 837 / 826 us on the three big shapes
     q.a_bytes = ((long)(p.M - 1) * p.lda + p.N1) * 2;
     q.b_bytes = ((long)(p.M - 1) * p.ldb + p.N2) * 2;
     // 32-bit buffer offsets; a lane's offset + scalar offset (incl. the tap shift and 63 rows of run-ahead) must stay below 2^31
