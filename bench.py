@@ -212,6 +212,9 @@ def main():
     ap.add_argument("--cpu-timed-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--recompute", action="store_true",
+                    help="measurement only: regenerate the GroupNorm + GELU outputs in backward (what configs[3]'s '+ grad-checkpoint' would cost); "
+                         "adds config.recompute_activations / recompute_gib to the line")
     ap.add_argument("--layer-times", action="store_true", help="print a per-layer GEMM table (stderr) after the run")
     ap.add_argument("--workload", default="vae", choices=["vae", "lc"],
                     help="vae = the headline hot path; lc = image latent-conditioner training step (BASELINE.json configs[4], secondary)")
@@ -246,6 +249,8 @@ def main():
     t_init = time.time()
     eng.load_state(init_state(cfg, 7, reference_init=True))   # same seed on every rank -> identical replicas
     eng.set_option("write_xhat", 0)   # train.py:142 discards the reconstruction (`_`)
+    if args.recompute:
+        eng.set_option("recompute_activations", 1)
     eng.seed(1234)                     # ONE noise seed for the job; the draws are keyed by the global sample row (sgv_set_shard)
     eng.set_shard(rank, world)
     # synthetic dataset, generated on the device, converted to the engine's resident layout (replicated: same samples on every rank)
@@ -345,6 +350,11 @@ def main():
                   "step_tflops": round((fwd + dx + dw) / (ms * 1e-3) / 1e12, 2),
                   "roofline": roof}
         result["config"].update(ddp_info)
+        mem = eng.memory_info()
+        result["config"]["resident_gib"] = round(sum(mem.values()) / 2 ** 30, 2)
+        if args.recompute:
+            result["config"]["recompute_activations"] = True
+            result["config"]["recompute_gib"] = round(eng.recompute_bytes() / 2 ** 30, 3)
     # per-kernel durations (hipEvents on the engine's stream around each GEMM's main kernel), outside the timed region
     if not args.no_kernel_timing:
         eng.kernel_time_reset(2)

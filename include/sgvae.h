@@ -232,6 +232,12 @@ int sgv_grad_payload_unpack(sgv_engine* e);
  * use_checkpointing flag is forced to False in its code, modules/VAE_network.py:68, and no recompute exists here either),
  * [5] split-K / reduction workspaces. */
 int sgv_memory_info(const sgv_engine* e, size_t out[6]);
+/* Measurement hook for BASELINE configs[3] ("+ grad-checkpoint"; the reference forces use_checkpointing to False,
+ * modules/VAE_network.py:68).  With sgv_set_option("recompute_activations", 1) the backward pass regenerates every stage's
+ * GroupNorm + GELU output from the stored pre-normalisation map right before the stage's backward (one extra streaming pass per
+ * stage; same values, buffers stay allocated): it TIMES what recompute would cost; sgv_recompute_bytes returns the bytes of
+ * the maps the last backward regenerated = what a recompute build would not keep resident. */
+int sgv_recompute_bytes(const sgv_engine* e, size_t* bytes);
 /* Gradient 2-norm accumulated by the AdamW pass(es) of the current step (same value sgv_grad_norm computes in a
  * separate pass).  [sync] */
 int sgv_last_grad_norm(sgv_engine* e, double* out);

@@ -158,6 +158,13 @@ struct sgv_engine {
     // updated in row chunks of the weight-gradient GEMM: chunk c's pack / all-reduce / AdamW run under chunk c + 1's GEMM, so only
     // the last chunk's exchange is exposed (engine-issued path; SGV_DDP_LAST_CHUNKS=1 turns it off).  Two chunks: 512 rows keep the
     // GEMM's 128 x 256 tiles at whole rounds of the chip, four chunks of 256 rows cost 27 % of the GEMM
+    // BASELINE configs[3] "+ grad-checkpoint": what recomputing the GroupNorm + GELU outputs in backward would cost.  With the option on,
+    // block_bwd regenerates every stage's activation a = act(GN(y)) from the stored pre-normalisation map and statistics right before
+    // the stage's backward reads it (one extra streaming pass per stage).  The buffers themselves stay allocated -- this times the
+    // recompute, it does not free the memory (sgv_memory_info's "activations" minus what recompute_bytes reports is what a
+    // recompute build would keep); `use_checkpointing` stays forced off as in the reference
+    bool recompute_act = false;
+    size_t recompute_bytes = 0;
     int ddp_last_chunks = getenv("SGV_DDP_LAST_CHUNKS") ? atoi(getenv("SGV_DDP_LAST_CHUNKS")) : 2;
     double ddp_chunk_min_gf = getenv("SGV_DDP_CHUNK_MIN_GF") ? atof(getenv("SGV_DDP_CHUNK_MIN_GF")) : 250.0;   // tests lower it to chunk a small first layer
     int dw_chunks = 1, dw_chunk_layer = -1;
@@ -1112,6 +1119,18 @@ static int block_bwd(sgv_engine* e, Block& b, const Tensor& in, const Tensor& dO
         // <G,W_eff> and the GroupNorm affine / bias gradients leave these kernels as block / per-sample partials in e->red; the
         // fixed-order sums run once per bucket (flush_fin in backward_impl)
         int* cnt = &e->dot_counts[e->fin_dots.size() % 512];
+        if (e->recompute_act && S.gn >= 0 && !S.y.f32) {
+            // regenerate this stage's output map exactly as block_fwd's unfused path writes it (the fused forward kernel normalises the
+            // same stored values): the map is read below as the next stage's convolution input (weight gradient) and by the
+            // residual adds; a recompute build would not have kept it
+            const GNLayer& g = e->gns[S.gn];
+            GNParams p = gn_base(e, g, B);
+            p.y = S.y.p; p.ldy = S.y.ld; p.sums = e->stats + S.sums; p.part = e->colpart;
+            p.out = S.a.p; p.ldout = S.a.ld;
+            if (b.residual && s + 1 == (int)b.st.size()) { p.res = in.p; p.ldres = in.ld; p.rscale = 0.1f; }
+            if (ew_gn_apply(e->dt, S.act, p, e->stream)) return fail(SGV_ERR_HIP, "activation recompute launch failed (%s)", L.prefix.c_str());
+            e->recompute_bytes += (size_t)M * g.C * e->esz;
+        }
         if (dy_ready) {
             dY = S.dy;
             dy_ready = false;
@@ -1634,6 +1653,7 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     else if (!strcmp(key, "vendor_gemm")) { if (value) return fail(SGV_ERR_ARG, "vendor_gemm: the library GEMM back end was removed from libsgvae.so (comparator: tests/micro/vendor)"); }
     else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
     else if (!strcmp(key, "lanes")) e->use_lanes = value != 0 && e->lane2 != nullptr;          // second compute lane (schedule only: results are bitwise the same)
+    else if (!strcmp(key, "recompute_activations")) e->recompute_act = value != 0;               // measurement only, see block_bwd
     else if (!strcmp(key, "fused_stages")) e->use_convgn = value != 0;                          // csrc/convgn.hip kernels for the small Conv -> GroupNorm -> GELU stages
     else return fail(SGV_ERR_ARG, "unknown option '%s'", key);
     return SGV_OK;
@@ -2091,6 +2111,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     const float coefB = beta / (float)B;
     int bucket = 0;
     e->ev_next = 0;
+    e->recompute_bytes = 0;
     int early_err = 0;
     // the inputs of a bucket's collective are what the main stream and the side stream hold so far.  They are gathered on the
     // stream the collective is issued from (the communicator's stream; with a callback the wire stream, option "wire_stream"), and
@@ -2512,6 +2533,11 @@ int sgv_memory_info(const sgv_engine* e, size_t out[6]) {
     if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
     out[0] = e->n_params * 4; out[1] = e->n_grads * 4; out[2] = e->n_grads * 8; out[3] = e->n_copies * e->esz; out[4] = e->act_bytes;
     out[5] = ((e->use_lanes ? 2 : 1) * (e->partial_floats + e->colpart_floats + e->gn_part_floats) + e->partial_tn_floats + e->red_floats + e->n_sn_tmp + e->xpose_floats) * 4;
+    return SGV_OK;
+}
+int sgv_recompute_bytes(const sgv_engine* e, size_t* bytes) {
+    if (!e || !bytes) return fail(SGV_ERR_ARG, "null argument");
+    *bytes = e->recompute_bytes;
     return SGV_OK;
 }
 int sgv_last_grad_norm(sgv_engine* e, double* out) {

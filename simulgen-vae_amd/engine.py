@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "sgv_seed", "sgv_set_shard", "sgv_set_option", "sgv_forward", "sgv_decode", "sgv_encode", "sgv_get_xhat", "sgv_get_activation",
     "sgv_backward", "sgv_set_bucket_callback", "sgv_grad_buffer", "sgv_scale_grads", "sgv_grad_norm",
     "sgv_adamw_step", "sgv_augment_collate", "sgv_dataset_convert", "sgv_dataset_sample_bytes",
-    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_wire_stream", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
+    "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_wire_stream", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_recompute_bytes", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_rccl_unique_id", "sgv_rccl_probe", "sgv_rccl_comm_count", "sgv_rccl_allreduce", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_fake_collective",
@@ -109,6 +109,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_set_rccl.argtypes = [vp, vp, vp]
     lib.sgv_last_grad_norm.argtypes = [vp, C.POINTER(C.c_double)]
     lib.sgv_memory_info.argtypes = [vp, C.POINTER(C.c_size_t)]
+    lib.sgv_recompute_bytes.argtypes = [vp, C.POINTER(C.c_size_t)]
     lib.sgv_scalars_accumulate.argtypes = [vp]
     lib.sgv_scalars_read.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.sgv_augment_collate.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
@@ -358,6 +359,12 @@ class Engine:
         buf = (C.c_size_t * 6)()
         _check(self.lib, self.lib.sgv_memory_info(self.h, buf), "sgv_memory_info")
         return dict(zip(("params", "grads", "adam", "copies", "activations", "workspaces"), [int(v) for v in buf]))
+
+    def recompute_bytes(self) -> int:
+        """Bytes of the activation maps the last backward regenerated under option "recompute_activations" (include/sgvae.h)."""
+        n = C.c_size_t()
+        _check(self.lib, self.lib.sgv_recompute_bytes(self.h, C.byref(n)), "sgv_recompute_bytes")
+        return int(n.value)
 
     def accumulate_scalars(self):
         """Add the scalars of the step just enqueued to the device-side epoch accumulator (no host sync)."""

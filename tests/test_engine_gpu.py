@@ -208,6 +208,40 @@ def test_engine_noise_is_keyed_by_the_global_sample_row():
             assert relerr(mean, gw) < 5e-5, (step, k, relerr(mean, gw))
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_recompute_activations_option_regenerates_the_same_maps(dtype):
+    """Option "recompute_activations" (the timing hook for BASELINE configs[3]'s "+ grad-checkpoint"): backward regenerates every
+    stage's GroupNorm + GELU output from the stored pre-normalisation map before it uses it.  Same values, so the step must give
+    the gradients of the plain step (fp32: bitwise -- the regenerating pass IS the forward's pass; bf16: the fused stage kernels
+    normalise the same stored values, rounding only), and the hook reports how many bytes it regenerated."""
+    import torch
+    cfg = make_cfg(G1)
+    B = 4
+    x = synthetic_samples(20251003, range(B), cfg.num_node, cfg.num_time)
+    eps = synthetic_eps(1234, 0, cfg, B)
+    state = init_state(cfg, 7)
+    names = [e.name for e in param_spec(cfg) if e.kind in ("bias", "weight_orig", "gn_weight", "gn_bias")]
+    out = []
+    for rec in (0, 1):
+        eng = E.Engine(cfg, max_batch=B, compute_dtype=dtype)
+        eng.load_state(state)
+        eng.set_option("recompute_activations", rec)
+        sc, _ = engine_step(eng, cfg, x, eps, 1e6, 1e-4, want_acts=False)
+        out.append((sc, {k: eng.grad(k) for k in names}, eng.grad_norm(), eng.recompute_bytes()))
+        eng.close()
+    (sa, ga, na, ba), (sb, gb, nb, bb) = out
+    assert ba == 0 and bb > 0
+    assert sa == sb                                   # forward is untouched
+    for k in names:
+        if ga[k] is None:
+            assert gb[k] is None
+        elif dtype == "f32":
+            assert np.array_equal(ga[k], gb[k]), k
+        else:
+            assert rel_l2(gb[k], ga[k]) < 2e-2, (k, rel_l2(gb[k], ga[k]))
+    assert abs(na - nb) <= (0 if dtype == "f32" else 5e-3) * na
+
+
 def test_augment_collate_matches_oracle():
     """A13: the fused noise/scale/mixup + collate kernel on the HBM-resident dataset vs oracle.augment_sample
     (augmentation.py:86-124).  Scale and mixup are exact arithmetic on the stored sample; the Gaussian noise comes from

@@ -46,7 +46,7 @@ r = b["roofline"]
 t256 = traffic.get("gemm_nt_t256_kernel", {})
 doc = f"""# Round {int(TAG[1:3])} — rocprofv3 summaries (MI355X, bf16, batch 16, preset-1 small)
 
-Collected by `tools/profile_round2.sh` in one gpurun call (separate rocprofv3 process per pass), assembled by
+Collected by `tools/profile_round2.sh` (round 3: through `tools/profile_round3.sh`) in one gpurun call (separate rocprofv3 process per pass), assembled by
 `tools/write_round2_summary.py` (tables by `tools/summarize_profile.py`, timeline by `tools/step_timeline.py`).  Code state: the
 commit this file belongs to.  Un-profiled bench on the same box (`profiles/{TAG}_bench_line.json`): **{b["value"]:.0f} samples/s,
 {b["ms_per_step"]:.2f} ms/step**, ELBO of the first step within {b.get("elbo_rel_vs_cpu_port")} (relative) of the CPU restatement; dominant kernel class
