@@ -65,12 +65,12 @@ def traffic(fetch_csv, write_csv):
         for x in step:
             k = x["Kernel_Name"]
             fam = next((n for n in ("gemm_nt_t256_kernel", "t256_reduce_kernel", "gemm_nt_wide64p_kernel", "gemm_nt_reduce", "gemm_nt_kernel",
-                                    "gemm_tn_w2_kernel", "gemm_tn_kernel", "sum_slabs_kernel", "adamw_sn_kernel") if n in k), None)
+                                    "gemm_tn_t256_kernel", "gemm_tn_w2_kernel", "gemm_tn_kernel", "sum_slabs_kernel", "adamw_sn_kernel") if n in k), None)
             if fam is None:
                 continue
             aux = fam in ("t256_reduce_kernel",)    # the 256x256 kernel's split-K combine: bytes of its class, not a launch of it
-            if fam == "gemm_tn_kernel":
-                fam = "gemm_tn_w2_kernel"      # one weight-gradient class (bench.py's roofline_gemm_tn covers both kernels)
+            if fam in ("gemm_tn_kernel", "gemm_tn_w2_kernel"):
+                fam = "gemm_tn_t256_kernel"    # one weight-gradient class (bench.py's roofline_gemm_tn covers the three kernels)
             if fam == "t256_reduce_kernel":
                 fam = "gemm_nt_t256_kernel"
             d = out.setdefault(fam, {"fetch_bytes": 0.0, "write_bytes": 0.0, "launches": 0})
