@@ -360,13 +360,16 @@ def test_auxiliary_streams_do_not_share_the_main_streams_hardware_queue():
     from tests.gpu_common import G1, make_cfg
     lib = E.load_library()
     lib.sgv_test_stream_overlap.argtypes = [C.c_void_p, C.c_int, C.POINTER(C.c_int)]
+    if int(os.environ.get("GPU_MAX_HW_QUEUES", "4")) < 4:
+        pytest.skip("fewer than four hardware queues configured: main / lane / side / optimizer cannot all have their own (ADVICE r2)")
     engines = [Engine(make_cfg(G1), max_batch=2, compute_dtype="bf16") for _ in range(3)]
     try:
         for eng in engines:
             for which in range(4):
                 o = C.c_int(-2)
                 assert lib.sgv_test_stream_overlap(eng.h, which, C.byref(o)) == 0, lib.sgv_last_error()
-                assert o.value == 1, (which, o.value)
+                assert o.value in (1, -1), (which, o.value)          # -1: the stream does not exist (option off)
+                assert which > 1 or o.value == 1, (which, o.value)  # the lane and the side stream always exist
     finally:
         for eng in engines:
             eng.close()
