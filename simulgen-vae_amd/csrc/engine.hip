@@ -2749,10 +2749,13 @@ int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias
     const int band_code = (mode >> 8) & 0xff, strm_code = (mode >> 16) & 7;
     p.band = band_code == 255 ? -1 : band_code;
     p.strm = strm_code == 7 ? -1 : strm_code;
+    const int ts_code = (mode >> 19) & 3;
+    p.ts = ts_code == 1 ? 1 : ts_code == 2 ? -1 : 0;
     mode &= 0xff;
     int r;
     if (mode == 0) {
-        if (plan_kind) *plan_kind = 1;
+        if (plan_kind) *plan_kind = p.ts == 1 ? 3 : 1;
+        if (p.ts < 0) p.ts = 0;
         r = launch_gemm_nt256(p, (hipStream_t)stream);
     } else {
         const GemmPlan pl = gemm_nt_plan(SGV_DTYPE_BF16, p, cap, sums != nullptr);

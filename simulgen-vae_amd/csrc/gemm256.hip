@@ -77,18 +77,29 @@ __device__ __forceinline__ float t256_hi(uint32_t v) { return __builtin_bit_cast
 // STRM: cache policy of the two streams of a launch whose activation tiles should stay in the XCD's L2 (the recon head: every
 //       weight panel is read once per XCD and 608 MB of output flow through the same 4 MiB): bit 0 = the weight stream is
 //       loaded non-temporally, bit 1 = the bf16 output is stored with sc1 (the line leaves the L2 once written)
-template <int OUT, bool MT, bool C2D = false, int STRM = 0>
+// TS:   tile shape.  0 = 256 (m) x 256 (n): wave (g, wq) = (row half, 64-column block).  1 = 128 (m) x 512 (n): all eight waves share
+//       the 128 rows and own 64 columns each -- M = 3200 is 25 such row tiles, so 25 x N/512 x slices fill ONE round of the chip with
+//       no 128-row tail launch.  Same sections and refill order; a K-tile is 16 KiB of activations + 64 KiB of weights (80 KiB per
+//       buffer, both buffers = the CU's whole LDS), the quarters are A0 / A1 = rows 0-63 / 64-127 (one DMA piece per wave) and
+//       B0 / B1 = columns 0-31 / 32-63 of every wave's block (four pieces per wave, its OWN weight rows), so any four consecutive
+//       sections issue 1 + 1 + 4 + 4 = 10 pieces per wave: the counted wait is vmcnt(10) where the square tile has vmcnt(8).
+template <int OUT, bool MT, bool C2D = false, int STRM = 0, int TS = 0>
 __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     constexpr int ESZ = 2;
     constexpr int NST = (OUT == 0 ? 16 : 32) + 1;     // buffer stores per wave and epilogue + the next item's bias load
-    __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];
+    constexpr int BUFB = TS ? 81920 : 65536;          // bytes of one K-tile buffer
+    constexpr int WOFF = TS ? 16384 : 32768;          // the weight region's offset inside a buffer
+    constexpr int VMW = TS ? 10 : 8;                  // DMA pieces a wave issues in four consecutive sections
+    constexpr int TMS = TS ? 7 : 8, TNS = TS ? 9 : 8; // log2 of the tile's rows / columns
+    static_assert(!(TS && C2D), "the 128 x 512 tile has no 2-D tap mode");
+    __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * BUFB];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int g = wave >> 2, wq = wave & 3;
 
     // ---------------- static schedule: XCD-chunked list of work items ----------------
-    const int tiles_m = (p.M + 255) >> 8, tiles_n = (p.N + 255) >> 8;
+    const int tiles_m = (p.M + (1 << TMS) - 1) >> TMS, tiles_n = (p.N + (1 << TNS) - 1) >> TNS;
     const int ntile = tiles_m * tiles_n;
     const int kchunks = (p.K + 63) >> 6;
     const int total_kt = p.taps * kchunks;
@@ -118,20 +129,24 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // ---------------- DMA roles ----------------
     // one op = 8 rows x 128 B.  Wave (g, wq): A rows g*128 + {0, 64} + wq*16 + {0, 8} + (lane >> 3) of the tile (its own row half),
     // W rows wsel*64 + {0, 32} + (wq & 1)*16 + {0, 8} + (lane >> 3) with wsel = 2g + (wq >> 1).
+    // TS = 1: one op = 8 rows x 128 B as well.  Wave w: A rows {0, 64} + w*8 + (lane >> 3) (one op per quarter), W rows w*64 +
+    // {0, 32} + {0, 8, 16, 24} + (lane >> 3) (four ops per quarter: its own 64 weight rows).
     const int rl = lane >> 3, dp = lane & 7;
-    const int a_row0 = g * 128 + wq * 16;                      // + 64 for the A1 quarter, + 8 for the second op
-    const int w_row0 = (2 * g + (wq >> 1)) * 64 + (wq & 1) * 16;
+    const int a_row0 = TS ? wave * 8 : g * 128 + wq * 16;      // + 64 for the A1 quarter, (TS = 0) + 8 for the second op
+    const int w_row0 = TS ? wave * 64 : (2 * g + (wq >> 1)) * 64 + (wq & 1) * 16;
     // source chunk of an op: dp ^ ((row >> 1) & 7) with row = base (multiple of 16) + {0, 8} + rl
     const int dc0 = dp ^ ((rl >> 1) & 7), dc1 = dp ^ (((8 + rl) >> 1) & 7);
+    const int dcA = TS ? dp ^ ((((wave & 1) << 2) + (rl >> 1)) & 7) : dc0;       // TS = 1: the A op's rows start at a multiple of 8
     unsigned char* const ldsA0 = smem + a_row0 * 128;
     unsigned char* const ldsA1 = smem + (a_row0 + 64) * 128;
-    unsigned char* const ldsB0 = smem + 32768 + w_row0 * 128;
-    unsigned char* const ldsB1 = smem + 32768 + (w_row0 + 32) * 128;
+    unsigned char* const ldsB0 = smem + WOFF + w_row0 * 128;
+    unsigned char* const ldsB1 = smem + WOFF + (w_row0 + 32) * 128;
 
     // per-item per-lane DMA state
     uint32_t vA0, vA1, vA2, vA3;          // A0 op 0/1, A1 op 0/1: (m0 + row) * lda_b + dc * 16 (relative to the shifted base)
     uint32_t imA0, imA1, imA2, imA3;      // bit j set: tap j of that row leaves the sample window
     uint32_t vW0, vW1, vW2, vW3;          // B0 op 0/1, B1 op 0/1: (n0 + row) * ldw_b + dc * 16, or out of range
+    uint32_t vW4 = 0, vW5 = 0, vW6 = 0, vW7 = 0;     // TS = 1: B0 ops 0-3 = vW0, vW1, vW4, vW5; B1 ops 0-3 = vW2, vW3, vW6, vW7
     // load cursor (wave-uniform)
     int li = it_lo + jb;                   // item being loaded
     int l_kt = 0, l_kt_end = 0;            // K-tile of item li the cursor points at / end of its slice
@@ -184,7 +199,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     {                                                                                                         \
         int z_, tm_, tn_;                                                                                     \
         T256_TILE_OF(li, z_, tm_, tn_)                                                                        \
-        const int m0_ = tm_ << 8, n0_ = tn_ << 8;                                                             \
+        const int m0_ = tm_ << TMS, n0_ = tn_ << TNS;                                                         \
         l_kt = T256_UNI((int)((long)total_kt * z_ / p.splitk));                                               \
         l_kt_end = T256_UNI((int)((long)total_kt * (z_ + 1) / p.splitk));                                     \
         const int kci_ = T256_UNI(l_kt / p.taps);                                                             \
@@ -196,6 +211,12 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
             sA = (ld_jh * p.cv_W + ld_jw) * lda_b + ld_kcb; sW = w0_b + ld_j * wstep_b + ld_kcb;              \
             T256_ROW2D(vA0, imA0, ar_, dc0) T256_ROW2D(vA1, imA1, ar_ + 8, dc1)                               \
             T256_ROW2D(vA2, imA2, ar_ + 64, dc0) T256_ROW2D(vA3, imA3, ar_ + 72, dc1)                         \
+        } else if constexpr (TS == 1) {                                                                       \
+            sA = ld_j * lda_b + ld_kcb; sW = ld_j * wts_b + ld_kcb;                                           \
+            vA0 = (uint32_t)((long)ar_ * lda_b + dcA * 16);                                                   \
+            vA2 = (uint32_t)((long)(ar_ + 64) * lda_b + dcA * 16);                                            \
+            vA1 = vA0; vA3 = vA2;                                                                             \
+            if (MT) { T256_ROWMASK(imA0, ar_) T256_ROWMASK(imA2, ar_ + 64) imA1 = imA0; imA3 = imA2; }        \
         } else {                                                                                              \
             sA = ld_j * lda_b + ld_kcb; sW = ld_j * wts_b + ld_kcb;                                           \
             vA0 = (uint32_t)((long)ar_ * lda_b + dc0 * 16);                                                   \
@@ -209,6 +230,12 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
         vW1 = wr_ + 8 < p.N ? (uint32_t)((long)(wr_ + 8) * ldw_b + dc1 * 16) : 0x80000000u;                   \
         vW2 = wr_ + 32 < p.N ? (uint32_t)((long)(wr_ + 32) * ldw_b + dc0 * 16) : 0x80000000u;                 \
         vW3 = wr_ + 40 < p.N ? (uint32_t)((long)(wr_ + 40) * ldw_b + dc1 * 16) : 0x80000000u;                 \
+        if constexpr (TS == 1) {                                                                              \
+            vW4 = wr_ + 16 < p.N ? (uint32_t)((long)(wr_ + 16) * ldw_b + dc0 * 16) : 0x80000000u;             \
+            vW5 = wr_ + 24 < p.N ? (uint32_t)((long)(wr_ + 24) * ldw_b + dc1 * 16) : 0x80000000u;             \
+            vW6 = wr_ + 48 < p.N ? (uint32_t)((long)(wr_ + 48) * ldw_b + dc0 * 16) : 0x80000000u;             \
+            vW7 = wr_ + 56 < p.N ? (uint32_t)((long)(wr_ + 56) * ldw_b + dc1 * 16) : 0x80000000u;             \
+        }                                                                                                     \
     }
     // per-lane offset of an A op: the row's offset, pushed out of range when the cursor's tap leaves the row's window
     // (v_bfe_i32 + v_and_or_b32); offsets + scalar offsets stay below 2^31, so an invalid lane stays >= 2^31 after the add
@@ -226,23 +253,39 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // quarter issues: F = 1 fast path (cursor active, no K tail), F = 0 general; PB = byte offset of the parity buffer filled
 #define T256_ISSUE_A0(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
-        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsA, T256_VA(vA0, imA0), sA, ldsA0 + (PB)) T256_DMA(rsA, T256_VA(vA1, imA1), sA, ldsA0 + (PB) + 1024) } \
+        if constexpr (TS == 1) {                                                                              \
+            if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsA, T256_VA(vA0, imA0), sA, ldsA0 + (PB)) }          \
+            else { T256_DMA(rsA, T256_KT(T256_VA(vA0, imA0), dcA), sA, ldsA0 + (PB)) }                        \
+        } else if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsA, T256_VA(vA0, imA0), sA, ldsA0 + (PB)) T256_DMA(rsA, T256_VA(vA1, imA1), sA, ldsA0 + (PB) + 1024) } \
         else { T256_DMA(rsA, T256_KT(T256_VA(vA0, imA0), dc0), sA, ldsA0 + (PB)) T256_DMA(rsA, T256_KT(T256_VA(vA1, imA1), dc1), sA, ldsA0 + (PB) + 1024) } \
     }
 #define T256_ISSUE_A1(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
-        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsA, T256_VA(vA2, imA2), sA, ldsA1 + (PB)) T256_DMA(rsA, T256_VA(vA3, imA3), sA, ldsA1 + (PB) + 1024) } \
+        if constexpr (TS == 1) {                                                                              \
+            if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsA, T256_VA(vA2, imA2), sA, ldsA1 + (PB)) }          \
+            else { T256_DMA(rsA, T256_KT(T256_VA(vA2, imA2), dcA), sA, ldsA1 + (PB)) }                        \
+        } else if ((F) || ld_kcb + 128 <= kK_b) { T256_DMA(rsA, T256_VA(vA2, imA2), sA, ldsA1 + (PB)) T256_DMA(rsA, T256_VA(vA3, imA3), sA, ldsA1 + (PB) + 1024) } \
         else { T256_DMA(rsA, T256_KT(T256_VA(vA2, imA2), dc0), sA, ldsA1 + (PB)) T256_DMA(rsA, T256_KT(T256_VA(vA3, imA3), dc1), sA, ldsA1 + (PB) + 1024) } \
     }
 #define T256_ISSUE_B0(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
-        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMAW(vW0, ldsB0 + (PB)) T256_DMAW(vW1, ldsB0 + (PB) + 1024) } \
-        else { T256_DMAW(T256_KT(vW0, dc0), ldsB0 + (PB)) T256_DMAW(T256_KT(vW1, dc1), ldsB0 + (PB) + 1024) } \
+        if ((F) || ld_kcb + 128 <= kK_b) {                                                                    \
+            T256_DMAW(vW0, ldsB0 + (PB)) T256_DMAW(vW1, ldsB0 + (PB) + 1024)                                  \
+            if constexpr (TS == 1) { T256_DMAW(vW4, ldsB0 + (PB) + 2048) T256_DMAW(vW5, ldsB0 + (PB) + 3072) } \
+        } else {                                                                                              \
+            T256_DMAW(T256_KT(vW0, dc0), ldsB0 + (PB)) T256_DMAW(T256_KT(vW1, dc1), ldsB0 + (PB) + 1024)      \
+            if constexpr (TS == 1) { T256_DMAW(T256_KT(vW4, dc0), ldsB0 + (PB) + 2048) T256_DMAW(T256_KT(vW5, dc1), ldsB0 + (PB) + 3072) } \
+        }                                                                                                     \
     }
 #define T256_ISSUE_B1(PB, F)                                                                                  \
     if ((F) || l_active) {                                                                                    \
-        if ((F) || ld_kcb + 128 <= kK_b) { T256_DMAW(vW2, ldsB1 + (PB)) T256_DMAW(vW3, ldsB1 + (PB) + 1024) } \
-        else { T256_DMAW(T256_KT(vW2, dc0), ldsB1 + (PB)) T256_DMAW(T256_KT(vW3, dc1), ldsB1 + (PB) + 1024) } \
+        if ((F) || ld_kcb + 128 <= kK_b) {                                                                    \
+            T256_DMAW(vW2, ldsB1 + (PB)) T256_DMAW(vW3, ldsB1 + (PB) + 1024)                                  \
+            if constexpr (TS == 1) { T256_DMAW(vW6, ldsB1 + (PB) + 2048) T256_DMAW(vW7, ldsB1 + (PB) + 3072) } \
+        } else {                                                                                              \
+            T256_DMAW(T256_KT(vW2, dc0), ldsB1 + (PB)) T256_DMAW(T256_KT(vW3, dc1), ldsB1 + (PB) + 1024)      \
+            if constexpr (TS == 1) { T256_DMAW(T256_KT(vW6, dc0), ldsB1 + (PB) + 2048) T256_DMAW(T256_KT(vW7, dc1), ldsB1 + (PB) + 3072) } \
+        }                                                                                                     \
     }
     // move the load cursor to the next K-tile of the stream
 #define T256_ADVANCE(F)                                                                                       \
@@ -268,11 +311,12 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     const int q = lane >> 4, lr = lane & 15;
     const int swz = lr >> 1;
     const uint32_t smem_b = (uint32_t)(uintptr_t)(t256_lds_t*)smem;
-    const uint32_t fA0 = smem_b + (g * 128 + lr) * 128 + ((q ^ swz) << 4);                // k sub-step 0
-    const uint32_t fA1 = smem_b + (g * 128 + lr) * 128 + (((4 + q) ^ swz) << 4);          // k sub-step 1
-    const uint32_t fB0 = smem_b + 32768 + (wq * 64 + lr) * 128 + ((q ^ swz) << 4);
-    const uint32_t fB1 = smem_b + 32768 + (wq * 64 + lr) * 128 + (((4 + q) ^ swz) << 4);
-    const uint32_t fA0n = fA0 + 65536, fA1n = fA1 + 65536, fB0n = fB0 + 65536, fB1n = fB1 + 65536;
+    const int fa_row = (TS ? 0 : g * 128) + lr, fb_row = (TS ? wave * 64 : wq * 64) + lr;   // TS = 1: every wave reads all 128 rows
+    const uint32_t fA0 = smem_b + fa_row * 128 + ((q ^ swz) << 4);                        // k sub-step 0
+    const uint32_t fA1 = smem_b + fa_row * 128 + (((4 + q) ^ swz) << 4);                  // k sub-step 1
+    const uint32_t fB0 = smem_b + WOFF + fb_row * 128 + ((q ^ swz) << 4);
+    const uint32_t fB1 = smem_b + WOFF + fb_row * 128 + (((4 + q) ^ swz) << 4);
+    const uint32_t fA0n = fA0 + BUFB, fA1n = fA1 + BUFB, fB0n = fB0 + BUFB, fB1n = fB1 + BUFB;
 
     t256_f4 acc[8][4];
 #pragma unroll
@@ -327,9 +371,9 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // 2: the DMA stream has ended (sections may have issued nothing: drain)
 #define T256_LEND(F)                                                                                          \
     {                                                                                                         \
-        if (T256_ABL_NOBAR_ && (F)) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");                          \
-        else if ((F) || wmode == 0) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");                  \
-        else if (wmode == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(8 + NST) : "memory");     \
+        if (T256_ABL_NOBAR_ && (F)) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(VMW) : "memory");                \
+        else if ((F) || wmode == 0) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(VMW) : "memory");    \
+        else if (wmode == 1) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(VMW + NST) : "memory");   \
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");                                    \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
@@ -421,7 +465,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     // waves 4-7 put it after their MFMAs (reads, wait, MFMAs inside one interval, beside the early half's MFMAs and reads).
     // Every wave still executes one barrier per section, each refill still comes two barriers after the reads it overwrites,
     // and each read still comes after the barrier that follows the counted wait of every wave that issued its DMA.
-    const bool early = !T256_STAGGER || g == 0;
+    const bool early = !T256_STAGGER || g == 0;          // TS = 1: waves 0-3 / 4-7 (g is wave >> 2 there as well)
 
     // ---------------- compute cursor ----------------
     int ci = it_lo + jb;
@@ -430,7 +474,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     {                                                                                                         \
         int tm_, tn_;                                                                                         \
         T256_TILE_OF(ci, c_z, tm_, tn_)                                                                       \
-        c_m0 = tm_ << 8; c_n0 = tn_ << 8; c_tile = tn_ * tiles_m + tm_;                                       \
+        c_m0 = tm_ << TMS; c_n0 = tn_ << TNS; c_tile = tn_ * tiles_m + tm_;                                   \
         c_nkt = T256_UNI((int)((long)total_kt * (c_z + 1) / p.splitk) - (int)((long)total_kt * c_z / p.splitk)); \
     }
     T256_DECODE_C()
@@ -441,7 +485,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     const bool has_bias = (OUT == 0 || p.splitk == 1) && p.bias != nullptr;
 #define T256_LOAD_BIAS(N0)                                                                                    \
     {                                                                                                         \
-        const int col_ = (N0) + wq * 64 + lane;                                                               \
+        const int col_ = (N0) + (TS ? wave : wq) * 64 + lane;                                                 \
         const float* bp_ = has_bias ? p.bias + (col_ < p.N ? col_ : 0) : reinterpret_cast<const float*>(p.W); \
         asm volatile("global_load_dword %0, %1, off" : "=v"(bias_lane) : "v"(bp_) : "memory");                \
     }
@@ -451,9 +495,9 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
     T256_SETUP_ITEM()
     T256_ISSUE_A0(0, 0) T256_ISSUE_B0(0, 0) T256_ISSUE_B1(0, 0) T256_ISSUE_A1(0, 0)
     T256_ADVANCE(0)
-    T256_ISSUE_A0(65536, 0) T256_ISSUE_B0(65536, 0)
-    // K-tile 0's A0 / B0 must have landed: everything but the (up to) 8 youngest DMAs
-    if (l_active) asm volatile("s_waitcnt vmcnt(8)\n\ts_barrier" ::: "memory");
+    T256_ISSUE_A0(BUFB, 0) T256_ISSUE_B0(BUFB, 0)
+    // K-tile 0's A0 / B0 must have landed: everything but the (up to) VMW youngest DMAs
+    if (l_active) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" :: "n"(VMW) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
 
     int kt = 0;
@@ -463,12 +507,12 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
         // fast path: two K-tiles with compile-time parity while neither the compute cursor (last K-tile of its item) nor the load
         // cursor (item change, K tail, end of the stream) meets a boundary
         while (pb == 0 && wmode == 0 && kt + 2 < c_nkt && l_kt + 2 < l_kt_end && ld_kcb + 384 <= kK_b) {
-            T256_KTILE(fA0, fA1, fB0, fB1, 0, 65536, 1)
-            T256_KTILE(fA0n, fA1n, fB0n, fB1n, 65536, 0, 1)
+            T256_KTILE(fA0, fA1, fB0, fB1, 0, BUFB, 1)
+            T256_KTILE(fA0n, fA1n, fB0n, fB1n, BUFB, 0, 1)
             kt += 2;
         }
         {
-            const uint32_t pn = pb ^ 65536u;
+            const uint32_t pn = (uint32_t)BUFB - pb;
             const uint32_t a0_ = fA0 + pb, a1_ = fA1 + pb, b0_ = fB0 + pb, b1_ = fB1 + pb;
             T256_KTILE(a0_, a1_, b0_, b1_, pb, pn, 0)
             ++kt;
@@ -476,7 +520,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
         }
         if (kt == c_nkt) {
             // ================= epilogue of item ci =================
-            const int mw = c_m0 + g * 128, nw = c_n0 + wq * 64;
+            const int mw = c_m0 + (TS ? 0 : g * 128), nw = c_n0 + (TS ? wave : wq) * 64;
             asm volatile("" : "+v"(bias_lane));
             float bv[4][4];          // bias of the lane's 16 columns nt*16 + 4q + r
 #pragma unroll
@@ -606,13 +650,16 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
 
 // Fixed-order reduction of the per-(item, wave) statistics partials into GroupNorm sums [sample][group][2] (fp64).
 // One 64-thread block per (sample, group); each thread walks a fixed subset of the candidate entries.
-__global__ __launch_bounds__(64) void t256_stats_finalize_kernel(const float* part, double* sums, int M, int N, int Tlen, int Cg, int G) {
+// ts: tile shape of the launch that wrote the partials (0: 256 x 256, wave (g, wq) = 128 rows x 64 columns at (g*128, wq*64);
+// 1: 128 x 512, wave w = 128 rows x 64 columns at (0, w*64))
+__global__ __launch_bounds__(64) void t256_stats_finalize_kernel(const float* part, double* sums, int M, int N, int Tlen, int Cg, int G, int ts) {
     const int b = blockIdx.x / G, gi = blockIdx.x - b * G;
-    const int tiles_m = (M + 255) >> 8;
+    const int tms = ts ? 7 : 8, tns = ts ? 9 : 8;
+    const int tiles_m = (M + (1 << tms) - 1) >> tms;
     const int r_lo = b * Tlen, r_hi = min((b + 1) * Tlen, M);          // rows of this sample
     const int c_lo = gi * Cg, c_hi = (gi + 1) * Cg;
-    const int tm_lo = r_lo >> 8, tm_hi = (r_hi - 1) >> 8;
-    const int tn_lo = c_lo >> 8, tn_hi = (c_hi - 1) >> 8;
+    const int tm_lo = r_lo >> tms, tm_hi = (r_hi - 1) >> tms;
+    const int tn_lo = c_lo >> tns, tn_hi = (c_hi - 1) >> tns;
     const int n_tm = tm_hi - tm_lo + 1, n_tn = tn_hi - tn_lo + 1;
     const int total = n_tm * n_tn * 8;
     double s1 = 0.0, s2 = 0.0;
@@ -621,7 +668,7 @@ __global__ __launch_bounds__(64) void t256_stats_finalize_kernel(const float* pa
         const int t = e >> 3;
         const int tn = tn_lo + t / n_tm, tm = tm_lo + t % n_tm;
         const int item = tn * tiles_m + tm;                            // split-K 1: item index = tile index
-        const int mw = (tm << 8) + (wave >> 2) * 128, nw = (tn << 8) + (wave & 3) * 64;
+        const int mw = ts ? (tm << 7) : (tm << 8) + (wave >> 2) * 128, nw = ts ? (tn << 9) + wave * 64 : (tn << 8) + (wave & 3) * 64;
         const int rb = (mw / Tlen + 1) * Tlen, cb = (nw / Cg + 1) * Cg;
         const float* v = part + ((long)item * 8 + wave) * 8;
         const double A1 = v[0], A2 = v[1], R1 = v[2], R2 = v[3], C1 = v[4], C2 = v[5], B1 = v[6], B2 = v[7];
@@ -719,8 +766,9 @@ int gemm_nt256_pick_splitk(int M, int N, int K, int taps) {
     }
     return best;
 }
-size_t gemm_nt256_part_floats(int M, int N, int splitk) {
-    return (size_t)t256_cdiv(M, 256) * t256_cdiv(N, 256) * (size_t)(splitk < 1 ? 1 : splitk) * 64;
+size_t gemm_nt256_part_floats(int M, int N, int splitk) {       // either tile shape: 64 floats per work item
+    const size_t t0 = (size_t)t256_cdiv(M, 256) * t256_cdiv(N, 256), t1 = (size_t)t256_cdiv(M, 128) * t256_cdiv(N, 512);
+    return (t0 > t1 ? t0 : t1) * (size_t)(splitk < 1 ? 1 : splitk) * 64;
 }
 
 int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
@@ -730,6 +778,9 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
     if (p.splitk < 1 || total_kt / p.splitk < 4) return -1;
     if (p.gn_part && (p.splitk != 1 || p.out_f32 || p.Tlen < 128 || p.gn_Cg < 64 || p.gn_Cg % 4 || p.gn_G < 1 || !p.gn_sums)) return -1;
     if (p.add_W > 0) return -1;          // the strided addend is the 128-row kernel's (gemm_nt_plan keeps such a product there)
+    const int ts = p.ts ? 1 : 0;         // 128 x 512 tiles: no 2-D taps, no stream policies, at least one full tile width
+    if (ts && (p.cv_kw > 0 || p.N < 512 || p.row0)) return -1;
+    const int TH = ts ? 128 : 256, TW = ts ? 512 : 256;
     GemmNT q = p;
     const long arows = p.a_rows > p.M ? p.a_rows : p.M;
     q.a_bytes = ((arows - 1) * p.lda + p.K) * 2;
@@ -742,8 +793,8 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
     static const int band_env = getenv("SGV_T256_BAND") ? atoi(getenv("SGV_T256_BAND")) : -1;
     static const int strm_env = getenv("SGV_T256_STRM") ? atoi(getenv("SGV_T256_STRM")) : -1;
     {
-        const int tm_all = t256_cdiv(p.M, 256), tn_all = t256_cdiv(p.N, 256);
-        const long a_tile_bytes = 256L * p.K * 2 * p.taps;
+        const int tm_all = t256_cdiv(p.M, TH), tn_all = t256_cdiv(p.N, TW);
+        const long a_tile_bytes = (long)TH * p.K * 2 * p.taps;
         int band = p.band, strm = p.strm;                                // 0: chosen here; < 0: off (tests)
         if (band == 0 && strm == 0 && !p.cv_kw && p.taps == 1 && p.splitk == 1 && tn_all >= 64 && (long)tm_all * a_tile_bytes > (7L << 19)) {
             band = (int)((7L << 19) / a_tile_bytes);                     // row tiles whose activations fit 3.5 MiB
@@ -756,13 +807,21 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
         if (strm_env >= 0 && p.strm == 0) strm = strm_env;
         if (band < 0 || band >= tm_all) band = 0;
         if (strm < 0) strm = 0;
-        q.band = band; q.strm = (!p.cv_kw && p.taps == 1 && !(p.splitk > 1 || p.out_f32)) ? (strm & 3) : 0;
+        q.band = band; q.strm = (!ts && !p.cv_kw && p.taps == 1 && !(p.splitk > 1 || p.out_f32)) ? (strm & 3) : 0;
     }
-    const int nitems = t256_cdiv(p.M, 256) * t256_cdiv(p.N, 256) * p.splitk;
+    const int nitems = t256_cdiv(p.M, TH) * t256_cdiv(p.N, TW) * p.splitk;
     int grid = ((nitems + 7) / 8) * 8;
     if (grid > 256) grid = 256;
     const bool f32 = p.splitk > 1 || p.out_f32;
-    if (p.cv_kw > 0) {
+    if (ts) {
+        if (p.taps > 1) {
+            if (f32) hipLaunchKernelGGL((gemm_nt_t256_kernel<1, true, false, 0, 1>), dim3(grid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((gemm_nt_t256_kernel<0, true, false, 0, 1>), dim3(grid), dim3(512), 0, s, q);
+        } else {
+            if (f32) hipLaunchKernelGGL((gemm_nt_t256_kernel<1, false, false, 0, 1>), dim3(grid), dim3(512), 0, s, q);
+            else hipLaunchKernelGGL((gemm_nt_t256_kernel<0, false, false, 0, 1>), dim3(grid), dim3(512), 0, s, q);
+        }
+    } else if (p.cv_kw > 0) {
         if (p.taps % p.cv_kw || p.cv_S < 1 || p.cv_P < 0 || p.cv_H < 1 || p.cv_W < 1 || p.cv_Ho < 1 || p.cv_Wo < 1) return -1;
         if (p.M % (p.cv_Ho * p.cv_Wo) || p.a_rows != (long)(p.M / (p.cv_Ho * p.cv_Wo)) * p.cv_H * p.cv_W) return -1;
         if (p.gn_part || p.row0) return -1;
@@ -786,25 +845,28 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s) {
     }
     if (p.gn_part) {
         const int B = t256_cdiv(p.M, p.Tlen);
-        hipLaunchKernelGGL(t256_stats_finalize_kernel, dim3(B * p.gn_G), dim3(64), 0, s, p.gn_part, p.gn_sums, p.M, p.N, p.Tlen, p.gn_Cg, p.gn_G);
+        hipLaunchKernelGGL(t256_stats_finalize_kernel, dim3(B * p.gn_G), dim3(64), 0, s, p.gn_part, p.gn_sums, p.M, p.N, p.Tlen, p.gn_Cg, p.gn_G, ts);
     }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 
 // ---- kernel choice -------------------------------------------------------------------------------------------------
 // costs in units of one K-tile of the 256 kernel (~1.7 us): measured on MI355X with tests/micro/g256_harness.hip
-static double t256_cost(int M, int N, long total_kt, int sk) {
-    const double items = (double)t256_cdiv(M, 256) * t256_cdiv(N, 256) * sk;
+static double t256_cost(int M, int N, long total_kt, int sk, int ts = 0) {
+    const double items = (double)t256_cdiv(M, ts ? 128 : 256) * t256_cdiv(N, ts ? 512 : 256) * sk;
     const double rounds = ceil(items / 256.0);
-    double c = rounds * (ceil((double)total_kt / sk) + 2.5) + 3.0;
+    // a K-tile of the 128 x 512 tile moves 80 KiB instead of 64 and issues 10 DMA pieces per wave instead of 8: measured 11-13 %
+    // longer (5120 x 5120 x 5 taps: 630 us in one round of 250 items = the 256 x 256 kernel's 565 us + its 65 us tail)
+    static const double wide_kt = getenv("SGV_T256_WIDE_KT") ? atof(getenv("SGV_T256_WIDE_KT")) : 1.13;
+    double c = rounds * (ceil((double)total_kt / sk) * (ts ? wide_kt : 1.0) + 2.5) + 3.0;
     if (sk > 1) c += (2.0 * sk * (double)M * N * 4.0 / 3.5e12) / 1.7e-6 + 4.0;
     return c;
 }
-static int t256_best_sk(int M, int N, long total_kt, size_t partial_floats, double* cost) {
+static int t256_best_sk(int M, int N, long total_kt, size_t partial_floats, double* cost, int ts = 0) {
     int best = 1; double bc = 1e30;
     for (int sk = 1; sk <= 32; ++sk) {
         if (sk > 1 && (total_kt / sk < 24 || (size_t)sk * M * N > partial_floats)) break;
-        const double c = t256_cost(M, N, total_kt, sk);
+        const double c = t256_cost(M, N, total_kt, sk, ts);
         if (c < bc * 0.97) { bc = c; best = sk; }
     }
     if (cost) *cost = bc;
@@ -824,9 +886,20 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
         return pl;
     }
     const bool stats_ok = want_stats && p.Tlen >= 128 && p.gn_Cg >= 64 && p.gn_Cg % 4 == 0;
-    double c_all, c_main = 1e30;
+    // the 128 x 512 tile (kind 3): all rows in 128-row tiles, no tail launch.  SGV_T256_WIDE: 0 never, 1 where the cost model
+    // prefers it (default), 2 wherever it is eligible
+    static const int wide = getenv("SGV_T256_WIDE") ? atoi(getenv("SGV_T256_WIDE")) : 1;
+    // at least four column tiles (N >= 2048): with two (N = 1024: the K = 95 008 and 5120 -> 1024 layers) every workgroup re-reads
+    // half of the weight matrix for 128 rows of output and the tile measured slower than main + tail (70.6 vs 64.5 us, 613 vs 605 us)
+    const bool wide_ok = wide && !p.cv_kw && p.N >= (wide == 2 ? 512 : 2048) && p.ts >= 0;
+    double c_all, c_main = 1e30, c_wide = 1e30;
     const int sk_all = stats_ok ? 1 : t256_best_sk(p.M, p.N, total_kt, partial_floats, &c_all);
-    if (stats_ok) { pl.kind = 1; pl.sk_main = 1; pl.fuse_stats = 1; return pl; }
+    if (stats_ok) {
+        pl.kind = 1; pl.sk_main = 1; pl.fuse_stats = 1;
+        if (wide_ok && wide == 2) pl.kind = 3;        // the recon head measured the same either way (592 vs 594 us): it keeps its banded 256 x 256 order
+        return pl;
+    }
+    const int sk_wide = wide_ok ? t256_best_sk(p.M, p.N, total_kt, partial_floats, &c_wide, 1) : 1;
     const int rem = p.M & 255;
     int sk_main = 1, sk_tail = 1;
     if (rem > 0 && rem <= 128 && p.M - rem >= 256 && !p.cv_kw) {
@@ -839,6 +912,7 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
     }
     if (c_main < c_all) { pl.kind = 2; pl.sk_main = sk_main; pl.sk_tail = sk_tail; pl.m_main = p.M - rem; }
     else { pl.kind = 1; pl.sk_main = sk_all; }
+    if (wide_ok && (wide == 2 || c_wide < (c_main < c_all ? c_main : c_all))) { pl.kind = 3; pl.sk_main = sk_wide; pl.sk_tail = 1; pl.m_main = p.M; }
     return pl;
 }
 int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s) {
@@ -849,7 +923,9 @@ int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipSt
     GemmNT q = p;
     q.splitk = pl.sk_main;
     if (!pl.fuse_stats) { q.gn_part = nullptr; q.gn_sums = nullptr; }
-    if (pl.kind == 1) return launch_gemm_nt256(q, s);
+    if (pl.kind == 1) { q.ts = 0; return launch_gemm_nt256(q, s); }
+    if (pl.kind == 3) { q.ts = 1; return launch_gemm_nt256(q, s); }
+    q.ts = 0;
     q.M = pl.m_main; q.a_rows = p.M;
     int r = launch_gemm_nt256(q, s);
     if (r) return r;

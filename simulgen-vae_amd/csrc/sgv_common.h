@@ -162,6 +162,8 @@ struct GemmNT {
     // gemm256.hip item order, filled by launch_gemm_nt256: band > 0 = row tiles in bands of `band` (band-major list);
     // strm = cache policy of the weight / output streams (bit 0: non-temporal weight loads, bit 1: sc1 output stores)
     int band, strm;
+    int ts;                         // tile shape of the 256-thread... 512-thread persistent kernel: 0 = 256 x 256, 1 = 128 x 512 (set by
+                                    // launch_gemm_nt_planned from the plan; tests set it directly); < 0: the planner must not pick 128 x 512
 };
 // gemm256.hip
 bool gemm_nt256_eligible(int dtype, const GemmNT& p);
@@ -169,7 +171,8 @@ int gemm_nt256_pick_splitk(int M, int N, int K, int taps);
 size_t gemm_nt256_part_floats(int M, int N, int splitk);
 int launch_gemm_nt256(const GemmNT& p, hipStream_t s);
 // Kernel choice for one NT GEMM / implicit-GEMM convolution (gemm256.hip): kind 0 = 128x128 / 128x256 kernels of gemm.hip,
-// 1 = 256x256 persistent kernel over all rows, 2 = 256x256 kernel over the first m_main rows (a multiple of 256) + the
+// 1 = 256x256 persistent kernel over all rows, 3 = the same kernel with 128 x 512 tiles over all rows (M = 3200 = 25 row tiles:
+// no tail), 2 = 256x256 kernel over the first m_main rows (a multiple of 256) + the
 // gemm.hip kernels over the remaining <= 128 rows (M = 3200 is 12.5 row tiles: thirteen 256-row tiles would need two rounds
 // of the 256 workgroups where 12 x N/256 fit one).  fuse_stats: the GroupNorm statistics can come from the GEMM epilogue
 // deterministically (kind 1, split-K 1).

@@ -182,6 +182,15 @@ NT256_CASES = [
     (3100, 2048, 512, 1, 200, 1, 0 | (7 << 8) | (2 << 16)),   # bands of 7 + 6, ragged last row tile, sc1 output stores
     (3200, 1280, 320, 3, 200, 2, 0 | (4 << 8)),               # bands with taps and split-K slices
     (3200, 16640, 512, 1, 200, 1, 0),                         # the launcher's own choice for a one-tap product with >= 64 column panels
+    # 128 x 512 tiles (bit 19): all eight waves share the 128 rows, 80 KiB K-tile buffers, vmcnt(10)
+    (256, 512, 512, 1, 128, 1, 0 | (1 << 19)),               # two row tiles of one column tile
+    (3200, 1024, 1032, 5, 200, 1, 0 | (1 << 19)),            # 25 row tiles x 2 column tiles, five taps, K tail of 8
+    (3200, 1536, 4104, 1, 200, 3, 0 | (1 << 19)),            # split-K slabs with a K tail in the last slice
+    (3000, 1288, 520, 3, 200, 1, 0 | (1 << 19)),             # ragged last row / column tile, sample boundaries inside the tiles
+    (3200, 5120, 640, 3, 200, 1, 0 | (1 << 19)),             # 250 items: one round of the chip
+    (3200, 10240, 256, 5, 200, 1, 0 | (1 << 19) | (5 << 8)), # 500 items, row tiles in bands of 5: item transitions inside a workgroup
+    (256, 512, 95008, 1, 128, 4, 0 | (1 << 19)),             # the first encoder layer's K, four slices
+    (3200, 2560, 1280, 5, 200, 0, 1 | (2 << 19)),            # planned with the 128 x 512 tile forbidden: main + tail as in round 2
 ]
 
 
@@ -215,7 +224,9 @@ def test_gemm_nt256(case):
                                  taps, Tlen, splitk, 0, mode, 0, None, C.byref(kind), None)
     assert rc == 0, lib.sgv_last_error()
     if base == 1:
-        assert (kind.value in (1, 2)) if N * K * taps >= 1024 * 1280 * 5 else kind.value == 0, kind.value
+        if (mode >> 19) & 3 == 2:
+            assert kind.value != 3, kind.value
+        assert (kind.value in (1, 2, 3)) if N * K * taps >= 1024 * 1280 * 5 else kind.value == 0, kind.value
     want = _bf16_round(ref.astype(np.float32)).astype(np.float64) + add        # the kernels round before adding the addend
     got2 = out2.float().cpu().numpy()
     assert np.isfinite(got2).all()
@@ -230,6 +241,8 @@ NT256_STATS_CASES = [
     (3200, 2048, 512, 1, 200, 256),      # several items per workgroup
     (3200, 2048, 512, 1, 200, 256, 4),   # the same with the row tiles in bands of 4: the statistics partials are indexed by tile, not by list position
     (3000, 4224, 512, 1, 200, 132, 6),   # bands of 6 + 6, ragged last row tile, groups inside column blocks
+    (3200, 2048, 512, 1, 200, 256, 0, 1),   # 128 x 512 tiles: wave w = 128 rows x 64 columns at (0, 64 w)
+    (3000, 4224, 520, 1, 200, 132, 9, 1),   # the same with bands of 9 row tiles, ragged tiles, groups inside column blocks, K tail
 ]
 
 
@@ -241,6 +254,8 @@ def test_gemm_nt256_stats_epilogue(case):
     lib = E.load_library()
     M, N, K, taps, Tlen, Cg = case[:6]
     order = (case[6] << 8) | (3 << 16) if len(case) > 6 else 0     # bands + non-temporal weights + sc1 output
+    if len(case) > 7 and case[7]:
+        order = ((case[6] or 255) << 8) | (1 << 19)                # 128 x 512 tiles (no stream policies there)
     rng = np.random.default_rng(37)
     A = _bf16_round(rng.standard_normal((M, K)).astype(np.float32))
     W = _bf16_round(rng.standard_normal((taps, N, K)).astype(np.float32) * 0.1)
