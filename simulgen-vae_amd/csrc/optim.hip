@@ -284,7 +284,19 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
 // modified by the forward itself).  Saves two full passes over the 1.6 GB of master weights per step.
 // GLP: the gradient is read from the bf16 data-parallel wire copy (g_lp, same element offsets as the fp32 arena g_base) instead of
 // the arena -- the averaged bucket goes straight from the collective into the update, no unpack pass in between.
-template <typename T, bool GLP = false>
+// NTM: cache policy of the once-per-step streams.  bit 0: moments m / v (read once, written once, next touched a step later),
+// bit 1: the fp32 gradient read, bit 2: the fp32 master weight -- non-temporal, so that 12.6 GB per step do not sweep the operand
+// panels of the GEMMs running beside this pass out of L2 / Infinity Cache.
+typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
+    if constexpr (NT) { const f32x4_nt v = __builtin_nontemporal_load(reinterpret_cast<const f32x4_nt*>(p)); return make_float4(v[0], v[1], v[2], v[3]); }
+    else return *reinterpret_cast<const float4*>(p);
+}
+template <bool NT> __device__ __forceinline__ void st4(float* p, const float4 v) {
+    if constexpr (NT) { f32x4_nt o; o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w; __builtin_nontemporal_store(o, reinterpret_cast<f32x4_nt*>(p)); }
+    else *reinterpret_cast<float4*>(p) = v;
+}
+template <typename T, bool GLP = false, int NTM = 0>
 __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
                                                       float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
                                                       double* gnorm_sq, const float* g_base = nullptr, const uint16_t* g_lp = nullptr) {
@@ -324,11 +336,11 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
                 g.x = __builtin_bit_cast(float, raw.x << 16); g.y = __builtin_bit_cast(float, raw.x & 0xFFFF0000u);
                 g.z = __builtin_bit_cast(float, raw.y << 16); g.w = __builtin_bit_cast(float, raw.y & 0xFFFF0000u);
             } else {
-                g = *reinterpret_cast<const float4*>(a.g + i);
+                g = ld4<(NTM & 2) != 0>(a.g + i);
             }
-            p = *reinterpret_cast<const float4*>(a.p + i);
-            float4 m = *reinterpret_cast<const float4*>(a.m + i);
-            float4 vs = *reinterpret_cast<const float4*>(a.v + i);
+            p = ld4<(NTM & 4) != 0>(a.p + i);
+            float4 m = ld4<(NTM & 1) != 0>(a.m + i);
+            float4 vs = ld4<(NTM & 1) != 0>(a.v + i);
             const float u_r = d.u[row];
             const float ur = u_r * cdot;
             g.x = (g.x - ur * vv.x) * inv_sigma; g.y = (g.y - ur * vv.y) * inv_sigma;
@@ -341,9 +353,9 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
             p.F -= step * (m.F / (sqrtf(vs.F) / bc2sqrt + eps));
             SGV_ADAM1(x) SGV_ADAM1(y) SGV_ADAM1(z) SGV_ADAM1(w)
 #undef SGV_ADAM1
-            *reinterpret_cast<float4*>(a.p + i) = p;
-            *reinterpret_cast<float4*>(a.m + i) = m;
-            *reinterpret_cast<float4*>(a.v + i) = vs;
+            st4<(NTM & 4) != 0>(a.p + i, p);
+            st4<(NTM & 1) != 0>(a.m + i, m);
+            st4<(NTM & 1) != 0>(a.v + i, vs);
             if constexpr (sizeof(T) == 2) {
                 if (wc) {
                     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -380,14 +392,21 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* g_base, const void* g_lp) {
     if (n <= 0) return 0;
-    if (g_lp) {
-        const uint16_t* lp = reinterpret_cast<const uint16_t*>(g_lp);
-        if (compute_dtype == 1) hipLaunchKernelGGL((adamw_sn_kernel<bf16_t, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp);
-        else hipLaunchKernelGGL((adamw_sn_kernel<float, true>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp);
-        return hipGetLastError() == hipSuccess ? 0 : -2;
+    // default 1: the moments bypass the caches (measured, DESIGN.md section 13: 12.20 -> 12.05 ms per step, the pass alone 2.90 -> 2.70 ms)
+    static const int ntm = getenv("SGV_ADAM_NT") ? atoi(getenv("SGV_ADAM_NT")) : 1;
+    const uint16_t* lp = reinterpret_cast<const uint16_t*>(g_lp);
+#define SGV_ADAM_LAUNCH(TT, GLP, MODE) hipLaunchKernelGGL((adamw_sn_kernel<TT, GLP, MODE>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp)
+#define SGV_ADAM_MODES(TT, GLP)                                   \
+    switch (ntm) {                                                \
+        case 0: SGV_ADAM_LAUNCH(TT, GLP, 0); break;               \
+        case 3: SGV_ADAM_LAUNCH(TT, GLP, 3); break;               \
+        case 5: SGV_ADAM_LAUNCH(TT, GLP, 5); break;               \
+        default: SGV_ADAM_LAUNCH(TT, GLP, 1); break;              \
     }
-    if (compute_dtype == 1) hipLaunchKernelGGL((adamw_sn_kernel<bf16_t, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, (const float*)nullptr, (const uint16_t*)nullptr);
-    else hipLaunchKernelGGL((adamw_sn_kernel<float, false>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, (const float*)nullptr, (const uint16_t*)nullptr);
+    if (compute_dtype == 1) { if (lp) { SGV_ADAM_MODES(bf16_t, true) } else { SGV_ADAM_MODES(bf16_t, false) } }
+    else { if (lp) { SGV_ADAM_MODES(float, true) } else { SGV_ADAM_MODES(float, false) } }
+#undef SGV_ADAM_MODES
+#undef SGV_ADAM_LAUNCH
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
 int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
