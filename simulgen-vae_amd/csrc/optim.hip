@@ -285,7 +285,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(const AdamDesc* adam, const 
 // GLP: the gradient is read from the bf16 data-parallel wire copy (g_lp, same element offsets as the fp32 arena g_base) instead of
 // the arena -- the averaged bucket goes straight from the collective into the update, no unpack pass in between.
 // NTM: cache policy of the once-per-step streams.  bit 0: moments m / v (read once, written once, next touched a step later),
-// bit 1: the fp32 gradient read, bit 2: the fp32 master weight -- non-temporal, so that 12.6 GB per step do not sweep the operand
+// bit 1: the fp32 gradient read, bit 2: the fp32 master weight, bit 3: the bf16 operand copies (read by next step's GEMMs, 1.6 GB
+// later) -- non-temporal, so that 12.6 GB per step do not sweep the operand
 // panels of the GEMMs running beside this pass out of L2 / Infinity Cache.
 typedef float f32x4_nt __attribute__((ext_vector_type(4)));
 template <bool NT> __device__ __forceinline__ float4 ld4(const float* p) {
@@ -361,7 +362,10 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
                     typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
                     bf16x4_t o;
                     o[0] = (__bf16)p.x; o[1] = (__bf16)p.y; o[2] = (__bf16)p.z; o[3] = (__bf16)p.w;
-                    *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(a.wc) + i) = o;
+                    if constexpr ((NTM & 8) != 0) {
+                        typedef int i32x2_t __attribute__((ext_vector_type(2)));
+                        __builtin_nontemporal_store(__builtin_bit_cast(i32x2_t, o), reinterpret_cast<i32x2_t*>(reinterpret_cast<__bf16*>(a.wc) + i));
+                    } else *reinterpret_cast<bf16x4_t*>(reinterpret_cast<__bf16*>(a.wc) + i) = o;
                 }
             }
             t0 += p.x * u_r; t1 += p.y * u_r; t2 += p.z * u_r; t3 += p.w * u_r;
@@ -385,15 +389,19 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
         const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
         for (int r = ty; r < 64; r += 4) {
             const int cc = c0 + r, row = r0 + tx;
-            if (row < a.rows && cc < a.cols) dst[(long)cc * a.rows + row] = tile[tx * PITCH + r];
+            if (row < a.rows && cc < a.cols) {
+                if constexpr ((NTM & 8) != 0 && sizeof(T) == 2) __builtin_nontemporal_store(__builtin_bit_cast(unsigned short, tile[tx * PITCH + r]), reinterpret_cast<unsigned short*>(dst) + (long)cc * a.rows + row);
+                else dst[(long)cc * a.rows + row] = tile[tx * PITCH + r];
+            }
         }
     }
 }
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* g_base, const void* g_lp) {
     if (n <= 0) return 0;
-    // default 1: the moments bypass the caches (measured, DESIGN.md section 13: 12.20 -> 12.05 ms per step, the pass alone 2.90 -> 2.70 ms)
-    static const int ntm = getenv("SGV_ADAM_NT") ? atoi(getenv("SGV_ADAM_NT")) : 1;
+    // default 9: the moments and the bf16 operand copies bypass the caches (measured, DESIGN.md section 13: moments 12.20 -> 12.05 ms
+    // per step, the pass alone 2.90 -> 2.70 ms; the copies another 0.07 ms over eleven alternations)
+    static const int ntm = getenv("SGV_ADAM_NT") ? atoi(getenv("SGV_ADAM_NT")) : 9;
     const uint16_t* lp = reinterpret_cast<const uint16_t*>(g_lp);
 #define SGV_ADAM_LAUNCH(TT, GLP, MODE) hipLaunchKernelGGL((adamw_sn_kernel<TT, GLP, MODE>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp)
 #define SGV_ADAM_MODES(TT, GLP)                                   \
@@ -401,7 +409,8 @@ int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem*
         case 0: SGV_ADAM_LAUNCH(TT, GLP, 0); break;               \
         case 3: SGV_ADAM_LAUNCH(TT, GLP, 3); break;               \
         case 5: SGV_ADAM_LAUNCH(TT, GLP, 5); break;               \
-        default: SGV_ADAM_LAUNCH(TT, GLP, 1); break;              \
+        case 1: SGV_ADAM_LAUNCH(TT, GLP, 1); break;               \
+        default: SGV_ADAM_LAUNCH(TT, GLP, 9); break;              \
     }
     if (compute_dtype == 1) { if (lp) { SGV_ADAM_MODES(bf16_t, true) } else { SGV_ADAM_MODES(bf16_t, false) } }
     else { if (lp) { SGV_ADAM_MODES(float, true) } else { SGV_ADAM_MODES(float, false) } }
