@@ -2383,9 +2383,19 @@ static AdamCoef adam_coef(const sgv_engine* e) {
 static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, bool from_lp) {
     if (t1 <= t0) return 0;
     const AdamCoef c = adam_coef(e);
-    if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + t0, t1 - t0, lr, c.b1, c.b2, 1e-8f, 0.01f, c.bc1, c.bc2s, e->gnorm_part + e->n_items_adam_flat + t0, e->dt, st,
-                     e->grads, from_lp ? e->grads_lp : nullptr))
-        return fail(SGV_ERR_HIP, "adamw launch failed");
+    // Beside the backward pass (any stream but the main one) the pass goes out in slices of a few thousand 64 x 64 tiles: its
+    // workgroups are small and short-lived, so while one launch lasts they refill every CU the moment a slot frees, and a kernel of
+    // the main stream whose workgroup needs most of a CU's LDS (the 128-row GEMM tails, the fused Conv+GroupNorm stages) is not
+    // placed until the launch ends -- a kernel trace showed a 60 us tail taking 816 us beside a 1.3 ms AdamW launch.  At a launch
+    // boundary the chip drains, and the waiting workgroups get their CUs.
+    static const int slice_env = getenv("SGV_ADAM_SLICE") ? atoi(getenv("SGV_ADAM_SLICE")) : 2048;
+    const int slice = (st != e->stream && slice_env > 0) ? slice_env : t1 - t0;
+    for (int a = t0; a < t1; a += slice) {
+        const int b = std::min(t1, a + slice);
+        if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + a, b - a, lr, c.b1, c.b2, 1e-8f, 0.01f, c.bc1, c.bc2s, e->gnorm_part + e->n_items_adam_flat + a, e->dt, st,
+                         e->grads, from_lp ? e->grads_lp : nullptr))
+            return fail(SGV_ERR_HIP, "adamw launch failed");
+    }
     return 0;
 }
 static void unpack_bucket(sgv_engine* e, int b, hipStream_t st) {
