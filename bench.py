@@ -212,6 +212,7 @@ def main():
     ap.add_argument("--cpu-timed-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=16)
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-prefetch", action="store_true", help="build every batch at the start of its own step (sgv_augment_collate) instead of beside the previous step (sgv_augment_stage / sgv_augment_advance, the training loop's way)")
     ap.add_argument("--host-times", action="store_true", help="diagnostic: print the host's time inside each engine call")
     ap.add_argument("--recompute", action="store_true",
                     help="measurement only: regenerate the GroupNorm + GELU outputs in backward (what configs[3]'s '+ grad-checkpoint' would cost); "
@@ -287,7 +288,7 @@ def main():
     nprng = np.random.RandomState(5)
     epochs_beta = 1e-4   # WarmupKLLoss initial beta (train.py:75-81)
 
-    def one_step(step_idx):
+    def draw_plan():
         # AugmentedDataset decisions (augmentation.py:58-84) drawn on the host, applied on the device
         idx, seeds, scale, mix, lam = [], [], [], [], []
         for g in range(B * world):
@@ -303,7 +304,18 @@ def main():
                 m_, l_ = -1, 1.0
             if g % world == rank:
                 idx.append(i_); seeds.append(sd_); scale.append(sc_); mix.append(m_); lam.append(l_)
-        eng.augment_collate(data, idx, seeds, scale, mix, lam)
+        return idx, seeds, scale, mix, lam
+
+    prefetch = not args.no_prefetch and os.environ.get("SGV_BENCH_NO_PREFETCH") != "1"     # the env form is for A/B scripts
+    if prefetch:
+        eng.augment_stage(data, *draw_plan())          # modules/train.py's loop: batch i + 1 is built beside step i
+
+    def one_step(step_idx):
+        if prefetch:
+            eng.augment_advance()
+            eng.augment_stage(data, *draw_plan())
+        else:
+            eng.augment_collate(data, *draw_plan())
         eng.forward(train=True, sync=False)
         if ddp:
             allreduce.backward_step(eng, ALPHA, epochs_beta, LR)      # one rank: the fused single-GPU step, no collective

@@ -256,6 +256,18 @@ int sgv_scalars_read(sgv_engine* e, double* host16, int reset);
 int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const int32_t* idx,
                         const uint64_t* noise_seed, const float* scale, const int32_t* mix_idx,
                         const float* lam);
+/* The same batch construction, prefetched (the reference's DataLoader builds batch i + 1 in worker processes while step i
+ * runs, modules/data_processing.py + torch DataLoader prefetch; here the GPU builds it beside the step):
+ * sgv_augment_stage enqueues the augmentation of the NEXT batch into a second input buffer on a stream of its own -- its
+ * kernels are launched from inside the next forward pass, behind the first encoder layer -- and returns at once;
+ * sgv_augment_advance makes the staged batch the current input (what sgv_augment_collate does in one call).  Staging again
+ * before advancing replaces the staged batch.  The current batch, its forward / backward and sgv_set_input are untouched by a
+ * staged one.  sgv_augment_advance without a staged batch: SGV_ERR_STATE.  Same bytes as sgv_augment_collate for the same
+ * arguments.  Loop:  stage(0); for i: advance(); stage(i + 1); forward; backward_step. */
+int sgv_augment_stage(sgv_engine* e, const void* dataset_dev, int batch, const int32_t* idx,
+                      const uint64_t* noise_seed, const float* scale, const int32_t* mix_idx,
+                      const float* lam);
+int sgv_augment_advance(sgv_engine* e);
 /* utils.Dataset.__init__ with load_all (utils.py:41-43): device fp32 [count, num_node, num_time]
  * -> internal [count][num_time][num_node] in compute dtype at dst_dev. */
 int sgv_dataset_convert(sgv_engine* e, const float* src_dev, void* dst_dev, int count);

@@ -194,6 +194,18 @@ struct sgv_engine {
     int last_lin = -1, start_lin = -1;
     // tensors
     Tensor x_in, xhat, sbuf, d_sbuf, dy_recon;
+    // Prefetched augmentation (sgv_augment_stage / sgv_augment_advance): the NEXT batch is built in the spare input buffer on a
+    // stream of its own, in launches of a few samples, beside the short kernels that follow the first encoder layer's GEMM (the
+    // chip's HBM is idle there); the reference hides the same work in DataLoader worker processes.
+    Tensor x_bufs[2];
+    int x_cur = 0;
+    hipStream_t aug_stream = nullptr;
+    hipEvent_t aug_done = nullptr, aug_gate = nullptr, x_free[2] = {nullptr, nullptr};
+    bool x_free_set[2] = {false, false};
+    bool aug_staged = false, aug_fired = false, aug_pending = false;   // staged: control arrays on the device; fired: kernels enqueued; pending: the current batch's kernels may still run
+    const void* aug_data = nullptr;
+    int aug_next_batch = 0;
+    char* aug_ctl = nullptr;           // control arrays of the staged batch
     std::vector<Tensor> enc_h, d_h, enc_a_dummy, zs, dzs, cat, dcat, dec_out, d_out, d_u, d_pres, d_qres, d_outp, gp, gq, xl, d_xl;
     std::vector<float*> xs_raw, d_xs_raw, eps, zmap;
     std::vector<int> eps_set;
@@ -527,7 +539,8 @@ static int alloc_activations(sgv_engine* e) {
     const long M = (long)e->maxB * e->T;
     const int n = e->n, n_st = e->n_st;
     e->act_used = 256;   // offset 0 is reserved so that "p == 0" means unallocated
-    e->x_in = alloc_act(e, M, e->N);
+    e->x_bufs[0] = alloc_act(e, M, e->N);
+    e->x_bufs[1] = alloc_act(e, M, e->N);
     e->xhat = alloc_act(e, M, e->N);
     e->dy_recon = alloc_act(e, M, e->N);
     e->enc_h.resize(n); e->d_h.resize(n);
@@ -612,7 +625,8 @@ static void rebase_block(sgv_engine* e, Block& b) {
 static void rebase_all(sgv_engine* e) {
     auto R = [&](Tensor& t) { rebase(e, t); };
     auto RF = [&](float*& p) { if (p) p = (float*)(e->act + (size_t)p); };
-    R(e->x_in); R(e->xhat); R(e->dy_recon); R(e->sbuf); R(e->d_sbuf);
+    R(e->x_bufs[0]); R(e->x_bufs[1]); e->x_cur = 0; e->x_in = e->x_bufs[0];
+    R(e->xhat); R(e->dy_recon); R(e->sbuf); R(e->d_sbuf);
     for (auto& b : e->encA) rebase_block(e, b);
     for (auto& b : e->encR) rebase_block(e, b);
     for (auto& b : e->decU) rebase_block(e, b);
@@ -1306,6 +1320,51 @@ static hipStream_t ensure_wire(sgv_engine* e) {
     if (!e->wire && make_aux_stream(&e->wire, "SGV_PRIO_WIRE", SGV_PRIO_OPT_DEFAULT, {e->stream, e->side}) != hipSuccess) e->wire = nullptr;
     return e->wire;
 }
+// ---- prefetched augmentation (see the members) ----
+static constexpr size_t AUG_CTL = 8192;
+static bool ensure_aug(sgv_engine* e) {
+    if (e->aug_stream) return true;
+    if (make_aux_stream(&e->aug_stream, "SGV_PRIO_AUG", 0, {e->stream, e->side, e->lane2}) != hipSuccess) { e->aug_stream = nullptr; return false; }
+    bool ok = hipEventCreateWithFlags(&e->aug_done, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&e->aug_gate, hipEventDisableTiming) == hipSuccess;
+    for (int i = 0; i < 2 && ok; ++i) ok = hipEventCreateWithFlags(&e->x_free[i], hipEventDisableTiming) == hipSuccess;
+    ok = ok && hipMalloc((void**)&e->aug_ctl, AUG_CTL) == hipSuccess;
+    if (!ok) { hipStreamDestroy(e->aug_stream); e->aug_stream = nullptr; }
+    return ok;
+}
+// Enqueue the staged batch's kernels, ordered after the current position of the stream the caller enqueues on.  A few samples per
+// launch: one launch of 8192 small workgroups would refill every CU as slots free and keep the forward pass's big-LDS workgroups
+// (fused Conv+GroupNorm stages, 128-row GEMMs) off the chip until it ends (AdamW slices).
+static int aug_fire(sgv_engine* e) {
+    if (!e->aug_staged || e->aug_fired) return SGV_OK;
+    static const int per = getenv("SGV_AUG_SLICE") ? std::max(1, atoi(getenv("SGV_AUG_SLICE"))) : 2;
+    const int nb = 1 - e->x_cur, batch = e->aug_next_batch;
+    char* scratch = e->aug_ctl;
+    int* d_idx = (int*)scratch; int* d_mix = d_idx + batch;
+    float* d_scale = (float*)(d_mix + batch); float* d_lam = d_scale + batch;
+    unsigned long long* d_seed = (unsigned long long*)(scratch + align_up((size_t)batch * 16, 8));
+    HIPCHK(hipEventRecord(e->aug_gate, e->stream));
+    HIPCHK(hipStreamWaitEvent(e->aug_stream, e->aug_gate, 0));
+    const long se = (long)e->N * e->T;
+    for (int b0 = 0; b0 < batch; b0 += per) {
+        const int nbt = std::min(per, batch - b0);
+        ew_augment(e->dt, e->aug_data, (char*)e->x_bufs[nb].p + (size_t)b0 * se * e->esz, se, nbt, d_idx + b0, d_seed + b0, d_scale + b0, d_mix + b0, d_lam + b0, e->aug_stream);
+    }
+    HIPCHK(hipEventRecord(e->aug_done, e->aug_stream));
+    if (e->timing) HIPCHK(hipStreamWaitEvent(e->stream, e->aug_done, 0));      // kernel-timing passes keep the step on one stream
+    e->aug_fired = true;
+    return SGV_OK;
+}
+// the main stream takes the batch whose prefetch kernels may still be running
+static int aug_join(sgv_engine* e) {
+    if (e->aug_pending) { HIPCHK(hipStreamWaitEvent(e->stream, e->aug_done, 0)); e->aug_pending = false; }
+    return SGV_OK;
+}
+// the main stream is done reading the current input buffer (end of a forward pass, end of backward)
+static void x_release(sgv_engine* e) {
+    if (!e->aug_stream) return;
+    if (hipEventRecord(e->x_free[e->x_cur], e->stream) == hipSuccess) e->x_free_set[e->x_cur] = true;
+}
 static hipError_t make_stream(hipStream_t* s, const char* env, int level) {
     if (getenv(env)) level = atoi(getenv(env));
     if (level == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
@@ -1424,6 +1483,10 @@ int sgv_destroy(sgv_engine* e) {
     if (e->wire) { hipStreamSynchronize(e->wire); hipStreamDestroy(e->wire); }
     if (e->comm_own) { hipStreamSynchronize(e->comm_own); hipStreamDestroy(e->comm_own); }
     if (e->lane2) { hipStreamSynchronize(e->lane2); hipStreamDestroy(e->lane2); }
+    if (e->aug_stream) {
+        hipStreamSynchronize(e->aug_stream); hipStreamDestroy(e->aug_stream);
+        hipEventDestroy(e->aug_done); hipEventDestroy(e->aug_gate); hipEventDestroy(e->x_free[0]); hipEventDestroy(e->x_free[1]); hipFree(e->aug_ctl);
+    }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
     if (e->lane_join) hipEventDestroy(e->lane_join);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
@@ -1610,8 +1673,10 @@ int sgv_prepare(sgv_engine* e) {
 int sgv_set_input(sgv_engine* e, const float* x_dev, int batch) {
     if (!e || !x_dev) return fail(SGV_ERR_ARG, "null argument");
     if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "batch %d outside [1,%d]", batch, e->maxB);
+    CHK(aug_join(e));
     // [B][N][T] fp32 -> [B][T][N] compute dtype
     ew_transpose(0, e->dt, x_dev, e->x_in.p, batch, e->N, e->T, e->T, e->x_in.ld, (long)e->N * e->T, (long)e->T * e->x_in.ld, e->stream);
+    x_release(e);
     e->batch = batch;
     e->have_fwd = false;
     return SGV_OK;
@@ -1661,9 +1726,11 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
 
 static int encoder_fwd(sgv_engine* e, int B, bool join_lane) {
     const int n = e->n;
+    CHK(aug_join(e));
     Tensor x = e->x_in;
     for (int i = 0; i < n; ++i) {
         CHK(block_fwd(e, e->encA[i], x, B));
+        if (i == 0) CHK(aug_fire(e));          // a staged next batch: built beside the short kernels from here on
         CHK(block_fwd(e, e->encR[i], e->encA[i].st.back().a, B));
         x = e->enc_h[i];
         if (i < n - 1) {
@@ -1775,6 +1842,7 @@ int sgv_forward(sgv_engine* e, int train, int mode_fix, float* scalars_host) {
     e->have_fwd = true;
     e->fwd_train = train != 0;
     for (int s = 0; s < e->n_st; ++s) e->eps_set[s] = 0;
+    x_release(e);                        // re-recorded at the end of the backward pass, which reads the batch again
     if (scalars_host) CHK(read_scalars(e, B, scalars_host));
     return SGV_OK;
 }
@@ -1812,6 +1880,7 @@ int sgv_encode(sgv_engine* e, float* mu_host, float* logvar_host, float* xs_host
     if (!e->deterministic) HIPCHK(hipMemsetAsync(e->stats, 0, e->n_stats_fwd * 8, e->stream));   // only the fp64-atomic statistics epilogue accumulates
     CHK(run_sn(e, 0));
     CHK(encoder_fwd(e, B, true));
+    x_release(e);
     std::vector<float> last((size_t)B * 2 * e->Z);
     HIPCHK(hipMemcpyAsync(last.data(), e->last, last.size() * 4, hipMemcpyDeviceToHost, e->stream));
     HIPCHK(hipStreamSynchronize(e->stream));
@@ -1839,6 +1908,7 @@ int sgv_get_activation(sgv_engine* e, const char* name, float* host, size_t coun
     const int B = e->batch;
     std::string s(name);
     if (s == "x_in") {     // the input batch as the engine holds it (after sgv_set_input / sgv_augment_collate)
+        CHK(aug_join(e));
         if (B < 1) return fail(SGV_ERR_STATE, "no input batch");
         if ((long)count != (long)B * e->T * e->N) return fail(SGV_ERR_ARG, "size mismatch for activation 'x_in'");
         return export_act(e, e->x_in, B, host);
@@ -2332,11 +2402,13 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     CHK(join_side(e));
     return SGV_OK;
 }
-int sgv_backward(sgv_engine* e, float alpha, float beta) { return backward_impl(e, alpha, beta, -1.f); }
+// every path out of backward_impl has joined the side stream: the main stream's position is past the last reader of the batch
+static int backward_done(sgv_engine* e, int rc) { if (rc == SGV_OK) x_release(e); return rc; }
+int sgv_backward(sgv_engine* e, float alpha, float beta) { return backward_done(e, backward_impl(e, alpha, beta, -1.f)); }
 int sgv_backward_step(sgv_engine* e, float alpha, float beta, float lr) {
     if (lr < 0.f) return fail(SGV_ERR_ARG, "negative learning rate");
     if (e && e->cb) return fail(SGV_ERR_STATE, "sgv_backward_step is the single-GPU path: with a bucket callback use sgv_backward + sgv_adamw_step_range");
-    return backward_impl(e, alpha, beta, lr);
+    return backward_done(e, backward_impl(e, alpha, beta, lr));
 }
 
 int sgv_grad_norm(sgv_engine* e, double* out) {
@@ -2625,6 +2697,7 @@ int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const
                         const float* scale, const int32_t* mix_idx, const float* lam) {
     if (!e || !dataset_dev || !idx || !noise_seed || !scale || !mix_idx || !lam) return fail(SGV_ERR_ARG, "null argument");
     if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "batch %d outside [1,%d]", batch, e->maxB);
+    CHK(aug_join(e));
     // small per-sample control arrays go through a device scratch at the head of xpose_tmp
     char* scratch = (char*)e->xpose_tmp;
     int* d_idx = (int*)scratch; int* d_mix = d_idx + batch;
@@ -2640,8 +2713,43 @@ int sgv_augment_collate(sgv_engine* e, const void* dataset_dev, int batch, const
     memcpy(h + seed_off, noise_seed, batch * 8);
     HIPCHK(hipMemcpyAsync(scratch, h, total, hipMemcpyHostToDevice, e->stream));
     ew_augment(e->dt, dataset_dev, e->x_in.p, (long)e->N * e->T, batch, d_idx, d_seed, d_scale, d_mix, d_lam, e->stream);
+    x_release(e);
     e->batch = batch;
     e->have_fwd = false;
+    return SGV_OK;
+}
+
+int sgv_augment_stage(sgv_engine* e, const void* dataset_dev, int batch, const int32_t* idx, const uint64_t* noise_seed,
+                      const float* scale, const int32_t* mix_idx, const float* lam) {
+    if (!e || !dataset_dev || !idx || !noise_seed || !scale || !mix_idx || !lam) return fail(SGV_ERR_ARG, "null argument");
+    if (batch < 1 || batch > e->maxB) return fail(SGV_ERR_ARG, "batch %d outside [1,%d]", batch, e->maxB);
+    const size_t seed_off = align_up((size_t)batch * 16, 8), total = seed_off + (size_t)batch * 8;
+    if (total > AUG_CTL) return fail(SGV_ERR_ARG, "batch %d: control arrays exceed the staging scratch", batch);
+    if (!ensure_aug(e)) return fail(SGV_ERR_HIP, "could not create the augmentation stream");
+    // the spare buffer's last reader (the backward pass two steps back, or a pass on a batch that was staged over) has ended;
+    // a batch staged before and never advanced to is replaced: same stream, so its kernels precede this copy
+    const int nb = 1 - e->x_cur;
+    if (e->x_free_set[nb]) HIPCHK(hipStreamWaitEvent(e->aug_stream, e->x_free[nb], 0));
+    std::vector<char>& hb = e->aug_host[e->aug_turn++ & 3];           // a buffer is reused four calls later
+    hb.resize(total);
+    char* h = hb.data();
+    memcpy(h, idx, batch * 4); memcpy(h + batch * 4, mix_idx, batch * 4);
+    memcpy(h + batch * 8, scale, batch * 4); memcpy(h + batch * 12, lam, batch * 4);
+    memcpy(h + seed_off, noise_seed, batch * 8);
+    HIPCHK(hipMemcpyAsync(e->aug_ctl, h, total, hipMemcpyHostToDevice, e->aug_stream));
+    e->aug_data = dataset_dev; e->aug_next_batch = batch;
+    e->aug_staged = true; e->aug_fired = false;
+    return SGV_OK;
+}
+int sgv_augment_advance(sgv_engine* e) {
+    if (!e) return fail(SGV_ERR_ARG, "null engine");
+    if (!e->aug_staged) return fail(SGV_ERR_STATE, "sgv_augment_advance: no batch staged (sgv_augment_stage)");
+    CHK(aug_fire(e));                        // no training forward since the stage call: the kernels go out now
+    e->x_cur = 1 - e->x_cur; e->x_in = e->x_bufs[e->x_cur];
+    e->batch = e->aug_next_batch;
+    e->have_fwd = false;
+    e->aug_staged = false; e->aug_fired = false;
+    e->aug_pending = true;                   // the next reader of the batch waits for aug_done
     return SGV_OK;
 }
 

@@ -30,6 +30,7 @@ ABI_SYMBOLS = [
     "sgv_adamw_step_range", "sgv_bucket_count", "sgv_bucket_dots", "sgv_wire_stream", "sgv_opt_stream", "sgv_adamw_bucket_async", "sgv_set_grad_payload", "sgv_grad_payload_buffer", "sgv_grad_payload_unpack", "sgv_memory_info", "sgv_recompute_bytes", "sgv_last_grad_norm", "sgv_scalars_accumulate", "sgv_scalars_read", "sgv_backward_step",
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_rccl_unique_id", "sgv_rccl_probe", "sgv_rccl_comm_count", "sgv_rccl_allreduce", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
+    "sgv_augment_stage", "sgv_augment_advance",
     "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_fake_collective",
 ]
 
@@ -113,6 +114,8 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_scalars_accumulate.argtypes = [vp]
     lib.sgv_scalars_read.argtypes = [vp, C.POINTER(C.c_double), i32]
     lib.sgv_augment_collate.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.sgv_augment_stage.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp]
+    lib.sgv_augment_advance.argtypes = [vp]
     lib.sgv_dataset_convert.argtypes = [vp, vp, vp, i32]
     lib.sgv_dataset_sample_bytes.argtypes = [vp]
     lib.sgv_dataset_sample_bytes.restype = C.c_size_t
@@ -456,6 +459,24 @@ class Engine:
                                                       sc.ctypes.data_as(C.c_void_p), mi.ctypes.data_as(C.c_void_p),
                                                       lm.ctypes.data_as(C.c_void_p)), "sgv_augment_collate")
         self.batch = B
+
+    def augment_stage(self, dataset, idx, noise_seed, scale, mix_idx, lam):
+        """Prefetch: enqueue the NEXT batch's augmentation into the spare input buffer (runs beside the current step)."""
+        idx = np.ascontiguousarray(idx, np.int32)
+        ns = np.ascontiguousarray(noise_seed, np.uint64)
+        sc = np.ascontiguousarray(scale, np.float32)
+        mi = np.ascontiguousarray(mix_idx, np.int32)
+        lm = np.ascontiguousarray(lam, np.float32)
+        _check(self.lib, self.lib.sgv_augment_stage(self.h, C.c_void_p(dataset.data_ptr()), len(idx),
+                                                    idx.ctypes.data_as(C.c_void_p), ns.ctypes.data_as(C.c_void_p),
+                                                    sc.ctypes.data_as(C.c_void_p), mi.ctypes.data_as(C.c_void_p),
+                                                    lm.ctypes.data_as(C.c_void_p)), "sgv_augment_stage")
+        self._staged_batch = len(idx)
+
+    def augment_advance(self):
+        """The staged batch becomes the current input."""
+        _check(self.lib, self.lib.sgv_augment_advance(self.h), "sgv_augment_advance")
+        self.batch = self._staged_batch
 
     # ---- profiling ----
     def kernel_time_reset(self, enable: bool):

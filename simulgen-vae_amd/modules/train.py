@@ -401,6 +401,15 @@ def make_allreduce(engine, group=None):
     return GradAllReduce(engine, group)
 
 
+def _lookahead(it, first):
+    """(current, next) pairs over `first` followed by the items of `it`; next is None for the last one."""
+    cur = first
+    while cur is not None:
+        nxt = next(it, None)
+        yield cur, nxt
+        cur = nxt
+
+
 def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_enc, num_filter_dec, num_node, latent_dim,
           hierarchical_dim, num_time, alpha, lossfun, small, load_all, debug_mode=0, compute_dtype="bf16"):
     logging.basicConfig(level=logging.INFO, format="%(asctime)s - %(levelname)s - %(message)s")
@@ -444,10 +453,18 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
         lr = cosine_warm_restarts_lr(LR, epochs, epoch)
         batches = train_dataloader.batch_plans() if fused else iter(train_dataloader)
         eng.read_accumulated(reset=True)
+        if fused:
+            # the DataLoader's prefetch (workers build batch i + 1 while step i runs): the engine builds the next batch beside the step
+            batches = iter(batches)
+            nxt = next(batches, None)
+            if nxt is not None:
+                eng.augment_stage(data, *nxt)
+            batches = _lookahead(batches, nxt)
         for item in batches:
             if fused:
-                idx, seeds, scale, mix, lam = item
-                eng.augment_collate(data, idx, seeds, scale, mix, lam)
+                eng.augment_advance()                   # batch i (staged during step i - 1) becomes current
+                if item[1] is not None:
+                    eng.augment_stage(data, *item[1])   # batch i + 1
             else:
                 eng.set_input(model._prep(item))
             eng.forward(train=True, sync=False)          # nothing in the step waits for the host: the step's scalars and its

@@ -278,6 +278,71 @@ def test_augment_collate_matches_oracle():
     eng.close()
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_prefetched_augmentation_is_schedule_only(dtype):
+    """sgv_augment_stage / sgv_augment_advance (the training loop's prefetch: batch i + 1 is built in a second input buffer on a
+    stream of its own, beside step i) against sgv_augment_collate at the start of every step: six training steps with no host
+    synchronisation between them, an eval forward and a set_input in between, a staged batch that is replaced before it is
+    used -- bitwise the same batches, losses and weights.  Advancing with nothing staged is an error."""
+    import torch
+    cfg = make_cfg(G1)
+    P, B = 7, 4
+    x = synthetic_samples(37, range(P), cfg.num_node, cfg.num_time)
+    rs = np.random.RandomState(4)
+    plans = []
+    for s in range(7):
+        idx = rs.randint(0, P, B).tolist()
+        mix = [int((i + 1 + rs.randint(0, P - 1)) % P) if rs.rand() < 0.5 else -1 for i in idx]
+        plans.append((idx, [int(rs.randint(1, 1 << 30)) if rs.rand() < 0.5 else 0 for _ in idx],
+                      [float(0.9 + 0.2 * rs.rand()) for _ in idx], mix, [float(0.1 + 0.8 * rs.rand()) if m >= 0 else 1.0 for m in mix]))
+    plans[5] = tuple(v[:3] for v in plans[5])              # a ragged batch in the middle of the run
+    out = []
+    for prefetch in (0, 1):
+        eng = E.Engine(cfg, max_batch=B, compute_dtype=dtype)
+        eng.load_state(init_state(cfg, 3))
+        eng.seed(77)
+        data = torch.empty(P * eng.sample_bytes(), dtype=torch.uint8, device="cuda")
+        eng.dataset_convert(torch.from_numpy(x).cuda(), data, P)
+        rec = []
+        if prefetch:
+            with pytest.raises(E.SgvError):
+                eng.augment_advance()                       # nothing staged
+            eng.augment_stage(data, *plans[6])              # replaced by the next call before it is ever used
+            eng.augment_stage(data, *plans[0])
+        for s in range(6):
+            if prefetch:
+                eng.augment_advance()
+                eng.augment_stage(data, *plans[s + 1])
+            else:
+                eng.augment_collate(data, *plans[s])
+            if s == 2:
+                rec.append(eng.activation("x_in", (B, cfg.num_node, cfg.num_time)))
+            eng.forward(train=True, sync=False)
+            eng.backward_step(1e6, 1e-4, 1e-3)
+            if s == 1:
+                rec.append(eng.forward(train=False))           # same batch again, eval pass (fires nothing new: already fired)
+            if s == 3:
+                eng.set_input(torch.from_numpy(x[:B]).cuda())  # overwrites the CURRENT batch, not the staged one
+                rec.append(eng.forward(train=False))
+        rec.append(eng.forward(train=False))
+        sd = eng.state_dict()
+        rec.append(np.concatenate([np.asarray(sd[k], dtype=np.float32).ravel() for k in sorted(sd)]))
+        if prefetch:
+            eng.augment_advance()                               # plans[6], staged during the last step
+            want = E.Engine(cfg, max_batch=B, compute_dtype=dtype)
+            want.load_state(init_state(cfg, 3))
+            want.augment_collate(data, *plans[6])
+            np.testing.assert_array_equal(eng.activation("x_in", (B, cfg.num_node, cfg.num_time)),
+                                          want.activation("x_in", (B, cfg.num_node, cfg.num_time)))
+            want.close()
+        out.append(rec)
+        eng.close()
+    a, b = out
+    np.testing.assert_array_equal(a[1], b[1])                   # the batch of step 2
+    assert a[0] == b[0] and a[2] == b[2] and a[3] == b[3]
+    np.testing.assert_array_equal(a[4], b[4])
+
+
 def test_api_error_behaviour():
     """Status codes + sgv_last_error text instead of crashes: wrong call order, bad sizes, unknown names."""
     import torch

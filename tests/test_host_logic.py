@@ -347,3 +347,15 @@ def test_keyed_augmentation_plans_do_not_depend_on_the_world_size():
         for k in range(18):
             assert f0[k] == flat1[2 * k] and f1[k] == flat1[2 * k + 1], (e, k)
         assert any(p[1] for p in f0) and any(p[3] >= 0 for p in f0)      # noise seeds and mixup partners do occur
+
+
+def test_lookahead_pairs_every_batch_with_its_successor():
+    """modules/train.py's prefetch loop: (current, next) over the epoch's batch plans, next = None for the last batch; an empty
+    epoch yields nothing (the caller then raises the reference's ZeroDivisionError)."""
+    from simulgen_vae_amd.modules.train import _lookahead
+    def pairs(seq):
+        it = iter(seq)
+        return list(_lookahead(it, next(it, None)))
+    assert pairs([]) == []
+    assert pairs(["a"]) == [("a", None)]
+    assert pairs(["a", "b", "c"]) == [("a", "b"), ("b", "c"), ("c", None)]
