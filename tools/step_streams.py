@@ -3,7 +3,7 @@
    python tools/step_streams.py <kernel_trace.csv> [t0_ms t1_ms]"""
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "augment_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "sn_wt_u_kernel" in r["Kernel_Name"]]
 lo, hi = marks[len(marks) // 2], marks[len(marks) // 2 + 1]
 t0 = int(rows[lo]["Start_Timestamp"])
 a = float(sys.argv[2]) if len(sys.argv) > 2 else 0.0

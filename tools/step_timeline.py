@@ -6,7 +6,7 @@ chains that leave most of the chip idle).
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "augment_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "sn_wt_u_kernel" in r["Kernel_Name"]]
 lo, hi = marks[len(marks) // 2], marks[len(marks) // 2 + 1]
 step = rows[lo:hi]
 t0 = int(step[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in step)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turn rocprofv3 CSV output (kernel stats / kernel trace / PMC counter collection) of a bench.py run into the
 small per-step summaries committed under profiles/.
-  python tools/summarize_profile.py stats  <kernel_stats.csv> <steps_in_run | 0 = count augment launches>
+  python tools/summarize_profile.py stats  <kernel_stats.csv> <steps_in_run | 0 = count sn_wt_u_kernel launches>
   python tools/summarize_profile.py pmc    <counter_collection.csv>      # FETCH_SIZE or WRITE_SIZE pass
   python tools/summarize_profile.py traffic <fetch.csv> <write.csv>      # JSON read by bench.py (roofline.traffic)
 Counter units: rocprofv3 reports FETCH_SIZE/WRITE_SIZE in KiB; on gfx950 FETCH_SIZE counts wide coalesced
@@ -16,8 +16,8 @@ SETUP = ("transpose_kernelIf", "at::native", "make_copies_kernel")     # dataset
 
 def stats(path, steps):
     rows = list(csv.DictReader(open(path)))
-    if steps <= 0:   # every training step launches the augment+collate kernel exactly once
-        steps = sum(int(r["Calls"]) for r in rows if "augment_kernel" in r["Name"])
+    if steps <= 0:   # every training forward starts its power iteration with exactly one sn_wt_u_kernel launch (the prefetched augmentation runs in several launches in the middle of a step)
+        steps = sum(int(r["Calls"]) for r in rows if "sn_wt_u_kernel" in r["Name"])
     setup = [r for r in rows if any(k in r["Name"] for k in SETUP)]
     rows = [r for r in rows if r not in setup]
     tot = sum(float(r["TotalDurationNs"]) for r in rows)
@@ -34,7 +34,7 @@ def pmc(path):
     rows = list(csv.DictReader(open(path)))
     name = rows[0]["Counter_Name"]
     corr = 2.0 if name == "FETCH_SIZE" else 1.0
-    idx = [i for i, x in enumerate(rows) if "augment_kernel" in x["Kernel_Name"]]     # one per training step, first kernel of it
+    idx = [i for i, x in enumerate(rows) if "sn_wt_u_kernel" in x["Kernel_Name"]]     # one per training step, first kernel of its forward pass
     step = rows[idx[-2]: idx[-1]]
     agg, cnt, dur = collections.Counter(), collections.Counter(), collections.Counter()
     for x in step:
@@ -50,7 +50,7 @@ def pmc(path):
 
 def step_rows(path):
     rows = list(csv.DictReader(open(path)))
-    idx = [i for i, x in enumerate(rows) if "augment_kernel" in x["Kernel_Name"]]
+    idx = [i for i, x in enumerate(rows) if "sn_wt_u_kernel" in x["Kernel_Name"]]
     return rows[0]["Counter_Name"], rows[idx[-2]: idx[-1]]
 
 

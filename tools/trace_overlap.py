@@ -5,7 +5,7 @@ and how much of every kernel class ran while another kernel was also running (st
 import csv, sys, collections
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "augment_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "sn_wt_u_kernel" in r["Kernel_Name"]]
 lo, hi = marks[len(marks) // 2], marks[len(marks) // 2 + 1]     # a step from the middle of the timed region
 step = rows[lo:hi]
 t0 = int(step[0]["Start_Timestamp"]); t1 = max(int(r["End_Timestamp"]) for r in step)
