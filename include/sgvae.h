@@ -338,6 +338,9 @@ int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M,
  * gradient side stream, 2 optimizer stream, 3 the engine's communication stream; 2 and 3 are created by the call if need be) can run
  * while a kernel of the engine stream is running, i.e. the two do not share a hardware queue; -1 if the engine has no such stream. */
 int sgv_test_stream_overlap(sgv_engine* e, int which, int* overlaps);
+/* Test hook: `blocks` workgroups of `threads` threads and `lds_bytes` of LDS spin for `ticks` of the 100 MHz clock (<= 10 ms) on
+ * `stream` -- a stand-in for a collective's resident channel workgroups when measuring how the persistent GEMMs cope. */
+int sgv_test_occupy(void* stream, int blocks, int threads, int lds_bytes, long long ticks);
 /* Test double for the collective of the engine-issued data-parallel step (sgv_set_rccl with any non-null communicator handle):
  * k != 0 replaces ncclAllReduce by "multiply the range in place by k on the given stream" (fp32 and bf16 ranges; no RCCL is
  * loaded or called), k == 0 restores the library.  With k a power of two a step through the double must leave bitwise the

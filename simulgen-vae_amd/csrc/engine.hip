@@ -2897,6 +2897,20 @@ int sgv_test_stream_overlap(sgv_engine* e, int which, int* overlaps) {
     *overlaps = streams_overlap(e->stream, s) ? 1 : 0;
     return SGV_OK;
 }
+// Test hook: occupy part of the chip for a bounded time (what a resident collective's channel workgroups do): `blocks` workgroups
+// of `threads` threads and `lds_bytes` of LDS each spin on the constant-rate clock for `ticks` (100 MHz) on `stream`; returns at once.
+__global__ void occupy_spin_kernel(long long ticks) {
+    extern __shared__ char occ_lds[];
+    if (threadIdx.x == 0xFFFFFF) occ_lds[0] = 1;
+    const long long t0 = (long long)wall_clock64();
+    while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+}
+int sgv_test_occupy(void* stream, int blocks, int threads, int lds_bytes, long long ticks) {
+    if (blocks < 1 || blocks > 1024 || threads < 64 || threads > 1024 || lds_bytes < 0 || lds_bytes > 160 * 1024 || ticks < 0 || ticks > 1000000)
+        return fail(SGV_ERR_ARG, "sgv_test_occupy: argument out of range (at most 1024 workgroups, 10 ms)");
+    hipLaunchKernelGGL(occupy_spin_kernel, dim3(blocks), dim3(threads), (size_t)lds_bytes, (hipStream_t)stream, ticks);
+    return hipGetLastError() == hipSuccess ? SGV_OK : fail(SGV_ERR_HIP, "occupy launch failed");
+}
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps, int Tlen, int splitk,
                      int use_tr, void* stream) {
     GemmTN p; memset(&p, 0, sizeof(p));

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "sgv_minmax_fit", "sgv_minmax_coeffs", "sgv_scale_convert",
     "sgv_rccl_unique_id", "sgv_rccl_probe", "sgv_rccl_comm_count", "sgv_rccl_allreduce", "sgv_rccl_comm_init", "sgv_rccl_comm_destroy", "sgv_allreduce_grads", "sgv_set_rccl", "sgv_comm_stream",
     "sgv_augment_stage", "sgv_augment_advance",
-    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_fake_collective",
+    "sgv_kernel_time", "sgv_kernel_time_reset", "sgv_kernel_time_tag", "sgv_test_gemm_nt", "sgv_test_gemm_nt_stats", "sgv_test_gemm_nt256", "sgv_test_conv_gn_fwd", "sgv_test_conv_gn_bwd", "sgv_test_gemm_tn", "sgv_test_stream_overlap", "sgv_test_occupy", "sgv_test_fake_collective",
 ]
 
 
@@ -128,6 +128,7 @@ def load_library(path: str = LIB_PATH):
     lib.sgv_test_gemm_nt.argtypes = [i32, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sgv_test_gemm_nt_stats.argtypes = [vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp, vp]
     lib.sgv_test_gemm_nt256.argtypes = [vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp, vp, vp]
+    lib.sgv_test_occupy.argtypes = [vp, i32, i32, i32, C.c_longlong]
     lib.sgv_test_gemm_tn.argtypes = [i32, vp, vp, vp, i32, i32, i32, i32, i32, i32, i32, vp]
     lib.sgv_test_conv_gn_fwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, f32, vp]
     lib.sgv_test_conv_gn_bwd.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, i32, i32, i32, i32, i32, i32, vp]

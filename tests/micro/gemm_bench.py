@@ -40,7 +40,13 @@ else:
 run(); torch.cuda.synchronize()
 ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 ts = []
+# OCCUPY="blocks,threads,lds_bytes": that many workgroups spin on another stream for 4 ms while the GEMM runs (a collective's channels)
+occ = [int(v) for v in os.environ["OCCUPY"].split(",")] if os.environ.get("OCCUPY") else None
+side = torch.cuda.Stream() if occ else None
 for _ in range(reps):
+    if occ:
+        assert lib.sgv_test_occupy(side.cuda_stream, occ[0], occ[1], occ[2], 400000) == 0, lib.sgv_last_error()
+        time.sleep(0.0005)           # the occupying workgroups are resident before the GEMM is launched
     ev0.record(); run(); ev1.record(); torch.cuda.synchronize(); ts.append(ev0.elapsed_time(ev1))
 best = min(ts)
 print(f"{kind} {a}x{b}x{c} taps={taps}: best {best*1e3:.0f} us  {flops/best/1e9:.0f} TFLOP/s (incl. launch+sync overhead)")

@@ -9,7 +9,7 @@ python3 - $O/p/p_kernel_trace.csv > $O/step.txt <<'PY'
 import csv, sys
 rows = [r for r in csv.DictReader(open(sys.argv[1]))]
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "augment_kernel" in r["Kernel_Name"]]
+marks = [i for i, r in enumerate(rows) if "sn_wt_u_kernel" in r["Kernel_Name"]]
 lo, hi = marks[len(marks) // 2], marks[len(marks) // 2 + 1]
 t0 = int(rows[lo]["Start_Timestamp"])
 qs = {}
