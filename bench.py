@@ -272,6 +272,8 @@ def main():
               f"({data.numel() / 1e9:.1f} GB), dtype {args.dtype}", file=sys.stderr)
 
     ddp = world > 1 or (os.environ.get("SGV_FORCE_DDP") == "1" and dist.is_initialized())   # forced: plumbing test at N=1
+    if not ddp and args.dtype == "bf16" and os.environ.get("SGV_BENCH_GRAD_BF16", "1") != "0":
+        eng.set_option("grad_bf16", 1)    # as modules/train.py does on one GPU: the big layers' gradients reach AdamW as bf16 (the data-parallel step's wire rounding)
     # bucketed mean all-reduce over RCCL, overlapped with backward and with AdamW (modules/train.py GradAllReduce)
     allreduce = make_allreduce(eng) if ddp else None
     ddp_info = allreduce.info() if allreduce is not None else {"ddp_path": None, "rccl_nranks": None, "torch_world": world,

@@ -113,7 +113,12 @@ int sgv_set_shard(sgv_engine* e, int rank, int world);
  * runs on the hand-written kernels; the hipBLASLt comparator lives in tests/micro/vendor, outside this library), "deterministic" (default 1: no
  * floating-point atomics anywhere in the step), "lanes" (second compute lane for the posterior branch of a decoder stage and
  * the xs heads; schedule only, results are bitwise the same; default 1), "fused_stages" (small Conv1d -> GroupNorm -> GELU
- * stages in one launch, csrc/convgn.hip; default 1, 0: GEMM + split-K combine + GroupNorm kernels). */
+ * stages in one launch, csrc/convgn.hip; default 1, 0: GEMM + split-K combine + GroupNorm kernels),
+ * "grad_bf16" (bf16 engines, single-GPU path; default 0, modules/train.py switches it on at world size 1: the weight gradients of
+ * the layers whose weight-gradient GEMM is the 256 x 256 kernel reach the optimizer as bf16 -- rounded to nearest even in the
+ * GEMM's epilogue, the rounding the data-parallel step's bf16 wire format applies to every weight gradient -- 4 bytes less written
+ * and read per parameter; sgv_export_grad / sgv_grad_norm refresh the fp32 arena from the bf16 copy on demand; ignored while a
+ * communicator or a bucket callback is registered). */
 int sgv_set_option(sgv_engine* e, const char* key, int value);
 
 /* VAE.forward (VAE_network.py:79-121) on the current input.  train != 0: spectral-norm power

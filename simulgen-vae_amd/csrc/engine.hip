@@ -71,6 +71,8 @@ struct Layer {
     int splitk_tn = 1;
     size_t dot_part = NPOS;                         // per-block <G,W_eff> partials of the layer's dY kernel (e->red arena)
     size_t col_part = NPOS;                         // per-block column sums of dY (bias gradient of a conv without GroupNorm), same arena
+    bool lp = false;                                // option grad_bf16: this layer's weight gradient lives in the bf16 mirror arena (fixed at creation:
+                                                    //   its weight-gradient GEMM takes the 256 x 256 kernel at the engine's full batch)
     long nw() const { return (long)cout * cin * k; }
 };
 struct GNLayer {
@@ -144,6 +146,17 @@ struct sgv_engine {
     // data-parallel wire format of the weight buckets: 0 = the fp32 arena itself, 1 = a bf16 copy (packed at the bucket's fire point,
     // averaged by the collective, unpacked into the arena in front of the bucket's AdamW).  The small bucket always travels in fp32.
     int payload_bf16 = 0; void* grads_lp = nullptr; std::vector<char> bucket_packed;
+    // option "grad_bf16" (bf16 engines, single-GPU path: no communicator, no bucket callback): the 256 x 256 weight-gradient kernel
+    // stores its result as bf16 into the mirror arena grads_lp and the AdamW pass reads it there (AdamDesc::glp) -- 4 B less
+    // written and read per parameter of the big layers.  The fp32 arena of those layers is refreshed on demand (lp_sync) for the
+    // calls that read it (sgv_export_grad, sgv_grad_norm).
+    // With the bf16 wire format of the data-parallel step the same kernel writes the wire copy directly (bit for bit what the pack
+    // pass produced from the fp32 result; that pass then skips those layers).
+    int grad_bf16 = 0;
+    bool lp_classified = false;
+    std::vector<char> lp_dirty;          // per layer: its gradient of the last backward was stored as bf16 into grads_lp (not into the fp32 arena)
+    std::vector<std::vector<int>> bucket_lp_layers;     // per weight bucket: its Layer::lp layers in arena order
+    bool dw_chunk_direct = false;        // chunked first-layer gradient (data-parallel): the chunk GEMMs write the wire copy themselves
     // data-parallel optimizer overlap: the <G,W_eff> scalars of a weight bucket's layers sit together at the head of the small zone
     // (bucket_dots[b] = their range), so they can be averaged WITH the bucket instead of with the small bucket at the end of backward;
     // the bucket's conv-weight AdamW then runs on `opt` as soon as both collectives have landed, under the rest of backward
@@ -738,6 +751,7 @@ static int upload_tables(sgv_engine* e) {
         AdamDesc a;
         a.p = e->params + p; a.g = e->grads + g; a.m = e->adam_m + g; a.v = e->adam_v + g;
         a.n = n; a.sn = sn; a.rows = rows; a.cols = cols; a.taps = taps; a.wc = wc; a.wct = wct;
+        a.glp = nullptr;                 // option grad_bf16 points it at the bf16 mirror arena
         const int id = (int)e->adam_host.size();
         e->adam_host.push_back(a);
         const long nch = (n + OPT_CHUNK - 1) / OPT_CHUNK;
@@ -954,6 +968,69 @@ static int join_side(sgv_engine* e) {
     e->side_dirty = false;
     return 0;
 }
+// ---- bf16 weight gradients straight from the 256 x 256 kernel (see the grad_bf16 member) ----
+static bool comm_is_single(void* comm);
+// which layers: those whose weight-gradient GEMM takes that kernel, unsplit, at the engine's full batch (fixed once: the AdamW table
+// points the layer at the mirror arena)
+static void classify_lp(sgv_engine* e) {
+    if (e->lp_classified) return;
+    const long M = (long)e->maxB * e->T;
+    for (auto& l : e->layers) {
+        l.lp = false;
+        if (!(l.used && l.has_grad && l.op != OP_LINEAR && l.cin % 4 == 0) || e->dt != SGV_DTYPE_BF16 || !e->use_tr) continue;
+        GemmTN q; memset(&q, 0, sizeof(q));
+        q.M = (int)M; q.N1 = l.cout; q.N2 = l.cin; q.taps = l.k; q.pad = (l.k - 1) / 2; q.Tlen = e->T; q.lda = l.cout; q.ldb = l.cin; q.ldo = l.cin; q.use_tr = 1; q.splitk = 1;
+        l.lp = gemm_tn_uses_t256(e->dt, q) && gemm_tn_pick_splitk(q.M, q.N1, q.N2, q.taps, e->dt, e->T) == 1;
+    }
+    e->bucket_lp_layers.assign(e->buckets.size(), {});
+    for (size_t b = 0; b + 1 < e->buckets.size(); ++b) {
+        std::vector<std::pair<size_t, int>> v;
+        for (size_t i = 0; i < e->layers.size(); ++i) {
+            const Layer& l = e->layers[i];
+            if (l.lp && l.gw >= e->buckets[b].first && l.gw < e->buckets[b].first + e->buckets[b].second) v.push_back({l.gw, (int)i});
+        }
+        std::sort(v.begin(), v.end());
+        for (auto& x : v) e->bucket_lp_layers[b].push_back(x.second);
+    }
+    e->lp_classified = true;
+}
+static int ensure_lp_mirror(sgv_engine* e) {
+    if (!e->grads_lp) HIPCHK(hipMalloc(&e->grads_lp, e->n_grads * 2));
+    classify_lp(e);
+    return 0;
+}
+// single-GPU option: no communicator, no bucket callback
+static inline bool grad_lp_active(const sgv_engine* e) { return e->grad_bf16 && e->grads_lp && !e->comm && !e->cb; }
+// data-parallel step with the bf16 wire format (the condition under which fire_at packs a bucket)
+static inline bool wire_lp_active(sgv_engine* e) {
+    const char* off = getenv("SGV_WIRE_DIRECT");           // read per call: a test compares both forms in one process
+    if (off && atoi(off) == 0) return false;
+    return e->payload_bf16 && e->grads_lp && e->lp_classified && (e->comm ? !comm_is_single(e->comm) : e->cb != nullptr);
+}
+// the fp32 arena of the layers whose last gradient was stored as bf16: refreshed for the calls that read it.  (After a
+// data-parallel step the mirror holds the averaged gradient of those layers.)
+static int lp_sync(sgv_engine* e) {
+    for (size_t i = 0; i < e->layers.size(); ++i) {
+        if (!e->lp_dirty[i]) continue;
+        const Layer& l = e->layers[i];
+        ew_unpack_bf16((const char*)e->grads_lp + 2 * l.gw, e->grads + l.gw, l.nw(), e->stream);
+        e->lp_dirty[i] = 0;
+    }
+    return 0;
+}
+// a bucket's fp32 gradients -> the bf16 wire copy, except the layers whose GEMM wrote the copy itself
+static void pack_bucket(sgv_engine* e, int b, hipStream_t st) {
+    size_t cur = e->buckets[b].first;
+    const size_t end = cur + e->buckets[b].second;
+    if (e->lp_classified && b < (int)e->bucket_lp_layers.size())
+        for (int li : e->bucket_lp_layers[b]) {
+            const Layer& l = e->layers[li];
+            if (!e->lp_dirty[li]) continue;
+            if (l.gw > cur) ew_pack_bf16(e->grads + cur, (char*)e->grads_lp + 2 * cur, (long)(l.gw - cur), st);
+            cur = l.gw + align_up((size_t)l.nw(), 4);
+        }
+    if (end > cur) ew_pack_bf16(e->grads + cur, (char*)e->grads_lp + 2 * cur, (long)(end - cur), st);
+}
 // dW[tap][co][ci] = sum_m dY[m][co] X[m+tap-pad][ci]
 static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Tensor& x, long M) {
     GemmTN p; memset(&p, 0, sizeof(p));
@@ -981,20 +1058,34 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     } else if ((size_t)sk * nw > e->partial_floats) sk = 1;
     if (e->dw_chunks > 1 && (int)(&l - e->layers.data()) == e->dw_chunk_layer && sk == 1 && !side && l.k == 1 && l.cout % (128 * e->dw_chunks) == 0) {
         const int rows = l.cout / e->dw_chunks;
+        GemmTN q0 = p; q0.splitk = 1; q0.N1 = rows;
+        const bool direct = l.lp && wire_lp_active(e) && gemm_tn_uses_t256(e->dt, q0);       // the chunks' wire copy straight from the GEMM
+        e->dw_chunk_direct = direct;
+        e->lp_dirty[(int)(&l - e->layers.data())] = direct ? 1 : 0;
         for (int c = 0; c < e->dw_chunks; ++c) {
             GemmTN q = p;
             q.splitk = 1; q.N1 = rows;
             q.A = (const char*)dy.p + (size_t)c * rows * e->esz;
             q.out = G + (size_t)c * rows * l.cin;
+            if (direct) { q.out = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(e->grads_lp) + l.gw + (size_t)c * rows * l.cin); q.out_bf16 = 1; }
             if (launch_gemm_tn(e->dt, q, st)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s (rows %d..%d)", l.prefix.c_str(), c * rows, (c + 1) * rows);
             if (e->dw_chunk_hook && e->dw_chunk_hook(c, e->dw_chunks, c * rows, (c + 1) * rows)) return fail(SGV_ERR_HIP, "weight-gradient chunk exchange failed for %s", l.prefix.c_str());
         }
         return 0;
     }
     ScopedTimer tm(e, "gemm_tn", &l, p.M, p.N1, p.N2, p.taps, sk);
+    const int li_ = (int)(&l - e->layers.data());
     if (sk == 1) {
         p.splitk = 1; p.out = G;
+        // grad_bf16: the 256 x 256 kernel rounds its accumulators to bf16 on the way out; the AdamW pass reads them there
+        const bool opt_lp = l.lp && grad_lp_active(e), wire_lp = l.lp && !opt_lp && wire_lp_active(e);
+        const bool lp = (opt_lp || wire_lp) && gemm_tn_uses_t256(e->dt, p);
+        if (lp) { p.out = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(e->grads_lp) + l.gw); p.out_bf16 = 1; }
         if (launch_gemm_tn(e->dt, p, st)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s", l.prefix.c_str());
+        // a smaller batch than the one the layer was classified at took another kernel: the optimizer still reads the mirror, so the
+        // fp32 result goes there in a pass (the wire copy gets it with the rest of the bucket: pack_bucket)
+        if (opt_lp && !lp) ew_pack_bf16(G, (char*)e->grads_lp + 2 * l.gw, nw, st);
+        e->lp_dirty[li_] = lp ? 1 : 0;
     } else {
         // split-K over the batch*time rows: each slice writes its own fp32 slab (plain stores), then one sum pass
         p.splitk = sk; p.out = slabs; p.out_slab_stride = nw;
@@ -1002,6 +1093,8 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
         tm.end_now();
         int blocks = (int)((nw / 4 + 255) / 256); if (blocks > 4096) blocks = 4096;     // four elements per thread (grid-stride either way)
         hipLaunchKernelGGL(sum_slabs_kernel, dim3(blocks), dim3(256), 0, st, G, slabs, sk, nw);
+        if (l.lp && grad_lp_active(e)) ew_pack_bf16(G, (char*)e->grads_lp + 2 * l.gw, nw, st);
+        e->lp_dirty[li_] = 0;
     }
     return 0;
 }
@@ -1427,6 +1520,7 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     } while (0)
     ALLOC(e->params, e->n_params * 4);
     ALLOC(e->grads, e->n_grads * 4);
+    e->lp_dirty.assign(e->layers.size(), 0);
     ALLOC(e->adam_m, e->n_grads * 4);
     ALLOC(e->adam_v, e->n_grads * 4);
     ALLOC(e->copies, e->n_copies * e->esz);
@@ -1628,6 +1722,7 @@ int sgv_export_grad(sgv_engine* e, const char* name, float* host, size_t count, 
     if (is_none) *is_none = (go == NPOS);
     if (go == NPOS) { memset(host, 0, count * 4); return SGV_OK; }
     std::vector<float> g(count);
+    CHK(lp_sync(e));
     HIPCHK(hipStreamSynchronize(e->stream));
     HIPCHK(hipMemcpy(g.data(), e->grads + go, count * 4, hipMemcpyDeviceToHost));
     if (s->kind == 1) {
@@ -1718,6 +1813,24 @@ int sgv_set_option(sgv_engine* e, const char* key, int value) {
     else if (!strcmp(key, "vendor_gemm")) { if (value) return fail(SGV_ERR_ARG, "vendor_gemm: the library GEMM back end was removed from libsgvae.so (comparator: tests/micro/vendor)"); }
     else if (!strcmp(key, "deterministic")) e->deterministic = value != 0;
     else if (!strcmp(key, "lanes")) e->use_lanes = value != 0 && e->lane2 != nullptr;          // second compute lane (schedule only: results are bitwise the same)
+    else if (!strcmp(key, "grad_bf16")) {                                                           // see the member
+        if (value && (e->dt != SGV_DTYPE_BF16)) return fail(SGV_ERR_ARG, "grad_bf16 needs a bf16 engine");
+        CHK(lp_sync(e));
+        if (value) {
+            CHK(ensure_lp_mirror(e));
+            // point the optimizer's table at the mirror for the classified layers (the kernel follows the pointer only when the launch
+            // says so: adamw_tiles)
+            bool changed = false;
+            for (auto& a : e->adam_host) {
+                if (a.sn < 0 || a.sn >= (int)e->layers.size()) continue;
+                const Layer& l = e->layers[a.sn];
+                if (!l.lp || a.g != e->grads + l.gw || a.glp) continue;
+                a.glp = reinterpret_cast<const unsigned short*>(e->grads_lp) + l.gw; changed = true;
+            }
+            if (changed) { HIPCHK(hipStreamSynchronize(e->stream)); HIPCHK(hipMemcpy(e->adam_dev, e->adam_host.data(), sizeof(AdamDesc) * e->adam_host.size(), hipMemcpyHostToDevice)); }
+        }
+        e->grad_bf16 = value != 0;
+    }
     else if (!strcmp(key, "recompute_activations")) e->recompute_act = value != 0;               // measurement only, see block_bwd
     else if (!strcmp(key, "fused_stages")) e->use_convgn = value != 0;                          // csrc/convgn.hip kernels for the small Conv -> GroupNorm -> GELU stages
     else return fail(SGV_ERR_ARG, "unknown option '%s'", key);
@@ -2203,7 +2316,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
             const hipStream_t ws = e->comm ? e->comm_stream : (e->use_wire ? e->wire : nullptr);
             if (ws ? gather_on(ws) : join_side(e)) { early_err = 1; return; }
             if (e->payload_bf16 && b != (int)e->buckets.size() - 1 && !(e->comm && comm_is_single(e->comm))) {
-                ew_pack_bf16(e->grads + e->buckets[b].first, (char*)e->grads_lp + 2 * e->buckets[b].first, (long)e->buckets[b].second, ws ? ws : e->stream);
+                pack_bucket(e, b, ws ? ws : e->stream);
                 e->bucket_packed[b] = 3;
             }
         }
@@ -2348,7 +2461,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
                     if (gather_on(cs)) return 1;                                  // the chunk's GEMM (main stream)
                     const bool lp = e->payload_bf16 != 0;
                     void* w = lp ? (void*)((char*)e->grads_lp + 2 * off) : (void*)(e->grads + off);
-                    if (lp) ew_pack_bf16(e->grads + off, w, (long)cnt, cs);
+                    if (lp && !e->dw_chunk_direct) ew_pack_bf16(e->grads + off, w, (long)cnt, cs);
                     if (g_rccl.AllReduce(w, w, cnt, lp ? kNcclBfloat16 : kNcclFloat32, kNcclAvg, e->comm, cs)) return 1;
                     if (c == 0 && e->bucket_dots[last_b].second) {
                         float* d = e->grads + e->bucket_dots[last_b].first;
@@ -2413,6 +2526,7 @@ int sgv_backward_step(sgv_engine* e, float alpha, float beta, float lr) {
 
 int sgv_grad_norm(sgv_engine* e, double* out) {
     if (!e || !out) return fail(SGV_ERR_ARG, "null argument");
+    CHK(lp_sync(e));
     if (opt_grad_norm(e->adam_dev, e->sn_dev, e->items_adam, e->n_items_adam, e->gnorm_part, e->stream)) return fail(SGV_ERR_HIP, "grad-norm launch failed");
     ew_rowsum_d(e->gnorm_part, e->n_items_adam, 1, e->scal + 15, 1.0, e->stream);
     double h = 0.0;
@@ -2465,7 +2579,7 @@ static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, 
     for (int a = t0; a < t1; a += slice) {
         const int b = std::min(t1, a + slice);
         if (opt_adamw_sn(e->adam_dev, e->sn_dev, e->items_adam_2d + a, b - a, lr, c.b1, c.b2, 1e-8f, 0.01f, c.bc1, c.bc2s, e->gnorm_part + e->n_items_adam_flat + a, e->dt, st,
-                         e->grads, from_lp ? e->grads_lp : nullptr))
+                         e->grads, from_lp ? e->grads_lp : nullptr, (!from_lp && grad_lp_active(e)) ? 1 : 0))
             return fail(SGV_ERR_HIP, "adamw launch failed");
     }
     return 0;
@@ -2588,7 +2702,7 @@ int sgv_set_grad_payload(sgv_engine* e, int dtype) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
     if (dtype != SGV_DTYPE_F32 && dtype != SGV_DTYPE_BF16) return fail(SGV_ERR_ARG, "gradient payload must be f32 or bf16");
     for (char c : e->bucket_packed) if (c) return fail(SGV_ERR_STATE, "a packed bucket is in flight: change the payload between steps");
-    if (dtype == SGV_DTYPE_BF16 && !e->grads_lp) HIPCHK(hipMalloc(&e->grads_lp, e->n_grads * 2));
+    if (dtype == SGV_DTYPE_BF16) CHK(ensure_lp_mirror(e));
     e->payload_bf16 = dtype == SGV_DTYPE_BF16;
     e->bucket_packed.assign(e->buckets.size(), 0);
     return SGV_OK;
@@ -2915,7 +3029,9 @@ int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M,
                      int use_tr, void* stream) {
     GemmTN p; memset(&p, 0, sizeof(p));
     p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
-    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_w2 = use_tr == 2 ? 1 : use_tr == 3 ? 2 : use_tr == 4 ? 3 : use_tr == 5 ? -1 : 0;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_w2 = use_tr == 2 ? 1 : use_tr == 3 ? 2 : (use_tr == 4 || use_tr == 6) ? 3 : use_tr == 5 ? -1 : 0;
+    p.out_bf16 = use_tr == 6 ? 1 : 0;          // 6: the 256 x 256 kernel with bf16 output (dW is then a bf16 array; splitk 1)
+    if (p.out_bf16 && (splitk > 1 || !gemm_tn256_eligible(dtype, p))) return fail(SGV_ERR_ARG, "sgv_test_gemm_tn: bf16 output needs the 256 x 256 kernel and splitk 1");
     float* partial = nullptr;
     const long nw = (long)taps * N1 * N2;
     if (p.splitk > 1) {

@@ -356,6 +356,25 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         if (kt == c_nkt) {
             // ================= epilogue of item ci: raw fp32 sums, 16 bytes per lane and tile =================
             const int mw = c_i0 + g * 128, nw = c_j0 + wq * 32;          // column tiles 0,1 at nw, tiles 2,3 at nw + 128
+            if (p.out_bf16) {      // same 32 stores per wave, 8 bytes per lane: round to nearest even, as the data-parallel wire copy does
+                unsigned short* outp = reinterpret_cast<unsigned short*>(p.out) + (long)c_tap * p.out_tap_stride;
+                const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)(((long)(p.N1 - 1) * p.ldo + p.N2) * 2), 0x00020000);
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const int row = mw + i * 16 + lr;
+#pragma unroll
+                    for (int nt = 0; nt < 4; ++nt) {
+                        const int col = nw + (nt >> 1) * 128 + (nt & 1) * 16 + q * 4;
+                        const bool ok = row < p.N1 && col < p.N2;
+                        const q256_f4 v = acc[i][nt];
+                        acc[i][nt] = (q256_f4){0.f, 0.f, 0.f, 0.f};
+                        typedef __bf16 q256_bf4 __attribute__((ext_vector_type(4)));
+                        typedef uint32_t q256_u2 __attribute__((ext_vector_type(2)));
+                        q256_bf4 o; o[0] = (__bf16)v[0]; o[1] = (__bf16)v[1]; o[2] = (__bf16)v[2]; o[3] = (__bf16)v[3];
+                        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(q256_u2, o), rsC, ok ? (uint32_t)(((long)row * p.ldo + col) * 2) : Q256_OOB, 0, 0);
+                    }
+                }
+            } else {
             float* outp = p.out + (long)c_z * p.out_slab_stride + (long)c_tap * p.out_tap_stride;
             const __amdgpu_buffer_rsrc_t rsC = __builtin_amdgcn_make_buffer_rsrc(outp, 0, (int)(((long)(p.N1 - 1) * p.ldo + p.N2) * 4), 0x00020000);
 #pragma unroll
@@ -369,6 +388,7 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
                     acc[i][nt] = (q256_f4){0.f, 0.f, 0.f, 0.f};
                     __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(q256_u4, v), rsC, ok ? (uint32_t)(((long)row * p.ldo + col) * 4) : Q256_OOB, 0, 0);
                 }
+            }
             }
             ci += nbx;
             const bool more = ci < it_hi;
@@ -409,6 +429,7 @@ bool gemm_tn_uses_t256(int dtype, const GemmTN& p) {
 int launch_gemm_tn256(const GemmTN& p, hipStream_t s) {
     if (!gemm_tn256_eligible(1, p)) return -1;
     if (p.splitk < 1 || (p.splitk > 1 && p.out_slab_stride <= 0)) return -1;
+    if (p.out_bf16 && (p.splitk != 1 || p.ldo % 4)) return -1;         // bf16 output: direct stores only (slabs stay fp32)
     if (q256_cdiv(p.M, 64) / p.splitk < 4) return -1;                 // every item keeps >= 4 K-tiles (prologue + counted waits)
     if (((uintptr_t)p.A & 15) || ((uintptr_t)p.B & 15) || ((uintptr_t)p.out & 15)) return -1;
     GemmTN q = p;

@@ -300,7 +300,7 @@ template <bool NT> __device__ __forceinline__ void st4(float* p, const float4 v)
 template <typename T, bool GLP = false, int NTM = 0>
 __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, const SNDesc* sn, const WorkItem* items, float lr,
                                                       float b1, float b2, float eps, float wd, float bc1, float bc2sqrt,
-                                                      double* gnorm_sq, const float* g_base = nullptr, const uint16_t* g_lp = nullptr) {
+                                                      double* gnorm_sq, const float* g_base = nullptr, const uint16_t* g_lp = nullptr, int desc_lp = 0) {
     constexpr int PITCH = 64 + (sizeof(T) == 2 ? 2 : 1);
     __shared__ T tile[64 * PITCH];
     __shared__ float tus[16][64];
@@ -334,6 +334,10 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
             float4 g;
             if constexpr (GLP) {
                 const uint2 raw = *reinterpret_cast<const uint2*>(g_lp + ((a.g + i) - g_base));       // 4 bf16, 8-byte aligned
+                g.x = __builtin_bit_cast(float, raw.x << 16); g.y = __builtin_bit_cast(float, raw.x & 0xFFFF0000u);
+                g.z = __builtin_bit_cast(float, raw.y << 16); g.w = __builtin_bit_cast(float, raw.y & 0xFFFF0000u);
+            } else if (desc_lp && a.glp) {          // this layer's weight-gradient GEMM wrote bf16 (single-GPU path, engine option grad_bf16)
+                const uint2 raw = *reinterpret_cast<const uint2*>(a.glp + i);
                 g.x = __builtin_bit_cast(float, raw.x << 16); g.y = __builtin_bit_cast(float, raw.x & 0xFFFF0000u);
                 g.z = __builtin_bit_cast(float, raw.y << 16); g.w = __builtin_bit_cast(float, raw.y & 0xFFFF0000u);
             } else {
@@ -397,13 +401,13 @@ __global__ __launch_bounds__(256) void adamw_sn_kernel(const AdamDesc* adam, con
     }
 }
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
-                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* g_base, const void* g_lp) {
+                 float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s, const float* g_base, const void* g_lp, int desc_lp) {
     if (n <= 0) return 0;
     // default 9: the moments and the bf16 operand copies bypass the caches (measured, DESIGN.md section 13: moments 12.20 -> 12.05 ms
     // per step, the pass alone 2.90 -> 2.70 ms; the copies another 0.07 ms over eleven alternations)
     static const int ntm = getenv("SGV_ADAM_NT") ? atoi(getenv("SGV_ADAM_NT")) : 9;
     const uint16_t* lp = reinterpret_cast<const uint16_t*>(g_lp);
-#define SGV_ADAM_LAUNCH(TT, GLP, MODE) hipLaunchKernelGGL((adamw_sn_kernel<TT, GLP, MODE>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp)
+#define SGV_ADAM_LAUNCH(TT, GLP, MODE) hipLaunchKernelGGL((adamw_sn_kernel<TT, GLP, MODE>), dim3(n), dim3(256), 0, s, adam_dev, sn_dev, items, lr, b1, b2, eps, wd, bc1, bc2sqrt, gnorm_sq, g_base, lp, desc_lp)
 #define SGV_ADAM_MODES(TT, GLP)                                   \
     switch (ntm) {                                                \
         case 0: SGV_ADAM_LAUNCH(TT, GLP, 0); break;               \

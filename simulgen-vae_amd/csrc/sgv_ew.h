@@ -168,6 +168,7 @@ struct AdamDesc {
     int rows, cols;    // SN geometry for the rank-1 correction (taps*rows*cols == n)
     void* wc; void* wct;  // compute-dtype copies [taps][rows][cols] and [taps'][cols][rows] (tap-flipped), or null
     int taps;
+    const unsigned short* glp;   // bf16 mirror of g (same element order) or null: read instead of g when the launch says so (desc_lp)
 };
 struct WorkItem { int desc; int chunk; };
 // <G,W_eff> of a layer lives in this many slots of the gradient arena's small zone; the AdamW pass adds them up.  The
@@ -187,7 +188,7 @@ int opt_adamw(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* it
 // 64x64-tile AdamW for spectrally-normalised conv weights; also writes wc/wct and accumulates W_new^T u into tmp_t
 int opt_adamw_sn(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, float lr, float b1, float b2,
                  float eps, float wd, float bc1, float bc2sqrt, double* gnorm_sq, int compute_dtype, hipStream_t s,
-                 const float* g_base = nullptr, const void* g_lp = nullptr);      // g_lp: gradients from the bf16 wire copy (offsets relative to g_base)
+                 const float* g_base = nullptr, const void* g_lp = nullptr, int desc_lp = 0);      // g_lp: gradients from the bf16 wire copy (offsets relative to g_base)
 int opt_grad_norm(const AdamDesc* adam_dev, const SNDesc* sn_dev, const WorkItem* items, int n, double* gnorm_sq,
                   hipStream_t s);
 int opt_make_copies(const AdamDesc* adam_dev, const WorkItem* items, int n, int compute_dtype, hipStream_t s);

@@ -432,6 +432,10 @@ def train(epochs, batch_size, train_dataloader, val_dataloader, LR, num_filter_e
         # 8 x 16 samples see the noise 1 x 128 would
         eng.seed(broadcast_replica_state(eng))
         eng.set_shard(rank, world)
+    if world == 1 and eng.compute_dtype in ("bf16", "bfloat16"):
+        # the four big layers' weight gradients go from the GEMM to the optimizer as bf16: the rounding point
+        # of the data-parallel step's bf16 wire format, which world > 1 takes by default
+        eng.set_option("grad_bf16", 1)
     fused = hasattr(train_dataloader, "batch_plans")
     data = train_dataloader.resident(eng) if fused else None
 

@@ -200,6 +200,56 @@ def test_fullsize_fused_step_is_bitwise_equal_to_separate_calls(dtype):
         assert np.array_equal(out[0][1][k], out[1][1][k]), k
 
 
+def test_fullsize_bf16_gradient_storage():
+    """Engine option grad_bf16 (single-GPU path; modules/train.py and bench.py switch it on for bf16 engines): the 256 x 256 weight-gradient kernel stores bf16 into
+    the mirror arena and the AdamW pass reads it there.  Batch 8, so that the four big layers take that kernel.  Against the plain
+    engine: the first forward is bitwise the same (nothing upstream changed), the gradient norm within 1e-3, the big weights after two
+    AdamW steps within 3e-3 rel-L2 (the bounds of the bf16 wire format of the data-parallel step, which rounds at the same point);
+    sgv_export_grad / sgv_grad_norm refresh the fp32 arena from the mirror (a big layer's gradient within 4e-3 rel-L2 of the plain
+    engine's, the norm within 1e-3); fused and separate calls are bitwise the same in this mode too."""
+    cfg = VAEConfig(32, 8, ENC, ENC[::-1], N, T, "MSE", True)
+    state = init_state(cfg, 7, reference_init=True)
+    Bs = 8
+    g = torch.Generator(device="cuda").manual_seed(9)
+    x = torch.rand((Bs, N, T), generator=g, device="cuda") * 1.4 - 0.7
+    dec = cfg.num_filter_dec
+    eps = [torch.randn((Bs, cfg.latent_dim), generator=g, device="cuda")] + \
+          [torch.randn((Bs, dec[i + 1], T), generator=g, device="cuda") for i in range(len(dec) - 2)]
+    names = BIG + ["encoder.encoder_blocks.0.module_list.0._seq.0.bias", "decoder.recon.1.bias"]
+    big = BIG[0]
+    out = []
+    for mode in ("plain", "lp_fused", "lp_separate"):
+        eng = E.Engine(cfg, max_batch=Bs, compute_dtype="bf16")
+        eng.load_state(state)
+        if mode != "plain":
+            eng.set_option("grad_bf16", 1)
+        rec, grads = [], None
+        for step in range(2):
+            eng.set_input(x)
+            eng.set_eps([e.contiguous() for e in eps])
+            sc = eng.forward(train=True)
+            if mode == "lp_separate" or (mode == "plain" and step == 0):
+                eng.backward(ALPHA, BETA)
+                if step == 0:
+                    grads = (eng.grad(big), eng.grad_norm())
+                eng.adamw_step(1e-3)
+            else:
+                eng.backward_step(ALPHA, BETA, 1e-3)
+            rec.append((sc["recon"], tuple(sc["kls"]), eng.last_grad_norm()))
+        sd = eng.state_dict()
+        out.append((rec, {k: sd[k] for k in names}, grads))
+        eng.close()
+    plain, fused, sep = out
+    assert plain[0][0][:2] == fused[0][0][:2] == sep[0][0][:2]                      # first forward: same losses
+    assert fused[0] == sep[0], (fused[0], sep[0])                                   # schedule only
+    for k in names:
+        assert np.array_equal(fused[1][k], sep[1][k]), k
+        assert rel_l2(fused[1][k], plain[1][k]) < 3e-3, (k, rel_l2(fused[1][k], plain[1][k]))
+    assert abs(fused[0][0][2] - plain[0][0][2]) <= 1e-3 * plain[0][0][2]
+    assert rel_l2(sep[2][0], plain[2][0]) < 4e-3, rel_l2(sep[2][0], plain[2][0])
+    assert abs(sep[2][1] - plain[2][1]) <= 1e-3 * plain[2][1]
+
+
 @pytest.mark.parametrize("payload", ["f32", "bf16"])
 def test_fullsize_engine_issued_data_parallel_step(monkeypatch, payload):
     """The data-parallel step at full size through REAL RCCL calls on a one-rank group (SGV_FORCE_COLLECTIVE=1: every bucket packed,
@@ -208,7 +258,9 @@ def test_fullsize_engine_issued_data_parallel_step(monkeypatch, payload):
     updated in two row chunks of its weight-gradient GEMM (batch 8: that GEMM is in the big-GEMM regime).  AVG over one rank is the
     identity, so with the fp32 wire format two steps must leave BITWISE the state of the plain step; with the bf16 wire format the
     weight gradients are rounded once to bf16 on the way (gradient norm within 1e-3, the big weights within 3e-3 rel-L2 of the
-    plain step after two AdamW steps)."""
+    plain step after two AdamW steps) -- by the 256 x 256 weight-gradient kernel's bf16 epilogue for the four big layers (the wire
+    copy straight from the GEMM), by the pack pass for the rest; SGV_WIRE_DIRECT=0 sends everything through the pack pass: bitwise
+    the same step."""
     import torch.distributed as dist
     from simulgen_vae_amd.modules.train import NativeAllReduce
     monkeypatch.setenv("SGV_FORCE_COLLECTIVE", "1")
@@ -229,10 +281,12 @@ def test_fullsize_engine_issued_data_parallel_step(monkeypatch, payload):
         created = True
     try:
         out = []
-        for mode in ("plain", "ddp"):
+        for mode in ("plain", "ddp") + (("ddp_packed",) if payload == "bf16" else ()):
+            # ddp_packed: the wire copy of the four big layers made by the pack pass from the fp32 result instead of by the GEMM itself
+            monkeypatch.setenv("SGV_WIRE_DIRECT", "0" if mode == "ddp_packed" else "1")
             eng = E.Engine(cfg, max_batch=Bs, compute_dtype="bf16")
             eng.load_state(state)
-            ar = NativeAllReduce.create(eng)[0] if mode == "ddp" else None
+            ar = NativeAllReduce.create(eng)[0] if mode != "plain" else None
             assert ar is None or not ar.single
             rec = []
             for step in range(2):
@@ -249,7 +303,12 @@ def test_fullsize_engine_issued_data_parallel_step(monkeypatch, payload):
             if ar is not None:
                 ar.close()
             eng.close()
-        (ra, sa), (rb, sb) = out
+        (ra, sa), (rb, sb) = out[0], out[1]
+        if payload == "bf16":      # the GEMM's bf16 epilogue rounds the same accumulators the pack pass rounds: bit for bit the same step
+            rc, sc_ = out[2]
+            assert rb == rc, (rb, rc)
+            for k in names:
+                assert np.array_equal(sb[k], sc_[k]), k
         if payload == "f32":
             assert ra == rb, (ra, rb)
             for k in names:

@@ -422,6 +422,27 @@ def test_gemm_tn256(case):
         assert np.abs(out.cpu().numpy() - r2).max() / np.abs(r2).max() < 2e-5
 
 
+@pytest.mark.parametrize("case", [c for c in TN256_CASES if c[5] == 1])
+def test_gemm_tn256_bf16_output(case):
+    """The same kernel with its bf16 epilogue (GemmTN::out_bf16, engine option grad_bf16): exactly the fp32 result rounded to nearest
+    even -- the accumulators are the same, only the store differs -- including the ragged edge tiles (no store outside the matrix: the
+    canary behind it survives)."""
+    import torch
+    lib = E.load_library()
+    M, N1, N2, taps, Tlen, _ = case
+    rng = np.random.default_rng(29)
+    dY = _bf16_round(rng.standard_normal((M, N1)).astype(np.float32))
+    X = _bf16_round(rng.standard_normal((M, N2)).astype(np.float32))
+    ddY, dX = _dev(dY, 1), _dev(X, 1)
+    ref32 = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+    assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), ref32.data_ptr(), M, N1, N2, taps, Tlen, 1, 4, None) == 0, lib.sgv_last_error()
+    n = taps * N1 * N2
+    out = torch.full((n + 64,), -7.0, dtype=torch.bfloat16, device="cuda")
+    assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, 1, 6, None) == 0, lib.sgv_last_error()
+    assert torch.equal(out[:n].view(taps, N1, N2), ref32.to(torch.bfloat16))
+    assert bool((out[n:] == -7.0).all())
+
+
 @pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1),
                                   (300, 296, 9008, 1, 100, 2), (256, 512, 4160, 1, 64, 1)])
 def test_gemm_nt_wide_stress(case):
