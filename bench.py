@@ -272,7 +272,8 @@ def main():
               f"({data.numel() / 1e9:.1f} GB), dtype {args.dtype}", file=sys.stderr)
 
     ddp = world > 1 or (os.environ.get("SGV_FORCE_DDP") == "1" and dist.is_initialized())   # forced: plumbing test at N=1
-    if not ddp and args.dtype == "bf16" and os.environ.get("SGV_BENCH_GRAD_BF16", "1") != "0":
+    grad_bf16 = not ddp and args.dtype == "bf16" and os.environ.get("SGV_BENCH_GRAD_BF16", "1") != "0"
+    if grad_bf16:
         eng.set_option("grad_bf16", 1)    # as modules/train.py does on one GPU: the big layers' gradients reach AdamW as bf16 (the data-parallel step's wire rounding)
     # bucketed mean all-reduce over RCCL, overlapped with backward and with AdamW (modules/train.py GradAllReduce)
     allreduce = make_allreduce(eng) if ddp else None
@@ -378,6 +379,8 @@ def main():
                   "step_tflops": round((fwd + dx + dw) / (ms * 1e-3) / 1e12, 2),
                   "roofline": roof}
         result["config"].update(ddp_info)
+        result["config"]["weight_grad_storage"] = "bf16 for the 256x256-TN layers (engine option grad_bf16)" if grad_bf16 else ("bf16 wire copy" if ddp_info.get("grad_payload") == "bf16" else "f32")
+        result["config"]["prefetched_augmentation"] = bool(prefetch)
         mem = eng.memory_info()
         result["config"]["resident_gib"] = round(sum(mem.values()) / 2 ** 30, 2)
         if args.recompute:
