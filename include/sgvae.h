@@ -334,7 +334,9 @@ int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const
  * Bits 8-15 of mode choose the work-item order of the 256x256 kernel (0: the launcher's choice, 1..254: row tiles in bands of
  * that many, 255: column-panel-major), bits 16-18 the cache policy of its streams (0: the launcher's choice, 7: default loads and
  * stores, else bit 0 = non-temporal weight loads, bit 1 = sc1 output stores), bits 19-20 its tile shape (0: 256 x 256 with mode 0 /
- * the plan's choice with mode 1, 1: 128 x 512, 2: the plan must not pick 128 x 512). */
+ * the plan's choice with mode 1, 1: 128 x 512, 2: the plan must not pick 128 x 512), bit 21 the split the engine runs on two
+ * streams (M = 128 mod 256, bf16 output: the first M - 128 rows on the 256 x 256 kernel in `splitk` slices, the last 128 rows as a
+ * launch of their own of the 128 x 512 tile shape on shifted row pointers; here one after the other on `stream`). */
 int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
                         int K, int taps, int Tlen, int splitk, int out_f32, int mode, int Cg, double* sums, int* plan_kind, void* stream);
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,

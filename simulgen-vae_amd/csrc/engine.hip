@@ -234,6 +234,7 @@ struct sgv_engine {
     // of small kernels that leave most of the chip idle, so they run side by side on two streams with workspaces of their own
     hipStream_t lane2 = nullptr; float* partial2 = nullptr; float* colpart2 = nullptr; float* gn_part2 = nullptr;
     hipEvent_t lane_fork = nullptr, lane_join = nullptr;
+    hipEvent_t tail_fork = nullptr, tail_join = nullptr;      // concurrent 128-row tail of a one-tap 256 x 256 launch (launch_nt)
     int use_lanes = getenv("SGV_LANES") ? atoi(getenv("SGV_LANES")) : 1;
     // small Conv1d -> GroupNorm -> GELU stages in one launch (convgn.hip); SGV_CONVGN=0 restores GEMM + combine + GroupNorm kernels
     int use_convgn = getenv("SGV_CONVGN") ? atoi(getenv("SGV_CONVGN")) : 1;
@@ -901,6 +902,28 @@ static int conv_fwd_stats_mode(sgv_engine* e, const Layer& l, const Tensor& x, c
 static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, int Cg, int G) {
     return conv_fwd_stats_mode(e, l, x, y, M, Cg, G) != 0;
 }
+// A planned 256 x 256 launch whose 128-row tail would follow it as a second launch (M = 3200: rows 3072..3199): when the main
+// launch leaves CUs free -- 240 work items on 256 CUs, the K = 95 008 products -- the tail runs BESIDE it instead, on the lane
+// stream, as one round of <= 16 items of the 128 x 512 tile shape (each workgroup of either launch needs a CU of its own, and
+// 240 + 16 = 256, so both are resident whatever the order they are placed in).  The tail is addressed by shifted row pointers
+// (GemmNT::trow0 keeps the tap windows of a multi-tap product on the absolute rows); gemm_nt_tail_split decides.
+static int launch_nt(sgv_engine* e, const GemmNT& p, const GemmPlan& pl) {
+    if (e->use_lanes && e->lane2 && e->tail_fork && !e->timing && e->stream != e->lane2) {
+        const int sk_t = gemm_nt_tail_split(e->dt, p, pl, e->partial_floats);
+        if (sk_t > 0) {
+            HIPCHK(hipEventRecord(e->tail_fork, e->stream));
+            HIPCHK(hipStreamWaitEvent(e->lane2, e->tail_fork, 0));
+            int r = launch_gemm_nt_main(p, pl, e->stream);
+            if (r) return r;
+            r = launch_gemm_nt_tail(p, pl, sk_t, e->partial2, e->lane2);
+            if (r) return r;
+            HIPCHK(hipEventRecord(e->tail_join, e->lane2));
+            HIPCHK(hipStreamWaitEvent(e->stream, e->tail_join, 0));
+            return 0;
+        }
+    }
+    return launch_gemm_nt_planned(e->dt, p, pl, e->stream);
+}
 static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor& y, long M, double* gn_sums = nullptr, int gn_Cg = 0,
                     int gn_G = 0) {
     GemmNT p; conv_fwd_params(e, l, x, y, M, p);
@@ -911,7 +934,7 @@ static int conv_fwd(sgv_engine* e, const Layer& l, const Tensor& x, const Tensor
     if (smode == 2) { p.gn_sums = gn_sums; p.gn_part = e->gn_part; }
     else if (smode == 1) { p.gn_sums = gn_sums; }
     ScopedTimer tm(e, pl.kind ? "gemm_nt_t256" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, pl.sk_main);
-    int r = launch_gemm_nt_planned(e->dt, p, pl, e->stream);
+    int r = launch_nt(e, p, pl);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt launch failed for %s (M=%d N=%d K=%d, kind %d)", l.prefix.c_str(), p.M, p.N, p.K, pl.kind);
     return 0;
 }
@@ -927,7 +950,7 @@ static int conv_bwd_dx(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     p.partial = e->partial;
     const GemmPlan pl = gemm_nt_plan(e->dt, p, e->partial_floats, 0);
     ScopedTimer tm(e, pl.kind ? "gemm_nt_t256" : gemm_nt_uses_wide(e->dt, p.N, p.K, p.taps) ? "gemm_nt_wide" : "gemm_nt", &l, p.M, p.N, p.K, p.taps, pl.sk_main);
-    int r = launch_gemm_nt_planned(e->dt, p, pl, e->stream);
+    int r = launch_nt(e, p, pl);
     if (r) return fail(SGV_ERR_ARG, "gemm_nt(dX) launch failed for %s", l.prefix.c_str());
     return 0;
 }
@@ -1536,7 +1559,8 @@ int sgv_create(const sgv_config* cfg, void* hip_stream, sgv_engine** out) {
     for (auto& l : e->layers) if (l.used && l.op != OP_LINEAR) e->gn_part_floats = std::max(e->gn_part_floats, gemm_nt256_part_floats((int)M, l.cout, 1));
     ALLOC(e->gn_part, e->gn_part_floats * 4);
     if (e->use_lanes && make_aux_stream(&e->lane2, "SGV_PRIO_LANE", SGV_PRIO_LANE_DEFAULT, {e->stream}) == hipSuccess &&
-        hipEventCreateWithFlags(&e->lane_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->lane_join, hipEventDisableTiming) == hipSuccess) {
+        hipEventCreateWithFlags(&e->lane_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->lane_join, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&e->tail_fork, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&e->tail_join, hipEventDisableTiming) == hipSuccess) {
         ALLOC(e->partial2, e->partial_floats * 4);
         ALLOC(e->gn_part2, e->gn_part_floats * 4);
     } else {
@@ -1582,6 +1606,8 @@ int sgv_destroy(sgv_engine* e) {
         hipEventDestroy(e->aug_done); hipEventDestroy(e->aug_gate); hipEventDestroy(e->x_free[0]); hipEventDestroy(e->x_free[1]); hipFree(e->aug_ctl);
     }
     if (e->lane_fork) hipEventDestroy(e->lane_fork);
+    if (e->tail_fork) hipEventDestroy(e->tail_fork);
+    if (e->tail_join) hipEventDestroy(e->tail_join);
     if (e->lane_join) hipEventDestroy(e->lane_join);
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
@@ -2983,9 +3009,31 @@ int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias
     p.strm = strm_code == 7 ? -1 : strm_code;
     const int ts_code = (mode >> 19) & 3;
     p.ts = ts_code == 1 ? 1 : ts_code == 2 ? -1 : 0;
+    const bool split_tail = (mode >> 21) & 1;          // planned launch with the 128-row tail as its own 128 x 512 launch (the engine runs it beside the main one)
     mode &= 0xff;
     int r;
-    if (mode == 0) {
+    if (split_tail) {
+        // the split is forced here (the planner's cost comparison and the "tail shorter than the main launch" rule decide speed, not results)
+        GemmPlan pl = gemm_nt_plan(SGV_DTYPE_BF16, p, cap, 0);
+        if (M % 256 != 128 || M < 384) { hipFree(partial); return fail(SGV_ERR_ARG, "split-tail test mode needs M = 128 (mod 256)"); }
+        pl.kind = 2; pl.m_main = M - 128; pl.fuse_stats = 0;
+        pl.sk_main = std::max(1, std::min(p.splitk, 8));
+        if (plan_kind) *plan_kind = pl.kind;
+        float* tp = nullptr;
+        HIPCHK(hipMalloc((void**)&tp, sizeof(float) * cap));
+        int sk_t = gemm_nt_tail_split(SGV_DTYPE_BF16, p, pl, cap);
+        if (sk_t <= 0) {
+            const long tkt = (long)taps * ((K + 63) / 64);
+            sk_t = (int)std::max(1L, std::min((long)(16 / std::max(1, (N + 511) / 512)), tkt / 24));
+        }
+        if (N < 512) r = -4;
+        else {
+            r = launch_gemm_nt_main(p, pl, (hipStream_t)stream);
+            if (!r) r = launch_gemm_nt_tail(p, pl, sk_t, tp, (hipStream_t)stream);
+        }
+        hipStreamSynchronize((hipStream_t)stream);
+        hipFree(tp);
+    } else if (mode == 0) {
         if (plan_kind) *plan_kind = p.ts == 1 ? 3 : 1;
         if (p.ts < 0) p.ts = 0;
         r = launch_gemm_nt256(p, (hipStream_t)stream);

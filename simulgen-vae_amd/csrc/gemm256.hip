@@ -159,7 +159,7 @@ __global__ __launch_bounds__(512) void gemm_nt_t256_kernel(const GemmNT p) {
 #define T256_ROWMASK(DST, AM)                                                                                 \
     {                                                                                                         \
         uint32_t mk_ = 0u;                                                                                    \
-        const int at_ = (AM) % p.Tlen;                                                                        \
+        const int at_ = ((AM) + p.trow0) % p.Tlen;                                                            \
         for (int j_ = 0; j_ < p.taps; ++j_)                                                                   \
             if ((unsigned)(at_ + j_ - p.pad) >= (unsigned)p.Tlen) mk_ |= 1u << j_;                            \
         DST = mk_;                                                                                            \
@@ -740,7 +740,7 @@ static inline int t256_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 bool gemm_nt256_eligible(int dtype, const GemmNT& p) {
     static const int on = getenv("SGV_GEMM_T256") ? atoi(getenv("SGV_GEMM_T256")) : 1;
     if (!on || dtype != 1) return false;
-    if (p.N < 256 || p.M < 256) return false;
+    if (p.N < 256 || p.M < (p.ts > 0 ? 128 : 256)) return false;      // the 128 x 512 tile shape takes a single 128-row tile too
     if (p.K % 8 || p.N % 8 || p.lda % 8 || p.ldw % 8 || p.w_tap_stride % 8 || p.ldc % 8) return false;
     if (p.addend && p.ldadd % 8) return false;
     if (((uintptr_t)p.C & 15) || (p.addend && ((uintptr_t)p.addend & 15))) return false;
@@ -914,6 +914,37 @@ GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int wan
     else { pl.kind = 1; pl.sk_main = sk_all; }
     if (wide_ok && (wide == 2 || c_wide < (c_main < c_all ? c_main : c_all))) { pl.kind = 3; pl.sk_main = sk_wide; pl.sk_tail = 1; pl.m_main = p.M; }
     return pl;
+}
+int gemm_nt_tail_split(int dtype, const GemmNT& p, const GemmPlan& pl, size_t tail_partial_floats) {
+    static const int on = getenv("SGV_TAIL_CONCURRENT") ? atoi(getenv("SGV_TAIL_CONCURRENT")) : 1;
+    const int rem = p.M - pl.m_main;
+    if (!on || dtype != 1 || pl.kind != 2 || pl.fuse_stats || p.cv_kw || rem != 128 || p.N < 512 || p.row0 || p.out_f32 || p.add_W > 0 || p.trow0) return 0;
+    if (pl.m_main < p.pad || p.taps > 24) return 0;
+    const int ctiles = (p.N + 511) / 512;
+    const long total_kt = (long)p.taps * ((p.K + 63) / 64);
+    const int main_items = (pl.m_main / 256) * ((p.N + 255) / 256) * pl.sk_main;
+    int sk_t = ctiles <= 16 ? 16 / ctiles : 0;
+    while (sk_t > 1 && total_kt / sk_t < 24) --sk_t;
+    if (sk_t < 1 || main_items + ctiles * sk_t > 256) return 0;
+    // a K-tile of the 128 x 512 tile costs 1.13 of the square tile's (t256_cost): the tail must be over before the main launch
+    if ((double)total_kt / sk_t * 1.13 > (double)total_kt / pl.sk_main * 1.05) return 0;
+    if ((size_t)sk_t * rem * p.N > tail_partial_floats) return 0;
+    return sk_t;
+}
+int launch_gemm_nt_main(const GemmNT& p, const GemmPlan& pl, hipStream_t s) {
+    GemmNT q = p;
+    q.splitk = pl.sk_main; q.gn_part = nullptr; q.gn_sums = nullptr; q.ts = 0; q.M = pl.m_main; q.a_rows = p.M;
+    return launch_gemm_nt256(q, s);
+}
+int launch_gemm_nt_tail(const GemmNT& p, const GemmPlan& pl, int sk_tail, float* tail_partial, hipStream_t s) {
+    GemmNT t = p;
+    const int rem = p.M - pl.m_main;
+    t.gn_part = nullptr; t.gn_sums = nullptr;
+    t.A = (const char*)p.A + (size_t)pl.m_main * p.lda * 2;
+    t.C = (char*)p.C + (size_t)pl.m_main * p.ldc * 2;
+    if (p.addend) t.addend = (const char*)p.addend + (size_t)pl.m_main * p.ldadd * 2;
+    t.M = rem; t.a_rows = rem; t.trow0 = pl.m_main % p.Tlen; t.ts = 1; t.splitk = sk_tail; t.partial = tail_partial; t.band = -1; t.strm = -1;
+    return launch_gemm_nt256(t, s);
 }
 int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s) {
     if (pl.kind == 0) {

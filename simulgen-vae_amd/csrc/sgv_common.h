@@ -164,6 +164,8 @@ struct GemmNT {
     int band, strm;
     int ts;                         // tile shape of the 256-thread... 512-thread persistent kernel: 0 = 256 x 256, 1 = 128 x 512 (set by
                                     // launch_gemm_nt_planned from the plan; tests set it directly); < 0: the planner must not pick 128 x 512
+    int trow0;                      // gemm256.hip: row 0 of this launch is row trow0 of the sample grid (a launch on a row range addressed by shifted
+                                    // pointers: the tap windows of a multi-tap product follow the absolute row)
 };
 // gemm256.hip
 bool gemm_nt256_eligible(int dtype, const GemmNT& p);
@@ -178,6 +180,12 @@ int launch_gemm_nt256(const GemmNT& p, hipStream_t s);
 // deterministically (kind 1, split-K 1).
 struct GemmPlan { int kind, sk_main, sk_tail, m_main, fuse_stats; };
 GemmPlan gemm_nt_plan(int dtype, const GemmNT& p, size_t partial_floats, int want_stats);
+// A kind-2 plan (256 x 256 kernel on the first rows + a 128-row tail launch) whose tail can run BESIDE the main launch as one round
+// of <= 16 items of the 128 x 512 tile shape (the main launch leaves that many CUs free and the tail is over before it):
+// gemm_nt_tail_split returns the tail's split-K factor, 0 if the plan does not qualify; launch_gemm_nt_main / _tail issue the halves.
+int gemm_nt_tail_split(int dtype, const GemmNT& p, const GemmPlan& pl, size_t tail_partial_floats);
+int launch_gemm_nt_main(const GemmNT& p, const GemmPlan& pl, hipStream_t s);
+int launch_gemm_nt_tail(const GemmNT& p, const GemmPlan& pl, int sk_tail, float* tail_partial, hipStream_t s);
 int launch_gemm_nt_planned(int dtype, const GemmNT& p, const GemmPlan& pl, hipStream_t s);
 bool gemm_nt_can_fuse_stats(int dtype, int M, int N, int K, int taps, int Tlen, int Cg);
 struct GemmTN {

@@ -191,6 +191,12 @@ NT256_CASES = [
     (3200, 10240, 256, 5, 200, 1, 0 | (1 << 19) | (5 << 8)), # 500 items, row tiles in bands of 5: item transitions inside a workgroup
     (256, 512, 95008, 1, 128, 4, 0 | (1 << 19)),             # the first encoder layer's K, four slices
     (3200, 2560, 1280, 5, 200, 0, 1 | (2 << 19)),            # planned with the 128 x 512 tile forbidden: main + tail as in round 2
+    # bit 21: the planned launch with its 128-row tail as a launch of its own on shifted row pointers (the engine runs it BESIDE the
+    # main launch on the lane stream): one round of <= 16 items of the 128 x 512 tile, GemmNT::trow0 = 3072 % 200 = 72 for the tap windows
+    (3200, 1024, 8200, 1, 200, 3, 1 | (1 << 21)),            # one tap, K tail of 8, main launch in 3 slices, tail in 5
+    (3200, 2560, 1280, 5, 200, 2, 1 | (1 << 21)),            # five taps: the tail's first rows continue the sample that starts in the main rows
+    (3200, 2560, 1536, 3, 128, 1, 1 | (1 << 21)),            # three taps, sample length 128: the tail starts exactly on a sample boundary
+    (1408, 1288, 520, 3, 88, 1, 1 | (1 << 21)),              # ragged column tile, sample length 88 (1280 % 88 = 48)
 ]
 
 
@@ -223,7 +229,9 @@ def test_gemm_nt256(case):
     rc = lib.sgv_test_gemm_nt256(dA.data_ptr(), dW.data_ptr(), out2.data_ptr(), dbias.data_ptr(), dscale.data_ptr(), dadd.data_ptr(), M, N, K,
                                  taps, Tlen, splitk, 0, mode, 0, None, C.byref(kind), None)
     assert rc == 0, lib.sgv_last_error()
-    if base == 1:
+    if (mode >> 21) & 1:
+        assert kind.value == 2, kind.value                  # forced: 256-row tiles + the 128-row tail on shifted pointers
+    elif base == 1:
         if (mode >> 19) & 3 == 2:
             assert kind.value != 3, kind.value
         assert (kind.value in (1, 2, 3)) if N * K * taps >= 1024 * 1280 * 5 else kind.value == 0, kind.value
