@@ -234,7 +234,8 @@ struct sgv_engine {
     // of small kernels that leave most of the chip idle, so they run side by side on two streams with workspaces of their own
     hipStream_t lane2 = nullptr; float* partial2 = nullptr; float* colpart2 = nullptr; float* gn_part2 = nullptr;
     hipEvent_t lane_fork = nullptr, lane_join = nullptr;
-    hipEvent_t tail_fork = nullptr, tail_join = nullptr;      // concurrent 128-row tail of a one-tap 256 x 256 launch (launch_nt)
+    hipEvent_t tail_fork = nullptr, tail_join = nullptr;      // concurrent 128-row tail of a 256 x 256 launch (launch_nt)
+    bool coll_inflight = false;        // data-parallel backward, from the first released bucket on: a collective's channel workgroups may hold CUs
     int use_lanes = getenv("SGV_LANES") ? atoi(getenv("SGV_LANES")) : 1;
     // small Conv1d -> GroupNorm -> GELU stages in one launch (convgn.hip); SGV_CONVGN=0 restores GEMM + combine + GroupNorm kernels
     int use_convgn = getenv("SGV_CONVGN") ? atoi(getenv("SGV_CONVGN")) : 1;
@@ -908,7 +909,9 @@ static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& x,
 // 240 + 16 = 256, so both are resident whatever the order they are placed in).  The tail is addressed by shifted row pointers
 // (GemmNT::trow0 keeps the tap windows of a multi-tap product on the absolute rows); gemm_nt_tail_split decides.
 static int launch_nt(sgv_engine* e, const GemmNT& p, const GemmPlan& pl) {
-    if (e->use_lanes && e->lane2 && e->tail_fork && !e->timing && e->stream != e->lane2) {
+    // not while a collective may be resident: the tail takes exactly the CUs the main launch leaves free, and a static item list that
+    // finds fewer CUs than items runs a second round
+    if (e->use_lanes && e->lane2 && e->tail_fork && !e->timing && e->stream != e->lane2 && !e->coll_inflight) {
         const int sk_t = gemm_nt_tail_split(e->dt, p, pl, e->partial_floats);
         if (sk_t > 0) {
             HIPCHK(hipEventRecord(e->tail_fork, e->stream));
@@ -2338,6 +2341,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     };
     auto fire_at = [&](int b) {
         if (b < 0 || b >= (int)e->buckets.size()) return;
+        if (e->cb || (e->comm && !comm_is_single(e->comm))) e->coll_inflight = true;
         if (e->comm || e->cb) {
             const hipStream_t ws = e->comm ? e->comm_stream : (e->use_wire ? e->wire : nullptr);
             if (ws ? gather_on(ws) : join_side(e)) { early_err = 1; return; }
@@ -2542,7 +2546,7 @@ static int backward_impl(sgv_engine* e, float alpha, float beta, float fuse_lr) 
     return SGV_OK;
 }
 // every path out of backward_impl has joined the side stream: the main stream's position is past the last reader of the batch
-static int backward_done(sgv_engine* e, int rc) { if (rc == SGV_OK) x_release(e); return rc; }
+static int backward_done(sgv_engine* e, int rc) { e->coll_inflight = false; if (rc == SGV_OK) x_release(e); return rc; }
 int sgv_backward(sgv_engine* e, float alpha, float beta) { return backward_done(e, backward_impl(e, alpha, beta, -1.f)); }
 int sgv_backward_step(sgv_engine* e, float alpha, float beta, float lr) {
     if (lr < 0.f) return fail(SGV_ERR_ARG, "negative learning rate");
