@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL: SGV_PACE / SGV_SLAB_DEFER were removed together with the experiment; kept as the record of how it was run.
 # Round 3 A/B: paced AdamW (SGV_PACE) and deferred split-K combines (SGV_SLAB_DEFER) on the whole step, alternating on one box.
 R=${GRAFT_REPO_ROOT:-$PWD}
 O=$R/gpurun_out/${1:-pace_ab}

@@ -1,4 +1,5 @@
 #!/bin/bash
+# HISTORICAL: the MFMA-statistics build was removed; kept as the record of how it was run.
 # GroupNorm statistics of the 256x256 kernel's epilogue through MFMA (in-tree build) vs VALU (SGV_LIB = -DT256_MFMA_STATS=0 build)
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${1:-stats_ab}; mkdir -p $O; B=$R/tests/micro/gemm_bench.py
 for i in 1 2 3; do
