@@ -339,8 +339,12 @@ int sgv_test_conv_gn_bwd(const void* A, const void* W, const float* scale, const
  * launch of their own of the 128 x 512 tile shape on shifted row pointers; here one after the other on `stream`). */
 int sgv_test_gemm_nt256(const void* A, const void* W, void* C, const float* bias, const float* scale, const void* addend, int M, int N,
                         int K, int taps, int Tlen, int splitk, int out_f32, int mode, int Cg, double* sums, int* plan_kind, void* stream);
+/* Weight-gradient GEMM test hook.  use_tr: 0 plain LDS reads, 1 the launcher's choice, 2 force the 128x256 two-blocks-per-CU kernel,
+ * 3 the same with its persistent walk, 4 force the persistent 256x256 kernel (csrc/gemm256tn.hip), 5 never that kernel, 6 that kernel
+ * with its bf16 epilogue (dW is then a bf16 array; splitk 1), 7 that kernel in its work-stealing form (what a data-parallel backward
+ * launches while a collective may hold CUs; results bitwise those of 4). */
 int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M, int N1, int N2, int taps,
-                     int Tlen, int splitk, int use_tr /* 2: force the 128x256 two-blocks-per-CU kernel */, void* stream);
+                     int Tlen, int splitk, int use_tr, void* stream);
 /* Test hook for the stream placement: *overlaps = 1 if kernels of the engine's auxiliary stream `which` (0 second lane, 1 weight-
  * gradient side stream, 2 optimizer stream, 3 the engine's communication stream; 2 and 3 are created by the call if need be) can run
  * while a kernel of the engine stream is running, i.e. the two do not share a hardware queue; -1 if the engine has no such stream. */

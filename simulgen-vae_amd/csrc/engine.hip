@@ -236,6 +236,8 @@ struct sgv_engine {
     hipEvent_t lane_fork = nullptr, lane_join = nullptr;
     hipEvent_t tail_fork = nullptr, tail_join = nullptr;      // concurrent 128-row tail of a 256 x 256 launch (launch_nt)
     bool coll_inflight = false;        // data-parallel backward, from the first released bucket on: a collective's channel workgroups may hold CUs
+    int* tn_sched = nullptr;           // 8 x 520 ints: work-stealing state of the 256 x 256 weight-gradient launches issued while coll_inflight
+    unsigned tn_sched_next = 0;
     int use_lanes = getenv("SGV_LANES") ? atoi(getenv("SGV_LANES")) : 1;
     // small Conv1d -> GroupNorm -> GELU stages in one launch (convgn.hip); SGV_CONVGN=0 restores GEMM + combine + GroupNorm kernels
     int use_convgn = getenv("SGV_CONVGN") ? atoi(getenv("SGV_CONVGN")) : 1;
@@ -1094,6 +1096,7 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
             q.A = (const char*)dy.p + (size_t)c * rows * e->esz;
             q.out = G + (size_t)c * rows * l.cin;
             if (direct) { q.out = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(e->grads_lp) + l.gw + (size_t)c * rows * l.cin); q.out_bf16 = 1; }
+            if (e->coll_inflight && e->tn_sched && !(getenv("SGV_TN256_STEAL") && atoi(getenv("SGV_TN256_STEAL")) == 0)) q.sched = e->tn_sched + 520 * (e->tn_sched_next++ & 7);
             if (launch_gemm_tn(e->dt, q, st)) return fail(SGV_ERR_ARG, "gemm_tn launch failed for %s (rows %d..%d)", l.prefix.c_str(), c * rows, (c + 1) * rows);
             if (e->dw_chunk_hook && e->dw_chunk_hook(c, e->dw_chunks, c * rows, (c + 1) * rows)) return fail(SGV_ERR_HIP, "weight-gradient chunk exchange failed for %s", l.prefix.c_str());
         }
@@ -1104,6 +1107,9 @@ static int conv_bwd_dw(sgv_engine* e, const Layer& l, const Tensor& dy, const Te
     if (sk == 1) {
         p.splitk = 1; p.out = G;
         // grad_bf16: the 256 x 256 kernel rounds its accumulators to bf16 on the way out; the AdamW pass reads them there
+        // a resident collective may keep some of the persistent kernel's workgroups off the chip: the work-stealing form (gemm256tn.hip)
+        static const int steal_on = getenv("SGV_TN256_STEAL") ? atoi(getenv("SGV_TN256_STEAL")) : 1;
+        if (steal_on && e->coll_inflight && e->tn_sched) p.sched = e->tn_sched + 520 * (e->tn_sched_next++ & 7);
         const bool opt_lp = l.lp && grad_lp_active(e), wire_lp = l.lp && !opt_lp && wire_lp_active(e);
         const bool lp = (opt_lp || wire_lp) && gemm_tn_uses_t256(e->dt, p);
         if (lp) { p.out = reinterpret_cast<float*>(reinterpret_cast<unsigned short*>(e->grads_lp) + l.gw); p.out_bf16 = 1; }
@@ -1615,6 +1621,7 @@ int sgv_destroy(sgv_engine* e) {
     for (auto ev : e->ev_pool) hipEventDestroy(ev);
     for (auto& t : e->timers) { hipEventDestroy(t.a); hipEventDestroy(t.b); }
     if (e->grads_lp) hipFree(e->grads_lp);
+    if (e->tn_sched) hipFree(e->tn_sched);
     delete e;
     return SGV_OK;
 }
@@ -2262,6 +2269,7 @@ int sgv_set_rccl(sgv_engine* e, void* rccl_comm, void* comm_stream) {
             e->bucket_done.push_back(ev);
         }
         e->bucket_pending.assign(e->buckets.size(), 0);
+        if (!e->tn_sched) HIPCHK(hipMalloc((void**)&e->tn_sched, 8 * 520 * sizeof(int)));
     }
     e->comm = rccl_comm;
     e->comm_stream = (hipStream_t)comm_stream;
@@ -2271,6 +2279,7 @@ int sgv_set_rccl(sgv_engine* e, void* rccl_comm, void* comm_stream) {
 int sgv_set_bucket_callback(sgv_engine* e, sgv_bucket_cb cb, void* user) {
     if (!e) return fail(SGV_ERR_ARG, "null engine");
     if (cb && e->comm) return fail(SGV_ERR_STATE, "an RCCL communicator is registered: use one of the two data-parallel paths");
+    if (cb && !e->tn_sched) HIPCHK(hipMalloc((void**)&e->tn_sched, 8 * 520 * sizeof(int)));
     e->cb = cb; e->cb_user = user;
     return SGV_OK;
 }
@@ -3081,8 +3090,11 @@ int sgv_test_gemm_tn(int dtype, const void* A, const void* Bm, float* dW, int M,
                      int use_tr, void* stream) {
     GemmTN p; memset(&p, 0, sizeof(p));
     p.A = A; p.lda = N1; p.B = Bm; p.ldb = N2; p.out = dW; p.ldo = N2; p.out_tap_stride = (long)N1 * N2;
-    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_w2 = use_tr == 2 ? 1 : use_tr == 3 ? 2 : (use_tr == 4 || use_tr == 6) ? 3 : use_tr == 5 ? -1 : 0;
+    p.M = M; p.N1 = N1; p.N2 = N2; p.taps = taps; p.pad = (taps - 1) / 2; p.Tlen = Tlen; p.splitk = splitk < 1 ? 1 : splitk; p.use_tr = use_tr != 0; p.force_w2 = use_tr == 2 ? 1 : use_tr == 3 ? 2 : (use_tr == 4 || use_tr == 6 || use_tr == 7) ? 3 : use_tr == 5 ? -1 : 0;
     p.out_bf16 = use_tr == 6 ? 1 : 0;          // 6: the 256 x 256 kernel with bf16 output (dW is then a bf16 array; splitk 1)
+    // 7: the 256 x 256 kernel in its work-stealing form
+    static int* test_sched = nullptr;          // allocated once: an allocation per call would wait for whatever else runs on the device
+    if (use_tr == 7) { if (!test_sched) HIPCHK(hipMalloc((void**)&test_sched, 513 * sizeof(int))); p.sched = test_sched; }
     if (p.out_bf16 && (splitk > 1 || !gemm_tn256_eligible(dtype, p))) return fail(SGV_ERR_ARG, "sgv_test_gemm_tn: bf16 output needs the 256 x 256 kernel and splitk 1");
     float* partial = nullptr;
     const long nw = (long)taps * N1 * N2;

@@ -38,10 +38,48 @@ typedef long q256_l2 __attribute__((ext_vector_type(2)));
 constexpr uint32_t Q256_OOB = 0x7FFFFFF0u;
 
 // MT: more than one tap (per-lane tap windows are tested when an X piece is issued)
-template <bool MT>
+// Work-stealing step of gemm_tn_t256_kernel<.., STEAL> (one thread): the next item of a list whose owner has not started, or -1.
+// sm[1] = victims looked at so far (-1 on the first call), sm[0] = result.
+__device__ __attribute__((noinline)) void q256_steal_next(int* sched, int* sm, int G, int self, int q8, int r8, bool had_list) {
+    int item = -1;
+    int* S = sched; int* Nc = sched + 256; int* C = sched + 512;
+    int scan = sm[1];
+    if (scan < 0) {
+        // a workgroup without a list of its own gets here microseconds after the launch: give the others time to announce
+        // themselves before taking anybody's list (12 x 64 x 64 cycles: about 20 us)
+        if (!had_list) for (int d_ = 0; d_ < 12; ++d_) __builtin_amdgcn_s_sleep(64);
+        scan = (__hip_atomic_load(C, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= G) ? G : 0;     // everybody started: nothing to take
+    }
+    while (scan < G) {
+        const int v = (int)(((unsigned)self + (unsigned)scan + 1u) % (unsigned)G);     // the last one looked at is the workgroup itself
+        int st = __hip_atomic_load(&S[v], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (st == 0) st = atomicCAS(&S[v], 0, 2) == 1 ? 1 : 2;
+        if (st == 1) { ++scan; continue; }             // its owner works on it
+        const int xv = v & 7, jv = v >> 3;
+        const int lo_v = xv < r8 ? xv * (q8 + 1) : r8 * (q8 + 1) + (xv - r8) * q8;
+        const int hi_v = lo_v + (xv < r8 ? q8 + 1 : q8);
+        const int nb_v = (G - xv + 7) >> 3;
+        const int k = atomicAdd(&Nc[v], 1);
+        const long it = (long)lo_v + jv + (long)k * nb_v;
+        if (it < hi_v) { item = (int)it; break; }      // stay on this victim
+        ++scan;
+    }
+    sm[1] = scan;
+    sm[0] = item;
+}
+
+// STEAL (GemmTN::sched != null; launched while another stream's resident workgroups -- a collective's channels -- may hold CUs):
+// the static lists stay, but a workgroup that is not placed until others have finished does not hold the launch back.  Every
+// workgroup announces itself at entry (sched[w]: 0 -> 1, one atomic before the pipeline starts); a workgroup that has finished
+// its own list looks for lists whose owner has not started (0 -> 2: from then on that list is handed out item by item through
+// the counter sched[256 + w], to thieves and to its late owner alike) and works them off one item at a time.  When every
+// workgroup has announced itself by the time the first one finishes (sched[512] == gridDim.x) nothing is scanned.  No waiting
+// on flags anywhere: every workgroup reaches its exit.
+template <bool MT, bool STEAL = false>
 __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     constexpr int NST = 32;                            // buffer stores per wave and epilogue
     __shared__ __attribute__((aligned(1024))) unsigned char smem[131072];
+    __shared__ int sched_sm[2];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -58,7 +96,21 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     const int it_lo = xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8;
     const int it_hi = it_lo + (xcd < r8 ? q8 + 1 : q8);
     const int nbx = ((int)gridDim.x - xcd + 7) >> 3;
-    if (it_lo + jb >= it_hi) return;                          // workgroup-uniform
+    // the list being worked on: items ls_first, ls_first + ls_stride, ... < ls_end (the static list first; STEAL: then single items)
+    int ls_first = __builtin_amdgcn_readfirstlane(it_lo + jb), ls_stride = __builtin_amdgcn_readfirstlane(nbx), ls_end = __builtin_amdgcn_readfirstlane(it_hi);
+    bool have = ls_first < ls_end;
+    if constexpr (!STEAL) {
+        if (!have) return;                                    // workgroup-uniform
+    } else {
+        if (tid == 0) {
+            sched_sm[0] = atomicCAS(&p.sched[blockIdx.x], 0, 1);
+            atomicAdd(&p.sched[512], 1);
+            sched_sm[1] = -1;
+        }
+        __syncthreads();
+        if (__builtin_amdgcn_readfirstlane(sched_sm[0]) != 0) have = false;      // placed late: thieves own the list (it is handed out through its counter)
+        __syncthreads();
+    }
 
     const int lda_b = (int)(p.lda * 2), ldx_b = (int)(p.ldb * 2);
     // the X descriptor starts `pad` rows BEFORE the buffer: the tap shift (tap - pad + pad >= 0 rows) goes to the scalar offset and
@@ -90,7 +142,7 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     uint32_t vA0, vA0b, vA1, vA1b, vB0, vB0b, vB1, vB1b;     // (kb + drow [+ 8]) * ld + column bytes of the quarters' two pieces, or out of range
     int t_lane = 0;                        // MT: time index of row l_kt * 64 + kb + drow inside its sample
     // load cursor (wave-uniform)
-    int li = it_lo + jb;
+    int li = ls_first;
     int l_kt = 0, l_kt_end = 0;
     int l_dt = 0;                          // tap - pad of item li
     uint32_t sP = 0, sQ = 0;               // scalar offsets: first row of the K-tile (X: + tap shift + pad) * ld
@@ -146,8 +198,8 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
             sP += (uint32_t)(64 * lda_b); sQ += (uint32_t)(64 * ldx_b);                                       \
             if (MT) { t_lane += 64; if (t_lane >= p.Tlen) t_lane -= p.Tlen; }                                 \
         } else {                                                                                              \
-            li += nbx;                                                                                        \
-            if (li < it_hi) Q256_SETUP_ITEM() else l_active = false;                                          \
+            li += ls_stride;                                                                                  \
+            if (li < ls_end) Q256_SETUP_ITEM() else l_active = false;                                         \
         }                                                                                                     \
     }
 
@@ -317,8 +369,8 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
     const bool early = g == 0;           // the two row halves run half a section out of phase (gemm256.hip)
 
     // ---------------- compute cursor ----------------
-    int ci = it_lo + jb;
-    int c_z, c_tap, c_i0, c_j0, c_nkt;
+    int ci = ls_first;
+    int c_z = 0, c_tap = 0, c_i0 = 0, c_j0 = 0, c_nkt = 0;
 #define Q256_DECODE_C()                                                                                       \
     {                                                                                                         \
         int t1_, t2_;                                                                                         \
@@ -326,6 +378,9 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
         c_i0 = t1_ << 8; c_j0 = t2_ << 8;                                                                     \
         c_nkt = Q256_UNI((int)((long)kts * (c_z + 1) / p.splitk) - (int)((long)kts * c_z / p.splitk));        \
     }
+    for (;;) {          // lists (one pass without STEAL)
+    if (have) {
+    li = ls_first; l_kt = 0; l_kt_end = 0; l_dt = 0; sP = 0; sQ = 0; l_active = true; ci = ls_first;
     Q256_DECODE_C()
 
     // ---------------- prologue: K-tile 0 entirely, the A0 / B0 quarters of K-tile 1 ----------------
@@ -390,8 +445,8 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
                 }
             }
             }
-            ci += nbx;
-            const bool more = ci < it_hi;
+            ci += ls_stride;
+            const bool more = ci < ls_end;
             if (more) Q256_DECODE_C()
             if (wmode != 2) wmode = 1;
             __builtin_amdgcn_sched_barrier(0);
@@ -401,6 +456,19 @@ __global__ __launch_bounds__(512) void gemm_tn_t256_kernel(const GemmTN p) {
             wmode = 0;               // the K-tile after an epilogue is over
         }
     }
+    }   // have
+    if constexpr (!STEAL) return;
+    else {
+        // ---- the next orphaned item, if any (thread 0 asks, everybody follows) ----
+        __syncthreads();                                       // every wave is past its last LDS read
+        if (tid == 0) q256_steal_next(p.sched, sched_sm, (int)gridDim.x, (int)blockIdx.x, q8, r8, it_lo + jb < it_hi);
+        __syncthreads();
+        const int item = __builtin_amdgcn_readfirstlane(sched_sm[0]);      // wave-uniform: scalar registers
+        if (item < 0) return;
+        ls_first = item; ls_stride = nitems + 1; ls_end = item + 1; have = true;
+        __syncthreads();
+    }
+    }   // lists
 }
 
 // =========================================================================================
@@ -443,7 +511,12 @@ int launch_gemm_tn256(const GemmTN& p, hipStream_t s) {
     const int nitems = q256_cdiv(p.N1, 256) * q256_cdiv(p.N2, 256) * p.taps * p.splitk;
     int grid = ((nitems + 7) / 8) * 8;
     if (grid > 256) grid = 256;
-    if (p.taps > 1) hipLaunchKernelGGL(gemm_tn_t256_kernel<true>, dim3(grid), dim3(512), 0, s, q);
-    else hipLaunchKernelGGL(gemm_tn_t256_kernel<false>, dim3(grid), dim3(512), 0, s, q);
+    // work stealing pays from about three rounds of items on (2 rounds: 381 vs 372 us under occupancy, tests/micro/occupy_ab.sh)
+    if (p.sched && (nitems >= 768 || p.force_w2 == 3)) {
+        if (hipMemsetAsync(p.sched, 0, 513 * sizeof(int), s) != hipSuccess) return -2;
+        if (p.taps > 1) hipLaunchKernelGGL((gemm_tn_t256_kernel<true, true>), dim3(grid), dim3(512), 0, s, q);
+        else hipLaunchKernelGGL((gemm_tn_t256_kernel<false, true>), dim3(grid), dim3(512), 0, s, q);
+    } else if (p.taps > 1) hipLaunchKernelGGL((gemm_tn_t256_kernel<true, false>), dim3(grid), dim3(512), 0, s, q);
+    else hipLaunchKernelGGL((gemm_tn_t256_kernel<false, false>), dim3(grid), dim3(512), 0, s, q);
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }

@@ -206,6 +206,8 @@ struct GemmTN {
     // gemm_tn_w2_kernel schedule, filled by launch_gemm_tn: order 1 = persistent walk over an XCD-chunked item list cut into
     // patches of pt1 x pt2 tiles x all taps (see the kernel); 0 = one item per block (round 1's raster)
     int order, pt1, pt2;
+    int* sched;                     // 256 x 256 kernel: 513 ints of device memory for the work-stealing form (gemm256tn.hip, STEAL; zeroed by the
+                                    // launcher), or null = static item lists only
     int out_bf16;                   // 256 x 256 kernel, splitk 1 only: `out` is a bf16 array of the same element layout (the gradient goes to
                                     // the optimizer in bf16: 2 B written and 2 B read per parameter instead of 4 + 4)
 };

@@ -32,7 +32,7 @@ else:
     dY = torch.randn(M, N1, device="cuda").to(torch.bfloat16)
     X = torch.randn(M, N2, device="cuda").to(torch.bfloat16)
     out = torch.empty(taps, N1, N2, device="cuda", dtype=torch.float32)
-    use_tr, sk = int(os.environ.get("USE_TR", "1")), int(os.environ.get("SPLITK", "1"))   # 2 = force the w2 kernel
+    use_tr, sk = int(os.environ.get("USE_TR", "1")), int(os.environ.get("SPLITK", "1"))   # 2 = force the w2 kernel, 4 = the 256 x 256 kernel, 6 = with bf16 output, 7 = its work-stealing form
     def run():
         rc = lib.sgv_test_gemm_tn(1, dY.data_ptr(), X.data_ptr(), out.data_ptr(), M, N1, N2, taps, T, sk, use_tr, None)
         assert rc == 0, lib.sgv_last_error()

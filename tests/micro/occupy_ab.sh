@@ -4,9 +4,11 @@
 R=${GRAFT_REPO_ROOT:-$PWD}; O=$R/gpurun_out/${1:-occupy}; mkdir -p $O; cd $R
 # (weight-gradient shapes only: the nt256 test hook allocates its workspaces, which waits for the spinning workgroups)
 for shape in "tn 3200 5120 5120 5" "tn 3200 1024 95008 1" "tn 3200 95008 1024 1" "tn 3200 2560 2560 5"; do
-  for occ in "" "16,512,0" "32,512,0" "64,512,0" "32,512,65536" "32,1024,0"; do
+  for occ in "" "32,512,0" "16,512,65536" "32,512,65536" "64,512,65536"; do
     echo "== occupy [$occ] $shape" >> $O/occ.txt
-    OCCUPY=$occ python3 tests/micro/gemm_bench.py $shape 5 2>/dev/null | tail -1 >> $O/occ.txt
+    OCCUPY=$occ USE_TR=4 python3 tests/micro/gemm_bench.py $shape 5 2>/dev/null | tail -1 >> $O/occ.txt
+    echo "== occupy [$occ] work-stealing $shape" >> $O/occ.txt
+    OCCUPY=$occ USE_TR=7 python3 tests/micro/gemm_bench.py $shape 5 2>/dev/null | tail -1 >> $O/occ.txt
   done
 done
 cat $O/occ.txt

@@ -3,6 +3,7 @@ difference is fp32 accumulation order).  Called through the C ABI (sgv_test_gemm
 import ctypes as C
 import os
 
+import time
 import numpy as np
 import pytest
 
@@ -449,6 +450,35 @@ def test_gemm_tn256_bf16_output(case):
     assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, 1, 6, None) == 0, lib.sgv_last_error()
     assert torch.equal(out[:n].view(taps, N1, N2), ref32.to(torch.bfloat16))
     assert bool((out[n:] == -7.0).all())
+
+
+@pytest.mark.parametrize("case", [TN256_CASES[0], TN256_CASES[2], TN256_CASES[3], TN256_CASES[4], TN256_CASES[7], (3200, 2560, 2560, 5, 200, 1)])
+@pytest.mark.parametrize("occupied", [0, 48])
+def test_gemm_tn256_work_stealing(case, occupied):
+    """The work-stealing form of the 256 x 256 weight-gradient kernel (GemmTN::sched; what a data-parallel backward launches while a
+    collective's channel workgroups may hold CUs): bitwise the static kernel's result -- on a free chip (nobody is late: nothing is
+    taken) and with `occupied` workgroups of 512 threads and 64 KiB of LDS spinning on another stream for 3 ms, so that as many of
+    the kernel's workgroups are placed late, find their lists taken and join the thieves.  Shapes: one item (seven of eight
+    workgroups have no list), 90 and 16 items (grid < 256), 372 items, split-K, 550 and 500 items with taps."""
+    import torch
+    lib = E.load_library()
+    M, N1, N2, taps, Tlen, splitk = case
+    rng = np.random.default_rng(31)
+    dY = _bf16_round(rng.standard_normal((M, N1)).astype(np.float32))
+    X = _bf16_round(rng.standard_normal((M, N2)).astype(np.float32))
+    ddY, dX = _dev(dY, 1), _dev(X, 1)
+    ref = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+    assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), ref.data_ptr(), M, N1, N2, taps, Tlen, splitk, 4, None) == 0, lib.sgv_last_error()
+    side = torch.cuda.Stream()
+    for rep in range(3):
+        out = torch.full((taps, N1, N2), float("nan"), dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        if occupied:
+            assert lib.sgv_test_occupy(side.cuda_stream, occupied, 512, 65536, 300000) == 0, lib.sgv_last_error()
+            time.sleep(0.0005)
+        assert lib.sgv_test_gemm_tn(1, ddY.data_ptr(), dX.data_ptr(), out.data_ptr(), M, N1, N2, taps, Tlen, splitk, 7, None) == 0, lib.sgv_last_error()
+        torch.cuda.synchronize()
+        assert torch.equal(out, ref), (case, occupied, rep)
 
 
 @pytest.mark.parametrize("case", [(520, 320, 1024, 5, 40, 2), (640, 512, 2048, 1, 128, 1), (400, 1024, 640, 5, 200, 1),
