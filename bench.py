@@ -438,9 +438,10 @@ def main():
                     o["traffic"] = round((t["fetch_bytes"] + t["write_bytes"]) / t["launches"])
                     o["traffic_source"] = traffic.get("_source")
                 return o
-            acct = ("achieved = sum over its launches of 2*M*N*K*taps / sum of hipEvent durations of the launch's kernels (main kernel + "
-                    "its split-K combine and its 128-row tail launch for M = 3200); traffic = (FETCH_SIZE x2 + WRITE_SIZE) per "
-                    "launch from the committed rocprofv3 --pmc passes")
+            acct = ("achieved = sum over its launches of 2*M*N*K*taps / sum of hipEvent durations of the launch groups on the main stream (main "
+                    "kernel + its split-K combine + the 128-row tail of M = 3200: a second launch behind the main one, or -- K = 95008 and "
+                    "2560^2 x 5 -- a 16-workgroup launch of the 128x512 tile shape BESIDE it on the lane stream, joined before the second event); "
+                    "traffic = (FETCH_SIZE x2 + WRITE_SIZE) per launch from the committed rocprofv3 --pmc passes")
             result["roofline"] = roof_obj(
                 "gemm_nt_t256", "gemm_nt_t256_kernel (conv forward / input-gradient implicit GEMM: 256x256 tiles, persistent, 8 waves, "
                 "quarter-refilled LDS-DMA double buffer)", acct) or result["roofline"]

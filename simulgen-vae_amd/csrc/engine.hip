@@ -913,7 +913,8 @@ static bool conv_fwd_fuses_stats(sgv_engine* e, const Layer& l, const Tensor& x,
 static int launch_nt(sgv_engine* e, const GemmNT& p, const GemmPlan& pl) {
     // not while a collective may be resident: the tail takes exactly the CUs the main launch leaves free, and a static item list that
     // finds fewer CUs than items runs a second round
-    if (e->use_lanes && e->lane2 && e->tail_fork && !e->timing && e->stream != e->lane2 && !e->coll_inflight) {
+    // (kernel-timing passes take it too: the timer brackets the launch group on the main stream, join included)
+    if (e->use_lanes && e->lane2 && e->tail_fork && e->stream != e->lane2 && !e->coll_inflight) {
         const int sk_t = gemm_nt_tail_split(e->dt, p, pl, e->partial_floats);
         if (sk_t > 0) {
             HIPCHK(hipEventRecord(e->tail_fork, e->stream));
