@@ -2609,12 +2609,12 @@ static AdamCoef adam_coef(const sgv_engine* e) {
 static int adamw_tiles(sgv_engine* e, float lr, int t0, int t1, hipStream_t st, bool from_lp) {
     if (t1 <= t0) return 0;
     const AdamCoef c = adam_coef(e);
-    // Beside the backward pass (any stream but the main one) the pass goes out in slices of a few thousand 64 x 64 tiles: its
+    // Beside the backward pass (any stream but the main one) the pass goes out in slices of 3072 64 x 64 tiles: its
     // workgroups are small and short-lived, so while one launch lasts they refill every CU the moment a slot frees, and a kernel of
     // the main stream whose workgroup needs most of a CU's LDS (the 128-row GEMM tails, the fused Conv+GroupNorm stages) is not
     // placed until the launch ends -- a kernel trace showed a 60 us tail taking 816 us beside a 1.3 ms AdamW launch.  At a launch
     // boundary the chip drains, and the waiting workgroups get their CUs.
-    static const int slice_env = getenv("SGV_ADAM_SLICE") ? atoi(getenv("SGV_ADAM_SLICE")) : 2048;
+    static const int slice_env = getenv("SGV_ADAM_SLICE") ? atoi(getenv("SGV_ADAM_SLICE")) : 3072;      // re-tuned on the final build: 2048 / 2560 / 3072 / 3584 = 11.16 / 11.11 / 11.10 / 11.11 ms
     const int slice = (st != e->stream && slice_env > 0) ? slice_env : t1 - t0;
     for (int a = t0; a < t1; a += slice) {
         const int b = std::min(t1, a + slice);
