@@ -40,11 +40,27 @@ __global__ __launch_bounds__(256) void sn_tsum_kernel(const SNDesc* descs, const
     const long i = (long)it.chunk * 64 + cq * 4;
     const int rb = (d.rows + SN_ROWS_PER_ITEM - 1) / SN_ROWS_PER_ITEM;
     float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (i < n)
-        for (int r = rl; r < rb; r += 16) {
+    if (i < n) {
+        // four independent chains (the recon head has 1485 row blocks: 93 dependent adds per lane otherwise, one load in flight each)
+        float4 a1 = a, a2 = a, a3 = a;
+        int r = rl;
+        for (; r + 48 < rb; r += 64) {
+            const float4 v0 = *reinterpret_cast<const float4*>(d.tpart + (long)r * n + i);
+            const float4 v1 = *reinterpret_cast<const float4*>(d.tpart + (long)(r + 16) * n + i);
+            const float4 v2 = *reinterpret_cast<const float4*>(d.tpart + (long)(r + 32) * n + i);
+            const float4 v3 = *reinterpret_cast<const float4*>(d.tpart + (long)(r + 48) * n + i);
+            a.x += v0.x; a.y += v0.y; a.z += v0.z; a.w += v0.w;
+            a1.x += v1.x; a1.y += v1.y; a1.z += v1.z; a1.w += v1.w;
+            a2.x += v2.x; a2.y += v2.y; a2.z += v2.z; a2.w += v2.w;
+            a3.x += v3.x; a3.y += v3.y; a3.z += v3.z; a3.w += v3.w;
+        }
+        for (; r < rb; r += 16) {
             const float4 v = *reinterpret_cast<const float4*>(d.tpart + (long)r * n + i);
             a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
         }
+        a.x = (a.x + a1.x) + (a2.x + a3.x); a.y = (a.y + a1.y) + (a2.y + a3.y);
+        a.z = (a.z + a1.z) + (a2.z + a3.z); a.w = (a.w + a1.w) + (a2.w + a3.w);
+    }
     sm[rl][cq] = a;
     __syncthreads();
     if (rl == 0 && i < n) {
